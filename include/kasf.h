@@ -1,0 +1,123 @@
+/* libkasf_hip -- C-ABI of the MI355X-native (gfx950) KASportsFormer forward/backward path.
+ *
+ * The reference (jw0r1n/KASportsFormer) is pure Python/PyTorch: its "FFI" for this path is the
+ * nn.Module call  KASportsFormer.forward(x[B,T,17,3]) -> [B,T,17,3]  plus autograd.  This header is
+ * the boundary a reference maintainer binds instead (ctypes stub in INTEGRATION.md): plain pointers
+ * and sizes, no torch types.  All pointers are DEVICE pointers owned by the caller (torch's caching
+ * allocator in the shipped host code); `stream` is a hipStream_t passed as void*.  Nothing here
+ * allocates, frees or synchronises in the hot path (graph-capture safe); only kasf_model_create()
+ * allocates a few KB of device tables.
+ *
+ * Every function returns 0 on success or a non-zero code; kasf_last_error() describes it.
+ *
+ * Reference interfaces replaced (paths relative to the reference checkout):
+ *   kasf_model_create      <- KASportsFormer.__init__             model/KASportsFormer.py:291-318
+ *   kasf_param_*           <- nn.Module.state_dict() layout       model/KASportsFormer.py:296-318 (names identical)
+ *   kasf_forward           <- KASportsFormer.forward              model/KASportsFormer.py:320-347
+ *   kasf_backward          <- torch.autograd of the above         train_and_evaluate_sp.py:241  (loss.backward())
+ *   kasf_loss3             <- mpjpe + 0.5 n_mpjpe + 20 velocity   utils/loss_calc.py:6-27, train_and_evaluate_sp.py:212-222
+ *   kasf_adamw_step        <- optim.AdamW(...).step()             train_and_evaluate_sp.py:270-272,243
+ *   kasf_op_*              <- the individual nn.Modules under model/modules/ (unit-test entry points)
+ */
+#ifndef KASF_H_
+#define KASF_H_
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KASF_DTYPE_F32 0   /* parity mode: fp32 storage, exact-f32 MFMA (v_mfma_f32_16x16x4_f32) */
+#define KASF_DTYPE_BF16 1  /* fast mode: bf16 activations/weights, fp32 accumulate/statistics/master weights */
+
+#define KASF_FLAG_TRAIN 1       /* BatchNorm batch statistics + running-stat update; keep activations for backward */
+#define KASF_FLAG_RETURN_REP 2  /* out is the [B,T,17,512] tanh representation (forward(x, return_rep=True)) */
+
+typedef struct kasf_model kasf_model;
+
+typedef struct kasf_config {
+    int32_t n_layers;            /* 26 in the shipped yaml (configs/sportspose-gt-kasportsformer.yaml:71) */
+    int32_t n_frames;            /* T: 27 or 81 (9 for tests) -- sizes the temporal BatchNorm1d and kernels */
+    int32_t num_heads;           /* must be 8 (yaml :84); head dim 16 */
+    int32_t neighbour_num;       /* top-k of the temporal GCN adjacency, 1..4 (yaml :89: 4) */
+    int32_t use_adaptive_fusion; /* 1: softmax gate, 0: plain mean (KASportsFormer.py:284) */
+    int32_t dtype;               /* KASF_DTYPE_* */
+} kasf_config;
+
+const char* kasf_last_error(void);
+int kasf_version(void);
+
+int kasf_model_create(const kasf_config* cfg, kasf_model** out);
+void kasf_model_destroy(kasf_model* m);
+
+/* ---- parameter / buffer layout: one flat fp32 array each; entries carry the reference's state_dict names ---- */
+int64_t kasf_param_count(const kasf_model* m);       /* elements of the flat parameter (and gradient) array, multiple of 4 */
+int64_t kasf_param_live_count(const kasf_model* m);  /* [0, live) receive gradients; [live, count) are the never-used norm1_limb */
+int32_t kasf_param_entries(const kasf_model* m);
+int kasf_param_entry(const kasf_model* m, int32_t idx, char* name, int32_t name_cap, int64_t* offset, int32_t* ndim, int64_t shape[4]);
+int64_t kasf_buffer_count(const kasf_model* m);      /* BatchNorm running_mean / running_var, fp32 */
+int32_t kasf_buffer_entries(const kasf_model* m);
+int kasf_buffer_entry(const kasf_model* m, int32_t idx, char* name, int32_t name_cap, int64_t* offset, int32_t* ndim, int64_t shape[4]);
+/* gradient ranges that become final after each backward stage (data-parallel all-reduce buckets) */
+int32_t kasf_backward_stages(const kasf_model* m);   /* n_layers + 2: head, layers (last to first), prologue */
+int kasf_stage_grad_range(const kasf_model* m, int32_t stage, int64_t* begin, int64_t* end);
+
+/* ---- kernel-side weight arena (dtype of the model; transposed / layer-scale-folded copies) ---- */
+int64_t kasf_packed_bytes(const kasf_model* m);
+int kasf_pack_weights(const kasf_model* m, const float* params, void* packed, void* stream);
+
+/* ---- workspace (activations kept for backward + scratch); caller allocates, 256-B aligned ---- */
+int64_t kasf_workspace_bytes(const kasf_model* m, int32_t batch, int32_t flags);
+
+/* x [B,T,17,3] fp32 -> out [B,T,17,3] fp32 (or [B,T,17,512] with KASF_FLAG_RETURN_REP).
+ * `buffers` (BN running stats) is updated when KASF_FLAG_TRAIN is set.  x and out must not alias. */
+int kasf_forward(const kasf_model* m, const float* params, const void* packed, float* buffers, const float* x, float* out, void* workspace,
+                 int64_t workspace_bytes, int32_t batch, int32_t flags, void* stream);
+
+/* Gradients of a preceding kasf_forward(KASF_FLAG_TRAIN) on the same workspace.  dout [B,T,17,3] fp32.
+ * Accumulates (+=) into grads[0, live); the caller zeroes it.  Stages [stage_begin, stage_end) of
+ * kasf_backward_stages() are run; call with (0, stages) for the whole backward, or stage by stage to
+ * overlap the gradient all-reduce of finished ranges. */
+int kasf_backward(const kasf_model* m, const float* params, const void* packed, const float* dout, float* grads, void* workspace,
+                  int64_t workspace_bytes, int32_t batch, int32_t stage_begin, int32_t stage_end, void* stream);
+
+/* losses[4] = {total, mpjpe, n_mpjpe, velocity}; dpred = grad_scale * dTotal/dpred */
+int kasf_loss3(const float* pred, const float* target, float* dpred, float* losses, int32_t batch, int32_t n_frames, float lambda_n_mpjpe,
+               float lambda_velocity, float grad_scale, void* stream);
+
+/* torch.optim.AdamW step over n contiguous fp32 elements (n multiple of 4); step_index starts at 1 */
+int kasf_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2, float eps,
+                    float weight_decay, int32_t step_index, float grad_scale, void* stream);
+
+/* debugging / tests: locate a named activation inside the workspace (see kasf_ws_name()) */
+int32_t kasf_ws_entries(const kasf_model* m, int32_t batch, int32_t flags);
+int kasf_ws_entry(const kasf_model* m, int32_t batch, int32_t flags, int32_t idx, char* name, int32_t name_cap, int64_t* byte_offset,
+                  int64_t* numel, int32_t* elem_kind /* 0: model dtype, 1: fp32, 2: fp64, 3: u32 */);
+
+/* ---- single-operator entry points (tensors of the model dtype are void*; M = tokens) ---- */
+/* y = act(LN?(a) W^T + bias): a [M,128], w [N,128] (dtype), N % 128 == 0; ln_g == NULL -> no LayerNorm; act 0 none, 1 tanh */
+int kasf_op_linear(int32_t dtype, const void* a, const void* w, const float* bias, void* y, int64_t M, int32_t N, const float* ln_g, const float* ln_b,
+                   void* xn_out, int32_t act, void* stream);
+/* modules/mlp.py inside a FormerModule: out = x + ls2 * (GELU(LN(x) W1^T + b1) W2^T + b2) */
+int kasf_op_mlp_fwd(int32_t dtype, const void* x, const float* ln_g, const float* ln_b, const void* w1, const float* b1, const void* w2, const float* b2,
+                    const float* ls2, void* out, int64_t M, void* stream);
+int kasf_op_mlp_bwd(int32_t dtype, const void* x, const void* g, const float* ln_g, const float* ln_b, const void* w1, const float* b1,
+                    const void* w2t_scaled, const void* w1t, void* hbuf, void* dzbuf, void* g_in, float* dgamma, float* dbeta, int64_t M, void* stream);
+/* dW[N,K] += G^T LN?(X), dbias[N] += colsum(G): G [M,N], X [M,K] */
+int kasf_op_wgrad(int32_t dtype, const void* g, int32_t N, const void* x, int32_t K, const float* ln_g, const float* ln_b, float* dw, float* dbias,
+                  int64_t M, void* stream);
+/* g_in = [resid] + LNbwd(dY Wt^T [+ add]): dY [M,Kd], Wt [128,Kd] */
+int kasf_op_dgrad_lnbwd(int32_t dtype, const void* dy, int32_t Kd, const void* wt, const void* dxn_add, const void* x, const float* gamma,
+                        const void* resid, void* out, int32_t accumulate, float* dgamma, float* dbeta, int64_t M, void* stream);
+/* attention core (selfattention.py:18-41): q [*,ldq], k/v [*,ldkv] token-major; mode 0 spatial, 1 temporal */
+int kasf_op_attention_fwd(int32_t dtype, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, void* o, int32_t batch, int32_t n_frames,
+                          int32_t mode, void* stream);
+int kasf_op_attention_bwd(int32_t dtype, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, const void* d_o, void* dq, int64_t lddq,
+                          void* dk, void* dv, int64_t lddkv, int32_t batch, int32_t n_frames, int32_t mode, void* stream);
+/* fp32 <-> model dtype */
+int kasf_op_cast(int32_t dtype, const void* src, void* dst, int64_t n, int32_t to_f32, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KASF_H_ */

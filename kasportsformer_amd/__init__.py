@@ -1,0 +1,14 @@
+"""kasportsformer_amd -- MI355X-native (gfx950) forward/backward path of KASportsFormer.
+
+Public surface mirrors the reference's interface for this path:
+  KASportsFormer, load_model            model/KASportsFormer.py:290, model/model_tools.py:79
+  loss3, mpjpe_loss / ...               utils/loss_calc.py:6-27 (+ the train-step combination)
+  FusedAdamW                            optim.AdamW as used in train_and_evaluate_sp.py:270-272
+  DataParallel                          nn.DataParallel replacement: one process per GPU, RCCL all-reduce
+"""
+from .model import KASportsFormer, load_model
+from .functional import loss3
+from .optim import FusedAdamW
+from .parallel import DataParallel
+
+__all__ = ["KASportsFormer", "load_model", "loss3", "FusedAdamW", "DataParallel"]

@@ -1,0 +1,218 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of the KASportsFormer path.
+// Everything here is written for 64-wide wavefronts and the 16x16 MFMA shapes:
+//   bf16 : v_mfma_f32_16x16x32_bf16  (8 k per lane)          -- fast mode
+//   f32  : v_mfma_f32_16x16x4_f32    (exact f32, 1 k per lane) -- parity mode
+// Both share the C/D map  col = lane&15, row = 4*(lane>>4)+reg.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+#define KASF_C 128          // dim_feat
+#define KASF_J 17           // joints
+#define KASF_H 8            // heads
+#define KASF_D 16           // head dim
+#define KASF_LN_EPS 1e-5f
+
+__device__ __forceinline__ float to_f(float x) { return x; }
+__device__ __forceinline__ float to_f(bf16 x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f(float x);
+template <> __device__ __forceinline__ float from_f<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16 from_f<bf16>(float x) { return (bf16)x; }
+
+// ---- 8 consecutive elements <-> 8 floats (16 B for bf16, 2 x 16 B for f32) ----
+__device__ __forceinline__ void load8(const bf16* p, float (&v)[8]) {
+    bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)t[i];
+}
+__device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[4 + i] = b[i]; }
+}
+__device__ __forceinline__ void store8(bf16* p, const float (&v)[8]) {
+    bf16x8 t;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = (bf16)v[i];
+    *reinterpret_cast<bf16x8*>(p) = t;
+}
+__device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
+    f32x4 a, b;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a[i] = v[i]; b[i] = v[4 + i]; }
+    *reinterpret_cast<f32x4*>(p) = a;
+    *reinterpret_cast<f32x4*>(p + 4) = b;
+}
+__device__ __forceinline__ void store4(bf16* p, const float (&v)[4]) {
+    bf16x4 t;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t[i] = (bf16)v[i];
+    *reinterpret_cast<bf16x4*>(p) = t;
+}
+__device__ __forceinline__ void store4(float* p, const float (&v)[4]) {
+    f32x4 a;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = v[i];
+    *reinterpret_cast<f32x4*>(p) = a;
+}
+
+// reduce over an aligned group of 16 lanes
+__device__ __forceinline__ float reduce16(float v) {
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8);
+    return v;
+}
+__device__ __forceinline__ float reduce64(float v) {
+    v = reduce16(v);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+
+// ------------------------------------------------------------------------------------------
+// LDS tile of [rows][128] elements, 16-byte chunks XOR-swizzled by (row & 15): a ds_read_b128
+// by 16 lanes reading the same chunk of 16 different rows is then bank-conflict free.
+// ------------------------------------------------------------------------------------------
+template <typename T> struct Tile {
+    static constexpr int EPC = 16 / sizeof(T);      // elements per 16-B chunk (8 / 4)
+    static constexpr int CPR = 128 / EPC;           // chunks per row (16 / 32)
+    __device__ static __forceinline__ int chunk_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 15)) * EPC); }
+    // offset of element (row, col), col a multiple of 4 (never crosses a chunk)
+    __device__ static __forceinline__ int off4(int row, int col) { return chunk_off(row, col / EPC) + (col % EPC); }
+};
+
+// Write 8 consecutive elements (col0 multiple of 8) of one tile row.
+__device__ __forceinline__ void tile_store8(bf16* s, int row, int col0, const float (&v)[8]) {
+    store8(s + Tile<bf16>::chunk_off(row, col0 / 8), v);
+}
+__device__ __forceinline__ void tile_store8(float* s, int row, int col0, const float (&v)[8]) {
+    float a[4] = {v[0], v[1], v[2], v[3]}, b[4] = {v[4], v[5], v[6], v[7]};
+    store4(s + Tile<float>::chunk_off(row, col0 / 4), a);
+    store4(s + Tile<float>::chunk_off(row, col0 / 4 + 1), b);
+}
+__device__ __forceinline__ void tile_load8(const bf16* s, int row, int col0, float (&v)[8]) {
+    load8(s + Tile<bf16>::chunk_off(row, col0 / 8), v);
+}
+__device__ __forceinline__ void tile_load8(const float* s, int row, int col0, float (&v)[8]) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(s + Tile<float>::chunk_off(row, col0 / 4));
+    f32x4 b = *reinterpret_cast<const f32x4*>(s + Tile<float>::chunk_off(row, col0 / 4 + 1));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[4 + i] = b[i]; }
+}
+
+// ------------------------------------------------------------------------------------------
+// One 128-deep MFMA sweep.  sW rows are output features n (the MFMA "A" operand), sX rows are
+// tokens m (the "B" operand); acc[nt][mt][r] = C[m = x_row0+16mt+(lane&15)][n = w_row0+16nt+4(lane>>4)+r].
+// Each lane thus owns 4 consecutive output features of one token (vector stores in the epilogue).
+// ------------------------------------------------------------------------------------------
+template <int NT, int MT>
+__device__ __forceinline__ void mma_k128(const bf16* sW, int w_row0, const bf16* sX, int x_row0, f32x4 (&acc)[NT][MT]) {
+    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        bf16x8 a[NT], b[MT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) a[nt] = *reinterpret_cast<const bf16x8*>(sW + Tile<bf16>::chunk_off(w_row0 + nt * 16 + i, 4 * s + g));
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) b[mt] = *reinterpret_cast<const bf16x8*>(sX + Tile<bf16>::chunk_off(x_row0 + mt * 16 + i, 4 * s + g));
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[nt], b[mt], acc[nt][mt], 0, 0, 0);
+    }
+}
+template <int NT, int MT>
+__device__ __forceinline__ void mma_k128(const float* sW, int w_row0, const float* sX, int x_row0, f32x4 (&acc)[NT][MT]) {
+    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {   // lane group g supplies k = 16s + 4g + r in MFMA r (same bijection on both operands)
+        f32x4 a[NT], b[MT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) a[nt] = *reinterpret_cast<const f32x4*>(sW + Tile<float>::chunk_off(w_row0 + nt * 16 + i, 4 * s + g));
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) b[mt] = *reinterpret_cast<const f32x4*>(sX + Tile<float>::chunk_off(x_row0 + mt * 16 + i, 4 * s + g));
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[nt][r], b[mt][r], acc[nt][mt], 0, 0, 0);
+    }
+}
+
+template <int NT, int MT> __device__ __forceinline__ void zero_acc(f32x4 (&acc)[NT][MT]) {
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < MT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// ------------------------------------------------------------------------------------------
+// Stage BM token rows x 128 channels (global row stride ld) into a swizzled tile with an
+// optional fused LayerNorm (two-pass variance, eps inside the sqrt).  256 threads: 16 lanes own
+// one row (8 channels each), 16 rows per sweep.  Rows >= M are zero filled.
+// ------------------------------------------------------------------------------------------
+template <typename T, int BM, bool LN>
+__device__ __forceinline__ void stage_rows(T* sA, const T* X, int64_t ld, int64_t row0, int64_t M, const float* gamma, const float* beta,
+                                           T* xn_out) {
+    const int sub = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    float gm[8], bt[8];
+    if (LN) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { gm[i] = gamma[sub * 8 + i]; bt[i] = beta[sub * 8 + i]; }
+    }
+#pragma unroll 2
+    for (int r = rl; r < BM; r += 16) {
+        const int64_t row = row0 + r;
+        float v[8];
+        if (row < M) load8(X + row * ld + sub * 8, v);
+        else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = 0.f;
+        }
+        if (LN) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s += v[i];
+            const float mean = reduce16(s) * (1.0f / 128.0f);
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { v[i] -= mean; q += v[i] * v[i]; }
+            const float rstd = rsqrtf(reduce16(q) * (1.0f / 128.0f) + KASF_LN_EPS);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = (row < M) ? v[i] * rstd * gm[i] + bt[i] : 0.f;
+            if (xn_out != nullptr && row < M) store8(xn_out + row * 128 + sub * 8, v);
+        }
+        tile_store8(sA, r, sub * 8, v);
+    }
+}
+
+// Stage a 128 x 128 weight block W[n0 + r][k0 + c] (row stride ldw) into a swizzled tile.
+template <typename T> __device__ __forceinline__ void stage_w(T* sB, const T* W, int64_t ldw) {
+    constexpr int EPC = Tile<T>::EPC, CPR = Tile<T>::CPR;
+#pragma unroll 4
+    for (int idx = threadIdx.x; idx < 128 * CPR; idx += 256) {
+        const int row = idx / CPR, ch = idx % CPR;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(W + (int64_t)row * ldw + ch * EPC);
+        *reinterpret_cast<f32x4*>(sB + Tile<T>::chunk_off(row, ch)) = v;
+    }
+}
+
+#define HIP_OK(x)                                                                 \
+    do {                                                                          \
+        hipError_t e_ = (x);                                                      \
+        if (e_ != hipSuccess) return kasf_set_error(1000 + (int)e_, hipGetErrorString(e_)); \
+    } while (0)

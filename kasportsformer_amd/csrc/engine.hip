@@ -1,0 +1,689 @@
+// Host-side engine of libkasf_hip: parameter layout (reference state_dict names), packed-weight table,
+// workspace plan and the forward / backward launch sequences of the KASportsFormer path
+// (reference: model/KASportsFormer.py:204-347).  Pure launch code: no allocation, no synchronisation.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kasf.h"
+#include "kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+struct Entry { std::string name; int64_t off; int ndim; int64_t shape[4]; };
+
+enum { KIND_ATT = 0, KIND_GRAPH = 1, KIND_BONE = 2 };
+const char* const BLOCK_NAMES[6] = {"att_spatial", "att_temporal", "graph_spatial", "graph_temporal", "bone_spatial", "bone_temporal"};
+const int BLOCK_KIND[6] = {KIND_ATT, KIND_ATT, KIND_GRAPH, KIND_GRAPH, KIND_BONE, KIND_BONE};
+// modules/bone_refusion.py:34-40 -- sizes of the 17 joint groups
+const int LIMB_N[17] = {3, 3, 2, 2, 3, 3, 4, 4, 4, 4, 3, 4, 4, 4, 4, 2, 2};
+
+struct BlockOff {
+    int kind, mode, nodes;
+    int64_t ls1, ls2, n1w, n1b, n1lw, n1lb, n2w, n2b, fc1w, fc1b, fc2w, fc2b;
+    int64_t mix_w, kv_w, proj_w, proj_b, uv_b, bn_w, bn_b;   // mix_w: qkv.weight | qkv_q.weight | U.weight(+V.weight)
+    int64_t bn_rm, bn_rv;                                     // offsets into the buffer array
+    int64_t p_mix, p_mixT, p_kv, p_kvT, p_proj, p_projTs, p_fc1, p_fc1T, p_fc2, p_fc2Ts;   // packed arena (elements)
+};
+struct LayerOff { BlockOff blk[6]; int64_t fus_w, fus_b, begin, end; };
+struct TopOff { int64_t norm_w, norm_b, fc_w, fc_b, head_w, head_b, p_fc, p_fcT, begin, end; };
+
+struct BlkWs { int64_t qkv, kv, o, xn, y, mask, x_mid, x_out, stats, bstats, coef; };
+struct LayerWs { BlkWs b[6]; int64_t gate_out, alpha; };
+struct WsEntry { std::string name; int64_t off, numel; int kind; };
+struct Plan {
+    int64_t total = 0, stats_begin = 0, stats_bytes = 0, bstats_begin = 0, bstats_bytes = 0;
+    int64_t x3, bone3, limb3, xj, xb, xl, rep, uv;
+    std::vector<LayerWs> layers;
+    int64_t g_layer, g_prev, ga, gg, gb, t1, t2, g_limb, g_bone, hbuf, dzbuf, d_o, dqkv, rbuf, duv, dlimb3;
+    std::vector<WsEntry> entries;
+};
+
+}  // namespace
+
+struct kasf_model {
+    kasf_config cfg;
+    std::vector<Entry> params, buffers;
+    std::vector<LayerOff> layers;
+    TopOff top;
+    KasfProOff pro;
+    int64_t n_params = 0, n_live = 0, n_buffers = 0, arena_elems = 0;
+    std::vector<KasfPackDesc> pack;
+    std::vector<int> pack_tile_start;
+    int pack_tiles = 0;
+    // device tables
+    KasfPackDesc* d_pack = nullptr;
+    int* d_tile_start = nullptr;
+    KasfProOff* d_pro = nullptr;
+};
+
+int kasf_set_error(int code, const char* msg) {
+    g_err = msg ? msg : "";
+    return code;
+}
+
+namespace {
+
+#define HIPCHK(x)                                                                           \
+    do {                                                                                    \
+        hipError_t e_ = (x);                                                                \
+        if (e_ != hipSuccess) return kasf_set_error(1000 + (int)e_, hipGetErrorString(e_)); \
+    } while (0)
+
+struct Alloc {
+    std::vector<Entry>* out;
+    int64_t cur = 0;
+    int64_t add(const std::string& name, std::initializer_list<int64_t> shape) {
+        cur = (cur + 3) & ~int64_t(3);
+        Entry e;
+        e.name = name;
+        e.off = cur;
+        e.ndim = (int)shape.size();
+        int64_t n = 1;
+        int i = 0;
+        for (int64_t s : shape) { e.shape[i++] = s; n *= s; }
+        for (; i < 4; ++i) e.shape[i] = 1;
+        out->push_back(e);
+        cur += n;
+        return e.off;
+    }
+};
+
+void build_layout(kasf_model* m) {
+    const int L = m->cfg.n_layers, T = m->cfg.n_frames;
+    Alloc A{&m->params};
+    Alloc B{&m->buffers};
+    int64_t arena = 0;
+    auto packd = [&](int64_t src, int rows, int cols, int64_t scale, int transpose) {
+        KasfPackDesc d{src, arena, scale, rows, cols, transpose, 0};
+        m->pack.push_back(d);
+        const int64_t at = arena;
+        arena += (int64_t)rows * cols;
+        return at;
+    };
+    m->layers.resize(L);
+    for (int l = 0; l < L; ++l) {
+        LayerOff& lo = m->layers[l];
+        lo.begin = (A.cur + 3) & ~int64_t(3);
+        for (int b = 0; b < 6; ++b) {
+            BlockOff& o = lo.blk[b];
+            memset(&o, 0xff, sizeof(o));
+            o.kind = BLOCK_KIND[b];
+            o.mode = b & 1;
+            o.nodes = o.mode == 0 ? 17 : T;
+            const std::string p = "layers_with_bone." + std::to_string(l) + "." + BLOCK_NAMES[b] + ".";
+            o.ls1 = A.add(p + "layer_scale_1", {128});
+            o.ls2 = A.add(p + "layer_scale_2", {128});
+            o.n1w = A.add(p + "norm1.weight", {128});
+            o.n1b = A.add(p + "norm1.bias", {128});
+            if (o.kind == KIND_BONE) {
+                o.n1lw = A.add(p + "norm1_limb.weight", {128});
+                o.n1lb = A.add(p + "norm1_limb.bias", {128});
+            }
+            o.n2w = A.add(p + "norm2.weight", {128});
+            o.n2b = A.add(p + "norm2.bias", {128});
+            if (o.kind == KIND_ATT) {
+                o.mix_w = A.add(p + "mixer.qkv.weight", {384, 128});
+                o.proj_w = A.add(p + "mixer.proj.weight", {128, 128});
+                o.proj_b = A.add(p + "mixer.proj.bias", {128});
+                o.p_mix = packd(o.mix_w, 384, 128, -1, 0);
+                o.p_mixT = packd(o.mix_w, 384, 128, -1, 1);
+            } else if (o.kind == KIND_BONE) {
+                o.mix_w = A.add(p + "mixer.qkv_q.weight", {128, 128});
+                o.kv_w = A.add(p + "mixer.qkv_kv.weight", {256, 128});
+                o.proj_w = A.add(p + "mixer.proj.weight", {128, 128});
+                o.proj_b = A.add(p + "mixer.proj.bias", {128});
+                o.p_mix = packd(o.mix_w, 128, 128, -1, 0);
+                o.p_mixT = packd(o.mix_w, 128, 128, -1, 1);
+                o.p_kv = packd(o.kv_w, 256, 128, -1, 0);
+                o.p_kvT = packd(o.kv_w, 256, 128, -1, 1);
+            } else {
+                o.mix_w = A.add(p + "mixer.U.weight", {128, 128});     // U then V: one [256,128] operand
+                A.add(p + "mixer.V.weight", {128, 128});
+                o.uv_b = A.add(p + "mixer.U.bias", {128});
+                A.add(p + "mixer.V.bias", {128});
+                o.bn_w = A.add(p + "mixer.batch_norm.weight", {o.nodes});
+                o.bn_b = A.add(p + "mixer.batch_norm.bias", {o.nodes});
+                o.bn_rm = B.add(p + "mixer.batch_norm.running_mean", {o.nodes});
+                o.bn_rv = B.add(p + "mixer.batch_norm.running_var", {o.nodes});
+                o.p_mix = packd(o.mix_w, 256, 128, -1, 0);
+                o.p_mixT = packd(o.mix_w, 256, 128, -1, 1);
+            }
+            if (o.kind != KIND_GRAPH) {
+                o.p_proj = packd(o.proj_w, 128, 128, -1, 0);
+                o.p_projTs = packd(o.proj_w, 128, 128, o.ls1, 1);      // (ls1 . Wproj)^T for the dgrad
+            }
+            o.fc1w = A.add(p + "mlp.fc1.weight", {512, 128});
+            o.fc1b = A.add(p + "mlp.fc1.bias", {512});
+            o.fc2w = A.add(p + "mlp.fc2.weight", {128, 512});
+            o.fc2b = A.add(p + "mlp.fc2.bias", {128});
+            o.p_fc1 = packd(o.fc1w, 512, 128, -1, 0);
+            o.p_fc1T = packd(o.fc1w, 512, 128, -1, 1);
+            o.p_fc2 = packd(o.fc2w, 128, 512, -1, 0);
+            o.p_fc2Ts = packd(o.fc2w, 128, 512, o.ls2, 1);             // (ls2 . W2)^T
+        }
+        const std::string p = "layers_with_bone." + std::to_string(l) + ".fusion_three_channel.";
+        lo.fus_w = A.add(p + "weight", {3, 384});
+        lo.fus_b = A.add(p + "bias", {3});
+        lo.end = (A.cur + 3) & ~int64_t(3);
+    }
+    TopOff& t = m->top;
+    t.begin = (A.cur + 3) & ~int64_t(3);
+    const char* emb[3] = {"joints_embed", "bone_embed", "limb_embed"};
+    const char* pos[3] = {"pos_embed", "bone_pos_embed", "limb_pos_embed"};
+    for (int s = 0; s < 3; ++s) {
+        m->pro.embed_w[s] = A.add(std::string(emb[s]) + ".weight", {128, 3});
+        m->pro.embed_b[s] = A.add(std::string(emb[s]) + ".bias", {128});
+        m->pro.pos[s] = A.add(pos[s], {1, 17, 128});
+    }
+    t.norm_w = A.add("norm.weight", {128});
+    t.norm_b = A.add("norm.bias", {128});
+    const char* chn[3] = {"mlp_dir_x", "mlp_dir_y", "mlp_len"};
+    for (int i = 0; i < 17; ++i)
+        for (int c = 0; c < 3; ++c) {
+            const std::string p = "bone_refusion.mlp_layers." + std::to_string(i) + "." + chn[c] + ".";
+            m->pro.mlp[i * 3 + c][0] = A.add(p + "fc1.weight", {16, LIMB_N[i]});
+            m->pro.mlp[i * 3 + c][1] = A.add(p + "fc1.bias", {16});
+            m->pro.mlp[i * 3 + c][2] = A.add(p + "fc2.weight", {1, 16});
+            m->pro.mlp[i * 3 + c][3] = A.add(p + "fc2.bias", {1});
+        }
+    t.fc_w = A.add("rep_logit.fc.weight", {512, 128});
+    t.fc_b = A.add("rep_logit.fc.bias", {512});
+    t.head_w = A.add("head.weight", {3, 512});
+    t.head_b = A.add("head.bias", {3});
+    t.p_fc = packd(t.fc_w, 512, 128, -1, 0);
+    t.p_fcT = packd(t.fc_w, 512, 128, -1, 1);
+    t.end = m->n_live = (A.cur + 3) & ~int64_t(3);
+    A.cur = m->n_live;
+    for (int l = 0; l < L; ++l)                      // never-used norm1_limb of the non-bone blocks (KASportsFormer.py:73)
+        for (int b = 0; b < 4; ++b) {
+            const std::string p = "layers_with_bone." + std::to_string(l) + "." + BLOCK_NAMES[b] + ".";
+            m->layers[l].blk[b].n1lw = A.add(p + "norm1_limb.weight", {128});
+            m->layers[l].blk[b].n1lb = A.add(p + "norm1_limb.bias", {128});
+        }
+    m->n_params = (A.cur + 3) & ~int64_t(3);
+    m->n_buffers = (B.cur + 3) & ~int64_t(3);
+    m->arena_elems = arena;
+    int tiles = 0;
+    for (const KasfPackDesc& d : m->pack) {
+        m->pack_tile_start.push_back(tiles);
+        tiles += (d.rows / 32) * (d.cols / 32);
+    }
+    m->pack_tiles = tiles;
+}
+
+inline int esize(const kasf_model* m) { return m->cfg.dtype == KASF_F32 ? 4 : 2; }
+
+void build_plan(const kasf_model* m, int B, bool train, bool names, Plan& p) {
+    const int L = m->cfg.n_layers, T = m->cfg.n_frames, es = esize(m);
+    const int64_t M = (int64_t)B * T * 17, groupsT = (int64_t)B * 17;
+    int64_t cur = 0;
+    auto take = [&](int64_t numel, int kind, const char* name, int l = -1, int b = -1) {
+        const int64_t bytes = numel * (kind == 0 ? es : (kind == 2 ? 8 : 4));
+        const int64_t off = cur;
+        cur = (cur + bytes + 255) & ~int64_t(255);
+        if (names) {
+            std::string n;
+            if (l >= 0) n = "L" + std::to_string(l) + ".";
+            if (b >= 0) n += std::string(BLOCK_NAMES[b]) + ".";
+            p.entries.push_back(WsEntry{n + name, off, numel, kind});
+        }
+        return off;
+    };
+    const int nl = train ? L : 1;
+    p.layers.resize(nl);
+    p.stats_begin = cur;
+    for (int l = 0; l < nl; ++l)
+        for (int b = 2; b < 4; ++b) p.layers[l].b[b].stats = take(96 * 2, 2, "bn_stats", l, b);
+    p.stats_bytes = cur - p.stats_begin;
+    p.bstats_begin = cur;
+    for (int l = 0; l < nl; ++l)
+        for (int b = 2; b < 4; ++b) p.layers[l].b[b].bstats = take(96 * 2, 2, "bn_bwd_stats", l, b);
+    p.bstats_bytes = cur - p.bstats_begin;
+    p.x3 = take(M * 3, 1, "x_input");
+    p.bone3 = take(M * 3, 1, "bone3");
+    p.limb3 = take(M * 3, 1, "limb3");
+    p.xj = take(M * 128, 0, "x_joint");
+    p.xb = take(M * 128, 0, "x_bone");
+    p.xl = take(M * 128, 0, "x_limb");
+    for (int l = 0; l < nl; ++l) {
+        LayerWs& lw = p.layers[l];
+        for (int b = 0; b < 6; ++b) {
+            BlkWs& w = lw.b[b];
+            const int kind = BLOCK_KIND[b];
+            if (kind == KIND_ATT) w.qkv = take(M * 384, 0, "qkv", l, b);
+            if (kind == KIND_BONE) { w.qkv = take(M * 128, 0, "q", l, b); w.kv = take(M * 256, 0, "kv", l, b); }
+            if (kind != KIND_GRAPH) w.o = take(M * 128, 0, "o", l, b);
+            if (kind == KIND_GRAPH) {
+                w.xn = take(M * 128, 0, "xn", l, b);
+                w.y = take(M * 128, 0, "y", l, b);
+                w.coef = take(96 * 8, 1, "bn_coef", l, b);
+                w.mask = (b & 1) ? take(groupsT * T * 3, 3, "adj_mask", l, b) : -1;
+            }
+            w.x_mid = take(M * 128, 0, "x_mid", l, b);
+            w.x_out = take(M * 128, 0, "x_out", l, b);
+        }
+        lw.gate_out = take(M * 128, 0, "gate_out", l);
+        lw.alpha = take(M * 4, 1, "alpha", l);
+    }
+    p.rep = take(M * 512, 0, "rep");
+    p.uv = take(M * 256, 0, "scratch_uv");
+    if (train) {
+        p.g_layer = take(M * 128, 0, "g_layer");
+        p.g_prev = take(M * 128, 0, "g_prev");
+        p.ga = take(M * 128, 0, "g_att");
+        p.gg = take(M * 128, 0, "g_graph");
+        p.gb = take(M * 128, 0, "g_bonebr");
+        p.t1 = take(M * 128, 0, "g_tmp1");
+        p.t2 = take(M * 128, 0, "g_tmp2");
+        p.g_limb = take(M * 128, 0, "g_limb");
+        p.g_bone = take(M * 128, 0, "g_bone");
+        p.hbuf = take(M * 512, 0, "mlp_h");
+        p.dzbuf = take(M * 512, 0, "mlp_dz");
+        p.d_o = take(M * 128, 0, "d_o");
+        p.dqkv = take(M * 384, 0, "dqkv");
+        p.rbuf = take(M * 128, 0, "gcn_r");
+        p.duv = take(M * 256, 0, "gcn_duv");
+        p.dlimb3 = take(M * 3, 1, "dlimb3");
+    }
+    p.total = cur;
+}
+
+// ----------------------------------------------------------------------------------------------
+struct Ctx {
+    const kasf_model* m;
+    const float* P;          // fp32 parameters
+    const char* A;           // packed arena
+    float* buf;              // BN buffers
+    float* G;                // gradients (backward)
+    char* ws;
+    hipStream_t s;
+    int B, T, dt, es;
+    int64_t M;
+    bool train;
+    const void* pk(int64_t elem_off) const { return A + elem_off * es; }
+    void* w(int64_t byte_off) const { return ws + byte_off; }
+};
+
+void block_forward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void* x_in, const void* x_limb, const Plan& p) {
+    const float* P = c.P;
+    if (o.kind == KIND_ATT) {
+        kasf_launch_linear(c.dt, c.s, x_in, 128, c.pk(o.p_mix), 128, nullptr, c.w(w.qkv), 384, c.M, 384, P + o.n1w, P + o.n1b, nullptr, 0);
+        const char* q = (const char*)c.w(w.qkv);
+        kasf_launch_attn_fwd(c.dt, c.s, q, 384, q + 128 * c.es, q + 256 * c.es, 384, c.w(w.o), c.B, c.T, o.mode);
+    } else if (o.kind == KIND_BONE) {
+        kasf_launch_linear(c.dt, c.s, x_in, 128, c.pk(o.p_mix), 128, nullptr, c.w(w.qkv), 128, c.M, 128, P + o.n1w, P + o.n1b, nullptr, 0);
+        kasf_launch_linear(c.dt, c.s, x_limb, 128, c.pk(o.p_kv), 128, nullptr, c.w(w.kv), 256, c.M, 256, P + o.n1lw, P + o.n1lb, nullptr, 0);
+        const char* kv = (const char*)c.w(w.kv);
+        kasf_launch_attn_fwd(c.dt, c.s, c.w(w.qkv), 128, kv, kv + 128 * c.es, 256, c.w(w.o), c.B, c.T, o.mode);
+    } else {
+        kasf_launch_linear(c.dt, c.s, x_in, 128, c.pk(o.p_mix), 128, P + o.uv_b, c.w(p.uv), 256, c.M, 256, P + o.n1w, P + o.n1b, c.w(w.xn), 0);
+        kasf_launch_gcn_agg_fwd(c.dt, c.s, c.w(p.uv), c.w(w.xn), c.w(w.y), w.mask >= 0 ? (uint32_t*)c.w(w.mask) : nullptr, (double*)c.w(w.stats), c.B,
+                                c.T, o.mode);
+        const double count = o.mode == 0 ? (double)c.B * c.T * 128 : (double)c.B * 17 * 128;
+        kasf_launch_bn_finalize(c.s, (const double*)c.w(w.stats), P + o.bn_w, P + o.bn_b, c.buf + o.bn_rm, c.buf + o.bn_rv, (float*)c.w(w.coef), o.nodes,
+                                count, c.train ? 1 : 0, 0.1f);
+        kasf_launch_gcn_apply(c.dt, c.s, x_in, c.w(w.xn), c.w(w.y), (const float*)c.w(w.coef), P + o.ls1, c.w(w.x_mid), c.B, c.T, o.mode);
+    }
+    if (o.kind != KIND_GRAPH)
+        kasf_launch_linear_res(c.dt, c.s, c.w(w.o), c.pk(o.p_proj), P + o.proj_b, P + o.ls1, x_in, c.w(w.x_mid), c.M);
+    kasf_launch_mlp_fwd(c.dt, c.s, c.w(w.x_mid), P + o.n2w, P + o.n2b, c.pk(o.p_fc1), P + o.fc1b, c.pk(o.p_fc2), P + o.fc2b, P + o.ls2, c.w(w.x_out), c.M);
+}
+
+// g_out: gradient w.r.t. the block output; writes (or accumulates) the gradient w.r.t. x_in into dst
+void block_backward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void* x_in, const void* x_limb, const void* g_out, void* dst, int accumulate,
+                    const Plan& p) {
+    const float* P = c.P;
+    float* G = c.G;
+    void* g_mid = c.w(p.t2);
+    // ---- MLP half ----
+    kasf_launch_mlp_bwd(c.dt, c.s, c.w(w.x_mid), g_out, P + o.n2w, P + o.n2b, c.pk(o.p_fc1), P + o.fc1b, c.pk(o.p_fc2Ts), c.pk(o.p_fc1T), c.w(p.hbuf),
+                        c.w(p.dzbuf), g_mid, G + o.n2w, G + o.n2b, c.M);
+    kasf_launch_wgrad(c.dt, c.s, c.w(p.dzbuf), 512, 512, c.w(w.x_mid), 128, 128, P + o.n2w, P + o.n2b, G + o.fc1w, 128, G + o.fc1b, c.M);
+    kasf_launch_wgrad(c.dt, c.s, g_out, 128, 128, c.w(p.hbuf), 512, 512, nullptr, nullptr, G + o.fc2w, 512, G + o.fc2b, c.M);
+    kasf_launch_finalize_ls(c.s, G + o.fc2w, P + o.fc2w, P + o.fc2b, P + o.ls2, G + o.fc2b, G + o.ls2, 128, 512);
+    // ---- mixer half ----
+    if (o.kind == KIND_GRAPH) {
+        kasf_launch_gcn_bwd1(c.dt, c.s, g_mid, c.w(w.xn), c.w(w.y), (const float*)c.w(w.coef), P + o.ls1, c.w(p.rbuf), G + o.ls1, (double*)c.w(w.bstats),
+                             c.B, c.T, o.mode);
+        const double count = o.mode == 0 ? (double)c.B * c.T * 128 : (double)c.B * 17 * 128;
+        kasf_launch_gcn_bwd_finalize(c.s, (const double*)c.w(w.bstats), (float*)c.w(w.coef), G + o.bn_w, G + o.bn_b, o.nodes, count);
+        kasf_launch_gcn_bwd2(c.dt, c.s, c.w(p.rbuf), c.w(w.y), (const float*)c.w(w.coef), w.mask >= 0 ? (const uint32_t*)c.w(w.mask) : nullptr, c.w(p.duv),
+                             c.B, c.T, o.mode);
+        kasf_launch_dgrad_lnbwd(c.dt, c.s, c.w(p.duv), 256, c.pk(o.p_mixT), c.w(p.rbuf), x_in, P + o.n1w, g_mid, dst, accumulate, G + o.n1w, G + o.n1b,
+                                c.M);
+        kasf_launch_wgrad(c.dt, c.s, c.w(p.duv), 256, 256, c.w(w.xn), 128, 128, nullptr, nullptr, G + o.mix_w, 128, G + o.uv_b, c.M);
+        return;
+    }
+    // d_o = g_mid . (ls1 . Wproj);  G_proj = g_mid^T o (unscaled) -> finalize: dWproj, dbproj, dls1
+    kasf_launch_linear(c.dt, c.s, g_mid, 128, c.pk(o.p_projTs), 128, nullptr, c.w(p.d_o), 128, c.M, 128, nullptr, nullptr, nullptr, 0);
+    kasf_launch_wgrad(c.dt, c.s, g_mid, 128, 128, c.w(w.o), 128, 128, nullptr, nullptr, G + o.proj_w, 128, G + o.proj_b, c.M);
+    kasf_launch_finalize_ls(c.s, G + o.proj_w, P + o.proj_w, P + o.proj_b, P + o.ls1, G + o.proj_b, G + o.ls1, 128, 128);
+    if (o.kind == KIND_ATT) {
+        const char* q = (const char*)c.w(w.qkv);
+        char* dq = (char*)c.w(p.dqkv);
+        kasf_launch_attn_bwd(c.dt, c.s, q, 384, q + 128 * c.es, q + 256 * c.es, 384, c.w(p.d_o), dq, 384, dq + 128 * c.es, dq + 256 * c.es, 384, c.B, c.T,
+                             o.mode);
+        kasf_launch_dgrad_lnbwd(c.dt, c.s, dq, 384, c.pk(o.p_mixT), nullptr, x_in, P + o.n1w, g_mid, dst, accumulate, G + o.n1w, G + o.n1b, c.M);
+        kasf_launch_wgrad(c.dt, c.s, dq, 384, 384, x_in, 128, 128, P + o.n1w, P + o.n1b, G + o.mix_w, 128, nullptr, c.M);
+    } else {
+        const char* kv = (const char*)c.w(w.kv);
+        char* dq = (char*)c.w(p.dqkv);
+        char* dkv = dq + c.M * 128 * c.es;
+        kasf_launch_attn_bwd(c.dt, c.s, c.w(w.qkv), 128, kv, kv + 128 * c.es, 256, c.w(p.d_o), dq, 128, dkv, dkv + 128 * c.es, 256, c.B, c.T, o.mode);
+        kasf_launch_dgrad_lnbwd(c.dt, c.s, dq, 128, c.pk(o.p_mixT), nullptr, x_in, P + o.n1w, g_mid, dst, accumulate, G + o.n1w, G + o.n1b, c.M);
+        kasf_launch_dgrad_lnbwd(c.dt, c.s, dkv, 256, c.pk(o.p_kvT), nullptr, x_limb, P + o.n1lw, nullptr, c.w(p.g_limb), 1, G + o.n1lw, G + o.n1lb, c.M);
+        kasf_launch_wgrad(c.dt, c.s, dq, 128, 128, x_in, 128, 128, P + o.n1w, P + o.n1b, G + o.mix_w, 128, nullptr, c.M);
+        kasf_launch_wgrad(c.dt, c.s, dkv, 256, 256, x_limb, 128, 128, P + o.n1lw, P + o.n1lb, G + o.kv_w, 128, nullptr, c.M);
+    }
+}
+
+int check_model(const kasf_model* m) {
+    if (m == nullptr) return kasf_set_error(2, "null model");
+    return 0;
+}
+
+}  // namespace
+
+// ================================================================================================ C-ABI
+extern "C" {
+
+const char* kasf_last_error(void) { return g_err.c_str(); }
+int kasf_version(void) { return 1; }
+
+int kasf_model_create(const kasf_config* cfg, kasf_model** out) {
+    if (cfg == nullptr || out == nullptr) return kasf_set_error(2, "null argument");
+    if (cfg->num_heads != 8) return kasf_set_error(3, "num_heads must be 8 (head dim 16); other values are not built");
+    if (cfg->n_layers < 1 || cfg->n_layers > 64) return kasf_set_error(3, "n_layers out of range");
+    if (cfg->n_frames != 9 && cfg->n_frames != 27 && cfg->n_frames != 81) return kasf_set_error(3, "n_frames must be 9, 27 or 81");
+    if (cfg->neighbour_num < 1 || cfg->neighbour_num > 4) return kasf_set_error(3, "neighbour_num must be 1..4");
+    if (cfg->neighbour_num != 4) return kasf_set_error(3, "neighbour_num != 4 is not wired through yet");
+    if (cfg->dtype != KASF_F32 && cfg->dtype != KASF_BF16) return kasf_set_error(3, "dtype must be KASF_DTYPE_F32 or KASF_DTYPE_BF16");
+    kasf_model* m = new kasf_model();
+    m->cfg = *cfg;
+    build_layout(m);
+    HIPCHK(hipMalloc((void**)&m->d_pack, m->pack.size() * sizeof(KasfPackDesc)));
+    HIPCHK(hipMalloc((void**)&m->d_tile_start, m->pack_tile_start.size() * sizeof(int)));
+    HIPCHK(hipMalloc((void**)&m->d_pro, sizeof(KasfProOff)));
+    HIPCHK(hipMemcpy(m->d_pack, m->pack.data(), m->pack.size() * sizeof(KasfPackDesc), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(m->d_tile_start, m->pack_tile_start.data(), m->pack_tile_start.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(m->d_pro, &m->pro, sizeof(KasfProOff), hipMemcpyHostToDevice));
+    kasf_gcn_init();
+    *out = m;
+    return 0;
+}
+
+// layout-only handle (no device): used by the CPU tests and by hosts that only need names/offsets
+int kasf_model_create_layout_only(const kasf_config* cfg, kasf_model** out) {
+    if (cfg == nullptr || out == nullptr) return kasf_set_error(2, "null argument");
+    kasf_model* m = new kasf_model();
+    m->cfg = *cfg;
+    build_layout(m);
+    *out = m;
+    return 0;
+}
+
+void kasf_model_destroy(kasf_model* m) {
+    if (m == nullptr) return;
+    if (m->d_pack) (void)hipFree(m->d_pack);
+    if (m->d_tile_start) (void)hipFree(m->d_tile_start);
+    if (m->d_pro) (void)hipFree(m->d_pro);
+    delete m;
+}
+
+int64_t kasf_param_count(const kasf_model* m) { return m ? m->n_params : 0; }
+int64_t kasf_param_live_count(const kasf_model* m) { return m ? m->n_live : 0; }
+int32_t kasf_param_entries(const kasf_model* m) { return m ? (int32_t)m->params.size() : 0; }
+int64_t kasf_buffer_count(const kasf_model* m) { return m ? m->n_buffers : 0; }
+int32_t kasf_buffer_entries(const kasf_model* m) { return m ? (int32_t)m->buffers.size() : 0; }
+
+static int entry_out(const std::vector<Entry>& v, int32_t idx, char* name, int32_t cap, int64_t* offset, int32_t* ndim, int64_t shape[4]) {
+    if (idx < 0 || idx >= (int32_t)v.size()) return kasf_set_error(2, "entry index out of range");
+    const Entry& e = v[idx];
+    if (name != nullptr && cap > 0) { strncpy(name, e.name.c_str(), cap - 1); name[cap - 1] = 0; }
+    if (offset) *offset = e.off;
+    if (ndim) *ndim = e.ndim;
+    if (shape) for (int i = 0; i < 4; ++i) shape[i] = e.shape[i];
+    return 0;
+}
+int kasf_param_entry(const kasf_model* m, int32_t idx, char* name, int32_t cap, int64_t* offset, int32_t* ndim, int64_t shape[4]) {
+    if (check_model(m)) return 2;
+    return entry_out(m->params, idx, name, cap, offset, ndim, shape);
+}
+int kasf_buffer_entry(const kasf_model* m, int32_t idx, char* name, int32_t cap, int64_t* offset, int32_t* ndim, int64_t shape[4]) {
+    if (check_model(m)) return 2;
+    return entry_out(m->buffers, idx, name, cap, offset, ndim, shape);
+}
+int32_t kasf_backward_stages(const kasf_model* m) { return m ? m->cfg.n_layers + 2 : 0; }
+int kasf_stage_grad_range(const kasf_model* m, int32_t stage, int64_t* begin, int64_t* end) {
+    if (check_model(m)) return 2;
+    const int L = m->cfg.n_layers;
+    if (stage < 0 || stage > L + 1) return kasf_set_error(2, "stage out of range");
+    if (stage == 0) { *begin = 0; *end = 0; }
+    else if (stage <= L) { *begin = m->layers[L - stage].begin; *end = m->layers[L - stage].end; }
+    else { *begin = m->top.begin; *end = m->top.end; }
+    return 0;
+}
+
+int64_t kasf_packed_bytes(const kasf_model* m) { return m ? ((m->arena_elems * esize(m) + 255) & ~int64_t(255)) : 0; }
+int kasf_pack_weights(const kasf_model* m, const float* params, void* packed, void* stream) {
+    if (check_model(m)) return 2;
+    if (m->d_pack == nullptr) return kasf_set_error(4, "layout-only model has no device tables");
+    kasf_launch_pack(m->cfg.dtype, (hipStream_t)stream, params, packed, m->d_pack, m->d_tile_start, (int)m->pack.size(), m->pack_tiles);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int64_t kasf_workspace_bytes(const kasf_model* m, int32_t batch, int32_t flags) {
+    if (m == nullptr || batch < 1) return 0;
+    Plan p;
+    build_plan(m, batch, (flags & KASF_FLAG_TRAIN) != 0, false, p);
+    return p.total;
+}
+int32_t kasf_ws_entries(const kasf_model* m, int32_t batch, int32_t flags) {
+    if (m == nullptr || batch < 1) return 0;
+    Plan p;
+    build_plan(m, batch, (flags & KASF_FLAG_TRAIN) != 0, true, p);
+    return (int32_t)p.entries.size();
+}
+int kasf_ws_entry(const kasf_model* m, int32_t batch, int32_t flags, int32_t idx, char* name, int32_t cap, int64_t* byte_offset, int64_t* numel,
+                  int32_t* elem_kind) {
+    if (check_model(m)) return 2;
+    Plan p;
+    build_plan(m, batch, (flags & KASF_FLAG_TRAIN) != 0, true, p);
+    if (idx < 0 || idx >= (int32_t)p.entries.size()) return kasf_set_error(2, "workspace entry index out of range");
+    const WsEntry& e = p.entries[idx];
+    if (name != nullptr && cap > 0) { strncpy(name, e.name.c_str(), cap - 1); name[cap - 1] = 0; }
+    if (byte_offset) *byte_offset = e.off;
+    if (numel) *numel = e.numel;
+    if (elem_kind) *elem_kind = e.kind;
+    return 0;
+}
+
+int kasf_forward(const kasf_model* m, const float* params, const void* packed, float* buffers, const float* x, float* out, void* workspace,
+                 int64_t workspace_bytes, int32_t batch, int32_t flags, void* stream) {
+    if (check_model(m)) return 2;
+    if (!params || !packed || !buffers || !x || !out || !workspace) return kasf_set_error(2, "null pointer argument");
+    if (m->d_pro == nullptr) return kasf_set_error(4, "layout-only model cannot run");
+    const bool train = (flags & KASF_FLAG_TRAIN) != 0;
+    Plan p;
+    build_plan(m, batch, train, false, p);
+    if (workspace_bytes < p.total) return kasf_set_error(5, "workspace too small (see kasf_workspace_bytes)");
+    Ctx c{m, params, (const char*)packed, buffers, nullptr, (char*)workspace, (hipStream_t)stream, batch, m->cfg.n_frames, m->cfg.dtype, esize(m),
+          (int64_t)batch * m->cfg.n_frames * 17, train};
+    g_err.clear();
+    HIPCHK(hipMemsetAsync(c.w(p.stats_begin), 0, p.stats_bytes, c.s));
+    if (train) HIPCHK(hipMemcpyAsync(c.w(p.x3), x, c.M * 3 * sizeof(float), hipMemcpyDeviceToDevice, c.s));
+    kasf_launch_prologue_fwd(c.dt, c.s, x, params, m->d_pro, c.w(p.xj), c.w(p.xb), c.w(p.xl), (float*)c.w(p.bone3), (float*)c.w(p.limb3),
+                             (int64_t)batch * c.T);
+    const void* xcur = c.w(p.xj);
+    const int L = m->cfg.n_layers;
+    for (int l = 0; l < L; ++l) {
+        const LayerOff& lo = m->layers[l];
+        const LayerWs& lw = p.layers[train ? l : 0];
+        if (!train && l > 0) HIPCHK(hipMemsetAsync(c.w(p.stats_begin), 0, p.stats_bytes, c.s));
+        for (int br = 0; br < 3; ++br) {
+            const void* in0 = (br == 2 && l == 0) ? c.w(p.xb) : xcur;         // layer 0: bone branch starts from the bone embedding (:332-336)
+            block_forward(c, lo.blk[2 * br], lw.b[2 * br], in0, c.w(p.xl), p);
+            block_forward(c, lo.blk[2 * br + 1], lw.b[2 * br + 1], c.w(lw.b[2 * br].x_out), c.w(p.xl), p);
+        }
+        kasf_launch_gate_fwd(c.dt, c.s, c.w(lw.b[1].x_out), c.w(lw.b[3].x_out), c.w(lw.b[5].x_out), params + lo.fus_w, params + lo.fus_b, c.w(lw.gate_out),
+                             (float*)c.w(lw.alpha), c.M, m->cfg.use_adaptive_fusion);
+        xcur = c.w(lw.gate_out);
+    }
+    const TopOff& t = m->top;
+    kasf_launch_linear(c.dt, c.s, xcur, 128, c.pk(t.p_fc), 128, params + t.fc_b, c.w(p.rep), 512, c.M, 512, params + t.norm_w, params + t.norm_b, nullptr, 1);
+    if (flags & KASF_FLAG_RETURN_REP) kasf_launch_cast_to_f32(c.dt, c.s, c.w(p.rep), out, c.M * 512);
+    else kasf_launch_head_fwd(c.dt, c.s, c.w(p.rep), params + t.head_w, params + t.head_b, out, c.M);
+    HIPCHK(hipGetLastError());
+    if (!g_err.empty()) return 3;
+    return 0;
+}
+
+int kasf_backward(const kasf_model* m, const float* params, const void* packed, const float* dout, float* grads, void* workspace, int64_t workspace_bytes,
+                  int32_t batch, int32_t stage_begin, int32_t stage_end, void* stream) {
+    if (check_model(m)) return 2;
+    if (!params || !packed || !dout || !grads || !workspace) return kasf_set_error(2, "null pointer argument");
+    const int L = m->cfg.n_layers;
+    if (stage_begin < 0 || stage_end > L + 2 || stage_begin > stage_end) return kasf_set_error(2, "bad stage range");
+    Plan p;
+    build_plan(m, batch, true, false, p);
+    if (workspace_bytes < p.total) return kasf_set_error(5, "workspace too small (see kasf_workspace_bytes)");
+    Ctx c{m, params, (const char*)packed, nullptr, grads, (char*)workspace, (hipStream_t)stream, batch, m->cfg.n_frames, m->cfg.dtype, esize(m),
+          (int64_t)batch * m->cfg.n_frames * 17, true};
+    g_err.clear();
+    const TopOff& t = m->top;
+    for (int st = stage_begin; st < stage_end; ++st) {
+        // the running gradient w.r.t. the current layer's output alternates between two buffers
+        auto gbuf = [&](int k) { return c.w((k & 1) ? p.g_prev : p.g_layer); };
+        if (st == 0) {
+            HIPCHK(hipMemsetAsync(c.w(p.bstats_begin), 0, p.bstats_bytes, c.s));
+            HIPCHK(hipMemsetAsync(c.w(p.g_limb), 0, c.M * 128 * c.es, c.s));
+            const void* x_final = c.w(p.layers[L - 1].gate_out);
+            kasf_launch_head_bwd(c.dt, c.s, dout, c.w(p.rep), params + t.head_w, c.w(p.hbuf), grads + t.head_w, grads + t.head_b, c.M);
+            kasf_launch_dgrad_lnbwd(c.dt, c.s, c.w(p.hbuf), 512, c.pk(t.p_fcT), nullptr, x_final, params + t.norm_w, nullptr, gbuf(0), 0, grads + t.norm_w,
+                                    grads + t.norm_b, c.M);
+            kasf_launch_wgrad(c.dt, c.s, c.w(p.hbuf), 512, 512, x_final, 128, 128, params + t.norm_w, params + t.norm_b, grads + t.fc_w, 128, grads + t.fc_b,
+                              c.M);
+        } else if (st <= L) {
+            const int l = L - st;
+            const LayerOff& lo = m->layers[l];
+            const LayerWs& lw = p.layers[l];
+            const void* x_in = l == 0 ? c.w(p.xj) : c.w(p.layers[l - 1].gate_out);
+            void* g_out = gbuf(st - 1);
+            void* g_in = gbuf(st);
+            kasf_launch_gate_bwd(c.dt, c.s, g_out, c.w(lw.b[1].x_out), c.w(lw.b[3].x_out), c.w(lw.b[5].x_out), params + lo.fus_w, (const float*)c.w(lw.alpha),
+                                 c.w(p.ga), c.w(p.gg), c.w(p.gb), grads + lo.fus_w, grads + lo.fus_b, c.M, m->cfg.use_adaptive_fusion);
+            const int64_t gsrc[3] = {p.ga, p.gg, p.gb};
+            for (int br = 0; br < 3; ++br) {
+                const bool bone0 = (br == 2 && l == 0);
+                const void* in0 = bone0 ? c.w(p.xb) : x_in;
+                block_backward(c, lo.blk[2 * br + 1], lw.b[2 * br + 1], c.w(lw.b[2 * br].x_out), c.w(p.xl), c.w(gsrc[br]), c.w(p.t1), 0, p);
+                block_backward(c, lo.blk[2 * br], lw.b[2 * br], in0, c.w(p.xl), c.w(p.t1), bone0 ? c.w(p.g_bone) : g_in, (bone0 || br == 0) ? 0 : 1, p);
+            }
+        } else {
+            void* g_x = gbuf(L);
+            const int64_t frames = (int64_t)batch * c.T;
+            const KasfProOff& po = m->pro;
+            const float* src[3] = {(const float*)c.w(p.x3), (const float*)c.w(p.bone3), (const float*)c.w(p.limb3)};
+            const void* gs[3] = {g_x, c.w(p.g_bone), c.w(p.g_limb)};
+            for (int sidx = 0; sidx < 3; ++sidx)
+                kasf_launch_embed_bwd(c.dt, c.s, gs[sidx], src[sidx], params + po.embed_w[sidx], grads + po.embed_w[sidx], grads + po.embed_b[sidx],
+                                      grads + po.pos[sidx], sidx == 2 ? (float*)c.w(p.dlimb3) : nullptr, frames);
+            kasf_launch_refusion_bwd(c.s, (const float*)c.w(p.x3), (const float*)c.w(p.dlimb3), params, grads, m->d_pro, frames);
+        }
+    }
+    HIPCHK(hipGetLastError());
+    if (!g_err.empty()) return 3;
+    return 0;
+}
+
+int kasf_loss3(const float* pred, const float* target, float* dpred, float* losses, int32_t batch, int32_t n_frames, float lambda_n_mpjpe,
+               float lambda_velocity, float grad_scale, void* stream) {
+    if (!pred || !target || !dpred || !losses) return kasf_set_error(2, "null pointer argument");
+    kasf_launch_loss3((hipStream_t)stream, pred, target, dpred, losses, batch, n_frames, lambda_n_mpjpe, lambda_velocity, grad_scale);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int kasf_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2, float eps,
+                    float weight_decay, int32_t step_index, float grad_scale, void* stream) {
+    if (!params || !grads || !exp_avg || !exp_avg_sq) return kasf_set_error(2, "null pointer argument");
+    if (n % 4 != 0 || step_index < 1) return kasf_set_error(2, "n must be a multiple of 4 and step_index >= 1");
+    const float bc1 = 1.0f - powf(beta1, (float)step_index), bc2 = 1.0f - powf(beta2, (float)step_index);
+    kasf_launch_adamw((hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+#define OP_DT_CHECK(dt) \
+    if ((dt) != KASF_F32 && (dt) != KASF_BF16) return kasf_set_error(3, "bad dtype")
+
+int kasf_op_linear(int32_t dtype, const void* a, const void* w, const float* bias, void* y, int64_t M, int32_t N, const float* ln_g, const float* ln_b,
+                   void* xn_out, int32_t act, void* stream) {
+    OP_DT_CHECK(dtype);
+    if (N % 128 != 0) return kasf_set_error(2, "N must be a multiple of 128");
+    kasf_launch_linear(dtype, (hipStream_t)stream, a, 128, w, 128, bias, y, N, M, N, ln_g, ln_b, xn_out, act);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int kasf_op_mlp_fwd(int32_t dtype, const void* x, const float* ln_g, const float* ln_b, const void* w1, const float* b1, const void* w2, const float* b2,
+                    const float* ls2, void* out, int64_t M, void* stream) {
+    OP_DT_CHECK(dtype);
+    kasf_launch_mlp_fwd(dtype, (hipStream_t)stream, x, ln_g, ln_b, w1, b1, w2, b2, ls2, out, M);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int kasf_op_mlp_bwd(int32_t dtype, const void* x, const void* g, const float* ln_g, const float* ln_b, const void* w1, const float* b1,
+                    const void* w2t_scaled, const void* w1t, void* hbuf, void* dzbuf, void* g_in, float* dgamma, float* dbeta, int64_t M, void* stream) {
+    OP_DT_CHECK(dtype);
+    kasf_launch_mlp_bwd(dtype, (hipStream_t)stream, x, g, ln_g, ln_b, w1, b1, w2t_scaled, w1t, hbuf, dzbuf, g_in, dgamma, dbeta, M);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int kasf_op_wgrad(int32_t dtype, const void* g, int32_t N, const void* x, int32_t K, const float* ln_g, const float* ln_b, float* dw, float* dbias,
+                  int64_t M, void* stream) {
+    OP_DT_CHECK(dtype);
+    if (N % 128 != 0 || K % 128 != 0) return kasf_set_error(2, "N and K must be multiples of 128");
+    if (ln_g != nullptr && K != 128) return kasf_set_error(2, "LayerNorm-fused wgrad needs K == 128");
+    kasf_launch_wgrad(dtype, (hipStream_t)stream, g, N, N, x, K, K, ln_g, ln_b, dw, K, dbias, M);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int kasf_op_dgrad_lnbwd(int32_t dtype, const void* dy, int32_t Kd, const void* wt, const void* dxn_add, const void* x, const float* gamma,
+                        const void* resid, void* out, int32_t accumulate, float* dgamma, float* dbeta, int64_t M, void* stream) {
+    OP_DT_CHECK(dtype);
+    if (Kd % 128 != 0) return kasf_set_error(2, "Kd must be a multiple of 128");
+    kasf_launch_dgrad_lnbwd(dtype, (hipStream_t)stream, dy, Kd, wt, dxn_add, x, gamma, resid, out, accumulate, dgamma, dbeta, M);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int kasf_op_attention_fwd(int32_t dtype, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, void* o, int32_t batch, int32_t n_frames,
+                          int32_t mode, void* stream) {
+    OP_DT_CHECK(dtype);
+    g_err.clear();
+    kasf_launch_attn_fwd(dtype, (hipStream_t)stream, q, ldq, k, v, ldkv, o, batch, n_frames, mode);
+    HIPCHK(hipGetLastError());
+    return g_err.empty() ? 0 : 3;
+}
+int kasf_op_attention_bwd(int32_t dtype, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, const void* d_o, void* dq, int64_t lddq,
+                          void* dk, void* dv, int64_t lddkv, int32_t batch, int32_t n_frames, int32_t mode, void* stream) {
+    OP_DT_CHECK(dtype);
+    g_err.clear();
+    kasf_launch_attn_bwd(dtype, (hipStream_t)stream, q, ldq, k, v, ldkv, d_o, dq, lddq, dk, dv, lddkv, batch, n_frames, mode);
+    HIPCHK(hipGetLastError());
+    return g_err.empty() ? 0 : 3;
+}
+int kasf_op_cast(int32_t dtype, const void* src, void* dst, int64_t n, int32_t to_f32, void* stream) {
+    OP_DT_CHECK(dtype);
+    if (to_f32) kasf_launch_cast_to_f32(dtype, (hipStream_t)stream, src, (float*)dst, n);
+    else kasf_launch_cast_from_f32(dtype, (hipStream_t)stream, (const float*)src, dst, n);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

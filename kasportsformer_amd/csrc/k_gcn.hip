@@ -1,0 +1,420 @@
+// GCN mixer (reference: modules/graph.py:19-134), split at the BatchNorm batch-statistics barrier:
+//   uv = LN(x) [U|V]^T + b                       (k_linear, writes xn = LN(x))
+//   y  = A_hat . V(xn) + U(xn)                   k_gcn_agg_{spatial,temporal}  (+ per-node sum / sum-of-squares)
+//   coef = BatchNorm scale/shift per node        k_bn_finalize               (+ running statistics, graph.py:37)
+//   out = x + ls1 * relu(xn + y*scale + shift)   k_gcn_apply                 (graph.py:128-129, KASportsFormer.py:109)
+// spatial : fixed skeleton adjacency (graph.py:16-17,52-61), D^-1/2 A D^-1/2, nodes = joints, BN channel = joint
+// temporal: per (b, joint) track, S = xn xn^T, threshold = 4th largest per row, A = (S >= thr) (ties kept,
+//           graph.py:104-112), D from row sums (graph.py:77-90), BN channel = frame.  The adjacency is a
+//           comparison result and carries no gradient; its bit mask is stored for the backward pass.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+// skeleton neighbours (graph.py:16-17) and D^-1/2 A D^-1/2 coefficients, filled by the host at load time
+struct SkelTable { int nb[KASF_J][4]; float coef[KASF_J][4]; };
+__constant__ SkelTable c_skel;
+
+constexpr int COEF_LD = 8;      // per node: scale, shift, mean, rstd, c1, c2, -, -
+constexpr int MASK_W = 3;       // 32-bit words per adjacency row (T <= 96)
+constexpr int SX_LD = 132;      // padded fp32 row of the temporal tiles
+
+__device__ __forceinline__ int node_of(int64_t tok, int T, int mode) { return mode == 0 ? (int)(tok % KASF_J) : (int)((tok / KASF_J) % T); }
+
+// ------------------------------------------------------------------ spatial aggregate (elementwise + 4-neighbour gather)
+template <typename T>
+__global__ __launch_bounds__(256) void k_gcn_agg_spatial(const T* __restrict__ uv, T* __restrict__ y, double* __restrict__ stats, int64_t M) {
+    __shared__ float sStat[KASF_J * 2];
+    if (threadIdx.x < KASF_J * 2) sStat[threadIdx.x] = 0.f;
+    __syncthreads();
+    const int sub = threadIdx.x & 15;
+    for (int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x; item < M * 16; item += (int64_t)gridDim.x * 256) {
+        const int64_t tok = item >> 4, frame0 = (tok / KASF_J) * KASF_J;
+        const int i = (int)(tok - frame0);
+        float acc[8];
+        load8(uv + tok * 256 + sub * 8, acc);                        // U
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int nb = c_skel.nb[i][e];
+            if (nb >= 0) {
+                float v[8];
+                load8(uv + (frame0 + nb) * 256 + 128 + sub * 8, v);  // V of the neighbour joint
+                const float c = c_skel.coef[i][e];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[k] += c * v[k];
+            }
+        }
+        store8(y + tok * 128 + sub * 8, acc);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const float r = to_f(from_f<T>(acc[k])); s1 += r; s2 += r * r; }   // statistics of the stored value
+        s1 = reduce16(s1);
+        s2 = reduce16(s2);
+        if (sub == 0) { atomicAdd(&sStat[i * 2], s1); atomicAdd(&sStat[i * 2 + 1], s2); }
+    }
+    __syncthreads();
+    if (threadIdx.x < KASF_J * 2) atomicAdd(stats + threadIdx.x, (double)sStat[threadIdx.x]);
+}
+
+// ------------------------------------------------------------------ temporal aggregate: one workgroup per (b, joint) track
+template <typename T, int L>
+__global__ __launch_bounds__(256) void k_gcn_agg_temporal(const T* __restrict__ uv, const T* __restrict__ xn, T* __restrict__ y,
+                                                          uint32_t* __restrict__ mask, double* __restrict__ stats, int Tn, int kth) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sX = reinterpret_cast<float*>(smem);         // [L][SX_LD]  LN(x) rows of the track
+    float* sV = sX + L * SX_LD;                         // [L][SX_LD]  V rows
+    float* sS = sV + L * SX_LD;                         // [L][L+1]    similarity
+    float* sDinv = sS + L * (L + 1);                    // [L]
+    float* sStat = sDinv + L;                           // [L][2]
+    uint32_t* sMask = reinterpret_cast<uint32_t*>(sStat + 2 * L);   // [L][MASK_W]
+    const int G = blockIdx.x, b = G / KASF_J, j = G % KASF_J;
+    auto tok = [&](int r) { return ((int64_t)b * Tn + r) * KASF_J + j; };
+    for (int idx = threadIdx.x; idx < L * 16; idx += 256) {
+        const int r = idx >> 4, sub = idx & 15;
+        float a[8], v[8];
+        load8(xn + tok(r) * 128 + sub * 8, a);
+        load8(uv + tok(r) * 256 + 128 + sub * 8, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sX[r * SX_LD + sub * 8 + e] = a[e]; sV[r * SX_LD + sub * 8 + e] = v[e]; }
+    }
+    if (threadIdx.x < 2 * L) sStat[threadIdx.x] = 0.f;
+    __syncthreads();
+    // similarity: every (r,c) with the same k order => bitwise symmetric
+    for (int idx = threadIdx.x; idx < L * L; idx += 256) {
+        const int r = idx / L, c = idx % L;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < 128; k += 4) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(sX + r * SX_LD + k), bb = *reinterpret_cast<const f32x4*>(sX + c * SX_LD + k);
+            s0 += a[0] * bb[0]; s1 += a[1] * bb[1]; s2 += a[2] * bb[2]; s3 += a[3] * bb[3];
+        }
+        sS[r * (L + 1) + c] = (s0 + s1) + (s2 + s3);
+    }
+    __syncthreads();
+    // k-th largest per row -> adjacency bits and degree
+    for (int r = threadIdx.x; r < L; r += 256) {
+        float top[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        for (int c = 0; c < L; ++c) {
+            float v = sS[r * (L + 1) + c];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (v > top[e]) { const float t = top[e]; top[e] = v; v = t; }
+            }
+        }
+        const float thr = kth <= 1 ? top[0] : (kth == 2 ? top[1] : (kth == 3 ? top[2] : top[3]));
+        uint32_t w[MASK_W] = {0u, 0u, 0u};
+        int deg = 0;
+        for (int c = 0; c < L; ++c) {
+            if (sS[r * (L + 1) + c] >= thr) { w[c >> 5] |= 1u << (c & 31); ++deg; }
+        }
+#pragma unroll
+        for (int e = 0; e < MASK_W; ++e) { sMask[r * MASK_W + e] = w[e]; mask[((int64_t)G * L + r) * MASK_W + e] = w[e]; }
+        sDinv[r] = 1.0f / sqrtf((float)deg);
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < L * 16; idx += 256) {
+        const int r = idx >> 4, sub = idx & 15;
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        for (int c = 0; c < L; ++c) {
+            if ((sMask[r * MASK_W + (c >> 5)] >> (c & 31)) & 1u) {
+                const float w = sDinv[r] * sDinv[c];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += w * sV[c * SX_LD + sub * 8 + e];
+            }
+        }
+        float u[8];
+        load8(uv + tok(r) * 256 + sub * 8, u);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { acc[e] += u[e]; const float q = to_f(from_f<T>(acc[e])); s1 += q; s2 += q * q; }
+        store8(y + tok(r) * 128 + sub * 8, acc);
+        s1 = reduce16(s1);
+        s2 = reduce16(s2);
+        if (sub == 0) { atomicAdd(&sStat[r * 2], s1); atomicAdd(&sStat[r * 2 + 1], s2); }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * L) atomicAdd(stats + threadIdx.x, (double)sStat[threadIdx.x]);
+}
+
+// ------------------------------------------------------------------ BatchNorm1d(num_nodes) statistics -> affine coefficients
+__global__ void k_bn_finalize(const double* __restrict__ stats, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ run_mean,
+                              float* __restrict__ run_var, float* __restrict__ coef, int nodes, double count, int training, float momentum) {
+    const int n = threadIdx.x;
+    if (n >= nodes) return;
+    float mean, var;
+    if (training) {
+        const double m = stats[2 * n] / count;
+        double v = stats[2 * n + 1] / count - m * m;
+        if (v < 0) v = 0;
+        mean = (float)m;
+        var = (float)v;
+        run_mean[n] = (1.0f - momentum) * run_mean[n] + momentum * mean;
+        run_var[n] = (1.0f - momentum) * run_var[n] + momentum * (float)(v * count / (count - 1.0));
+    } else {
+        mean = run_mean[n];
+        var = run_var[n];
+    }
+    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+    const float scale = w[n] * rstd;
+    coef[n * COEF_LD + 0] = scale;
+    coef[n * COEF_LD + 1] = bias[n] - mean * scale;
+    coef[n * COEF_LD + 2] = mean;
+    coef[n * COEF_LD + 3] = rstd;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_gcn_apply(const T* __restrict__ x_in, const T* __restrict__ xn, const T* __restrict__ y,
+                                                   const float* __restrict__ coef, const float* __restrict__ ls1, T* __restrict__ out, int64_t M, int Tn,
+                                                   int mode) {
+    const int sub = threadIdx.x & 15;
+    float ls[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ls[e] = ls1[sub * 8 + e];
+    for (int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x; item < M * 16; item += (int64_t)gridDim.x * 256) {
+        const int64_t tok = item >> 4;
+        const int node = node_of(tok, Tn, mode);
+        const float sc = coef[node * COEF_LD], sh = coef[node * COEF_LD + 1];
+        float a[8], b[8], c[8];
+        load8(x_in + tok * 128 + sub * 8, a);
+        load8(xn + tok * 128 + sub * 8, b);
+        load8(y + tok * 128 + sub * 8, c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] += ls[e] * fmaxf(b[e] + c[e] * sc + sh, 0.f);
+        store8(out + tok * 128 + sub * 8, a);
+    }
+}
+
+// ------------------------------------------------------------------ backward, stage 1: through layer-scale and ReLU; BN-backward sums
+template <typename T>
+__global__ __launch_bounds__(256) void k_gcn_bwd1(const T* __restrict__ g, const T* __restrict__ xn, const T* __restrict__ y, const float* __restrict__ coef,
+                                                  const float* __restrict__ ls1, T* __restrict__ rbuf, float* __restrict__ dls1,
+                                                  double* __restrict__ bstats, int64_t M, int Tn, int mode, int nodes) {
+    __shared__ float sStat[96 * 2];
+    __shared__ float sRed[16 * 128];
+    if (threadIdx.x < 2 * nodes) sStat[threadIdx.x] = 0.f;
+    __syncthreads();
+    const int sub = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    float ls[8], dls[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ls[e] = ls1[sub * 8 + e]; dls[e] = 0.f; }
+    for (int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x; item < M * 16; item += (int64_t)gridDim.x * 256) {
+        const int64_t tok = item >> 4;
+        const int node = node_of(tok, Tn, mode);
+        const float sc = coef[node * COEF_LD], sh = coef[node * COEF_LD + 1], mean = coef[node * COEF_LD + 2], rstd = coef[node * COEF_LD + 3];
+        float gg[8], b[8], c[8], r[8];
+        load8(g + tok * 128 + sub * 8, gg);
+        load8(xn + tok * 128 + sub * 8, b);
+        load8(y + tok * 128 + sub * 8, c);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float z = b[e] + c[e] * sc + sh;
+            dls[e] += gg[e] * fmaxf(z, 0.f);
+            r[e] = z > 0.f ? ls[e] * gg[e] : 0.f;
+            s1 += r[e];
+            s2 += r[e] * (c[e] - mean) * rstd;
+        }
+        store8(rbuf + tok * 128 + sub * 8, r);
+        s1 = reduce16(s1);
+        s2 = reduce16(s2);
+        if (sub == 0) { atomicAdd(&sStat[node * 2], s1); atomicAdd(&sStat[node * 2 + 1], s2); }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sRed[rl * 128 + sub * 8 + e] = dls[e];
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += sRed[k * 128 + threadIdx.x];
+        atomicAdd(dls1 + threadIdx.x, s);
+    }
+    if (threadIdx.x < 2 * nodes) atomicAdd(bstats + threadIdx.x, (double)sStat[threadIdx.x]);
+}
+
+__global__ void k_gcn_bwd_finalize(const double* __restrict__ bstats, float* __restrict__ coef, float* __restrict__ d_w, float* __restrict__ d_b, int nodes,
+                                   double count) {
+    const int n = threadIdx.x;
+    if (n >= nodes) return;
+    d_b[n] += (float)bstats[2 * n];
+    d_w[n] += (float)bstats[2 * n + 1];
+    coef[n * COEF_LD + 4] = (float)(bstats[2 * n] / count);
+    coef[n * COEF_LD + 5] = (float)(bstats[2 * n + 1] / count);
+}
+
+// dy of one 8-channel chunk: BN backward with the finalised per-node means
+template <typename T>
+__device__ __forceinline__ void dy_chunk(const T* rbuf, const T* y, const float* coef, int64_t tok, int node, int sub, float (&dy)[8]) {
+    const float sc = coef[node * COEF_LD], mean = coef[node * COEF_LD + 2], rstd = coef[node * COEF_LD + 3];
+    const float c1 = coef[node * COEF_LD + 4], c2 = coef[node * COEF_LD + 5];
+    float r[8], c[8];
+    load8(rbuf + tok * 128 + sub * 8, r);
+    load8(y + tok * 128 + sub * 8, c);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dy[e] = sc * (r[e] - c1 - (c[e] - mean) * rstd * c2);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_gcn_bwd2_spatial(const T* __restrict__ rbuf, const T* __restrict__ y, const float* __restrict__ coef,
+                                                          T* __restrict__ duv, int64_t M) {
+    const int sub = threadIdx.x & 15;
+    for (int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x; item < M * 16; item += (int64_t)gridDim.x * 256) {
+        const int64_t tok = item >> 4, frame0 = (tok / KASF_J) * KASF_J;
+        const int i = (int)(tok - frame0);
+        float dy[8], dv[8];
+        dy_chunk(rbuf, y, coef, tok, i, sub, dy);
+        store8(duv + tok * 256 + sub * 8, dy);                       // dU = dy
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dv[e] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {                                // A_hat is symmetric: dV_i = sum_nb coef * dy_nb
+            const int nb = c_skel.nb[i][e];
+            if (nb >= 0) {
+                float t[8];
+                dy_chunk(rbuf, y, coef, frame0 + nb, nb, sub, t);
+                const float c = c_skel.coef[i][e];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) dv[k] += c * t[k];
+            }
+        }
+        store8(duv + tok * 256 + 128 + sub * 8, dv);
+    }
+}
+
+template <typename T, int L>
+__global__ __launch_bounds__(256) void k_gcn_bwd2_temporal(const T* __restrict__ rbuf, const T* __restrict__ y, const float* __restrict__ coef,
+                                                           const uint32_t* __restrict__ mask, T* __restrict__ duv, int Tn) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sDy = reinterpret_cast<float*>(smem);        // [L][SX_LD]
+    float* sDinv = sDy + L * SX_LD;
+    uint32_t* sMask = reinterpret_cast<uint32_t*>(sDinv + L);
+    const int G = blockIdx.x, b = G / KASF_J, j = G % KASF_J;
+    auto tok = [&](int r) { return ((int64_t)b * Tn + r) * KASF_J + j; };
+    for (int idx = threadIdx.x; idx < L * 16; idx += 256) {
+        const int r = idx >> 4, sub = idx & 15;
+        float dy[8];
+        dy_chunk(rbuf, y, coef, tok(r), r, sub, dy);
+        store8(duv + tok(r) * 256 + sub * 8, dy);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sDy[r * SX_LD + sub * 8 + e] = dy[e];
+    }
+    for (int r = threadIdx.x; r < L; r += 256) {
+        int deg = 0;
+#pragma unroll
+        for (int e = 0; e < MASK_W; ++e) { const uint32_t w = mask[((int64_t)G * L + r) * MASK_W + e]; sMask[r * MASK_W + e] = w; deg += __popc(w); }
+        sDinv[r] = 1.0f / sqrtf((float)deg);
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < L * 16; idx += 256) {
+        const int c = idx >> 4, sub = idx & 15;
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        for (int r = 0; r < L; ++r) {
+            if ((sMask[r * MASK_W + (c >> 5)] >> (c & 31)) & 1u) {
+                const float w = sDinv[r] * sDinv[c];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += w * sDy[r * SX_LD + sub * 8 + e];
+            }
+        }
+        store8(duv + tok(c) * 256 + 128 + sub * 8, acc);
+    }
+}
+
+inline unsigned ew_grid(int64_t M) {
+    int64_t blocks = (M * 16 + 255) / 256;
+    return (unsigned)(blocks > 4096 ? 4096 : (blocks < 1 ? 1 : blocks));
+}
+template <typename K> void set_smem(K k, size_t bytes) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+template <int L> constexpr size_t agg_smem() { return (2 * L * SX_LD + L * (L + 1) + L + 2 * L) * sizeof(float) + L * MASK_W * sizeof(uint32_t); }
+template <int L> constexpr size_t bwd2_smem() { return (L * SX_LD + L) * sizeof(float) + L * MASK_W * sizeof(uint32_t); }
+
+template <typename T, int L>
+void agg_temporal_TL(hipStream_t s, const void* uv, const void* xn, void* y, uint32_t* mask, double* stats, int B, int Tn) {
+    set_smem(k_gcn_agg_temporal<T, L>, agg_smem<L>());
+    hipLaunchKernelGGL((k_gcn_agg_temporal<T, L>), dim3(B * KASF_J), dim3(256), agg_smem<L>(), s, (const T*)uv, (const T*)xn, (T*)y, mask, stats, Tn, 4);
+}
+template <typename T, int L>
+void bwd2_temporal_TL(hipStream_t s, const void* r, const void* y, const float* coef, const uint32_t* mask, void* duv, int B, int Tn) {
+    set_smem(k_gcn_bwd2_temporal<T, L>, bwd2_smem<L>());
+    hipLaunchKernelGGL((k_gcn_bwd2_temporal<T, L>), dim3(B * KASF_J), dim3(256), bwd2_smem<L>(), s, (const T*)r, (const T*)y, coef, mask, (T*)duv, Tn);
+}
+
+template <typename T>
+void agg_fwd_T(hipStream_t s, const void* uv, const void* xn, void* y, uint32_t* mask, double* stats, int B, int Tn, int mode) {
+    const int64_t M = (int64_t)B * Tn * KASF_J;
+    if (mode == 0) {
+        hipLaunchKernelGGL(k_gcn_agg_spatial<T>, dim3(ew_grid(M)), dim3(256), 0, s, (const T*)uv, (T*)y, stats, M);
+    } else if (Tn == 27) agg_temporal_TL<T, 27>(s, uv, xn, y, mask, stats, B, Tn);
+    else if (Tn == 81) agg_temporal_TL<T, 81>(s, uv, xn, y, mask, stats, B, Tn);
+    else if (Tn == 9) agg_temporal_TL<T, 9>(s, uv, xn, y, mask, stats, B, Tn);
+    else kasf_set_error(3, "temporal GCN: n_frames must be one of 9, 27, 81");
+}
+template <typename T>
+void bwd2_T(hipStream_t s, const void* r, const void* y, const float* coef, const uint32_t* mask, void* duv, int B, int Tn, int mode) {
+    const int64_t M = (int64_t)B * Tn * KASF_J;
+    if (mode == 0) hipLaunchKernelGGL(k_gcn_bwd2_spatial<T>, dim3(ew_grid(M)), dim3(256), 0, s, (const T*)r, (const T*)y, coef, (T*)duv, M);
+    else if (Tn == 27) bwd2_temporal_TL<T, 27>(s, r, y, coef, mask, duv, B, Tn);
+    else if (Tn == 81) bwd2_temporal_TL<T, 81>(s, r, y, coef, mask, duv, B, Tn);
+    else if (Tn == 9) bwd2_temporal_TL<T, 9>(s, r, y, coef, mask, duv, B, Tn);
+    else kasf_set_error(3, "temporal GCN: n_frames must be one of 9, 27, 81");
+}
+
+}  // namespace
+
+static bool g_skel_ready = false;
+void kasf_gcn_init() {
+    if (g_skel_ready) return;
+    // graph.py:16-17 -- copied as data (bit-exact indices); degree = number of listed neighbours
+    static const int adj[KASF_J][4] = {{1, 7, 4, -1}, {2, 0, -1, -1}, {3, 1, -1, -1}, {2, -1, -1, -1}, {5, 0, -1, -1}, {6, 4, -1, -1},
+                                       {5, -1, -1, -1}, {0, 8, -1, -1}, {7, 9, 11, 14}, {8, 10, -1, -1}, {9, -1, -1, -1}, {12, 8, -1, -1},
+                                       {13, 11, -1, -1}, {12, -1, -1, -1}, {15, 8, -1, -1}, {16, 14, -1, -1}, {15, -1, -1, -1}};
+    SkelTable t;
+    int deg[KASF_J];
+    for (int i = 0; i < KASF_J; ++i) { deg[i] = 0; for (int e = 0; e < 4; ++e) deg[i] += adj[i][e] >= 0; }
+    for (int i = 0; i < KASF_J; ++i)
+        for (int e = 0; e < 4; ++e) {
+            t.nb[i][e] = adj[i][e];
+            t.coef[i][e] = adj[i][e] >= 0 ? (1.0f / sqrtf((float)deg[i])) * (1.0f / sqrtf((float)deg[adj[i][e]])) : 0.f;
+        }
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(c_skel), &t, sizeof(t));
+    g_skel_ready = true;
+}
+
+void kasf_launch_gcn_agg_fwd(int dt, hipStream_t s, const void* uv, const void* xn, void* y, uint32_t* mask, double* stats, int B, int T, int mode) {
+    kasf_gcn_init();
+    if (dt == KASF_F32) agg_fwd_T<float>(s, uv, xn, y, mask, stats, B, T, mode);
+    else agg_fwd_T<bf16>(s, uv, xn, y, mask, stats, B, T, mode);
+}
+void kasf_launch_bn_finalize(hipStream_t s, const double* stats, const float* bn_w, const float* bn_b, float* run_mean, float* run_var, float* coef,
+                             int nodes, double count, int training, float momentum) {
+    hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(128), 0, s, stats, bn_w, bn_b, run_mean, run_var, coef, nodes, count, training, momentum);
+}
+void kasf_launch_gcn_apply(int dt, hipStream_t s, const void* x_in, const void* xn, const void* y, const float* coef, const float* ls1, void* out, int B,
+                           int T, int mode) {
+    const int64_t M = (int64_t)B * T * KASF_J;
+    if (dt == KASF_F32) hipLaunchKernelGGL(k_gcn_apply<float>, dim3(ew_grid(M)), dim3(256), 0, s, (const float*)x_in, (const float*)xn, (const float*)y, coef, ls1, (float*)out, M, T, mode);
+    else hipLaunchKernelGGL(k_gcn_apply<bf16>, dim3(ew_grid(M)), dim3(256), 0, s, (const bf16*)x_in, (const bf16*)xn, (const bf16*)y, coef, ls1, (bf16*)out, M, T, mode);
+}
+void kasf_launch_gcn_bwd1(int dt, hipStream_t s, const void* g, const void* xn, const void* y, const float* coef, const float* ls1, void* r,
+                          float* dls1, double* bstats, int B, int T, int mode) {
+    const int64_t M = (int64_t)B * T * KASF_J;
+    const int nodes = mode == 0 ? KASF_J : T;
+    unsigned grid = ew_grid(M);
+    if (grid > 1024) grid = 1024;
+    if (dt == KASF_F32) hipLaunchKernelGGL(k_gcn_bwd1<float>, dim3(grid), dim3(256), 0, s, (const float*)g, (const float*)xn, (const float*)y, coef, ls1, (float*)r, dls1, bstats, M, T, mode, nodes);
+    else hipLaunchKernelGGL(k_gcn_bwd1<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)g, (const bf16*)xn, (const bf16*)y, coef, ls1, (bf16*)r, dls1, bstats, M, T, mode, nodes);
+}
+void kasf_launch_gcn_bwd_finalize(hipStream_t s, const double* bstats, float* coef, float* d_bn_w, float* d_bn_b, int nodes, double count) {
+    hipLaunchKernelGGL(k_gcn_bwd_finalize, dim3(1), dim3(128), 0, s, bstats, coef, d_bn_w, d_bn_b, nodes, count);
+}
+void kasf_launch_gcn_bwd2(int dt, hipStream_t s, const void* r, const void* y, const float* coef, const uint32_t* mask, void* duv, int B, int T,
+                          int mode) {
+    kasf_gcn_init();
+    if (dt == KASF_F32) bwd2_T<float>(s, r, y, coef, mask, duv, B, T, mode);
+    else bwd2_T<bf16>(s, r, y, coef, mask, duv, B, T, mode);
+}

@@ -1,0 +1,90 @@
+// Internal host-side launchers (one per kernel family).  Everything takes raw device pointers;
+// tensors whose element type follows the model dtype (KASF_F32 / KASF_BF16) are passed as void*.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define KASF_F32 0
+#define KASF_BF16 1
+
+struct KasfPackDesc {
+    int64_t src;        // element offset into the fp32 parameter buffer
+    int64_t dst;        // element offset into the packed arena
+    int64_t scale;      // element offset of a per-row scale vector in the parameter buffer, or -1
+    int rows, cols;     // source is [rows][cols] row-major
+    int transpose;      // 1: destination is [cols][rows]
+    int pad_;
+};
+
+// element offsets (fp32 parameter buffer) used by the prologue kernels
+struct KasfProOff {
+    int64_t mlp[51][4];     // [group*3 + channel] -> fc1.weight [16][n], fc1.bias [16], fc2.weight [1][16], fc2.bias [1]
+    int64_t embed_w[3];     // joints_embed, bone_embed, limb_embed  weight [128][3]
+    int64_t embed_b[3];     //                                        bias   [128]
+    int64_t pos[3];         // pos_embed, bone_pos_embed, limb_pos_embed [17][128]
+};
+
+int kasf_set_error(int code, const char* msg);
+
+// ---- k_gemm.hip ----
+void kasf_launch_linear(int dt, hipStream_t s, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* C, int64_t ldc,
+                        int64_t M, int N, const float* ln_g, const float* ln_b, void* xn_out, int act);
+void kasf_launch_linear_res(int dt, hipStream_t s, const void* A, const void* W, const float* bias, const float* ls, const void* resid, void* C,
+                            int64_t M);
+void kasf_launch_dgrad_lnbwd(int dt, hipStream_t s, const void* dY, int Kd, const void* Wt, const void* dxn_add, const void* X, const float* gamma,
+                             const void* resid, void* out, int accumulate, float* dgamma, float* dbeta, int64_t M);
+void kasf_launch_wgrad(int dt, hipStream_t s, const void* G, int64_t ldg, int N, const void* X, int64_t ldx, int K, const float* ln_g,
+                       const float* ln_b, float* out, int64_t ldo, float* dbias, int64_t M);
+void kasf_launch_pack(int dt, hipStream_t s, const float* params, void* arena, const KasfPackDesc* desc, const int* tile_start, int ndesc,
+                      int total_tiles);
+
+// ---- k_mlp.hip ----
+// out = x + ls2 * (GELU(LN(x) W1^T + b1) W2^T + b2)
+void kasf_launch_mlp_fwd(int dt, hipStream_t s, const void* x, const float* ln_g, const float* ln_b, const void* W1, const float* b1, const void* W2,
+                         const float* b2, const float* ls2, void* out, int64_t M);
+// g_in = g + LNbwd(dA), also writes H = GELU(Z) and dZ ([M x 512] each) for the weight-gradient GEMMs
+void kasf_launch_mlp_bwd(int dt, hipStream_t s, const void* x, const void* g, const float* ln_g, const float* ln_b, const void* W1, const float* b1,
+                         const void* W2t_scaled, const void* W1t, void* Hbuf, void* dZbuf, void* g_in, float* dgamma, float* dbeta, int64_t M);
+
+// ---- k_attn.hip ----
+// mode 0: spatial (groups = B*T frames of 17 tokens), mode 1: temporal (groups = B*17 joint tracks of T tokens)
+void kasf_launch_attn_fwd(int dt, hipStream_t s, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, void* o, int B, int T,
+                          int mode);
+void kasf_launch_attn_bwd(int dt, hipStream_t s, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, const void* d_o, void* dq,
+                          int64_t lddq, void* dk, void* dv, int64_t lddkv, int B, int T, int mode);
+
+// ---- k_gcn.hip ----
+void kasf_gcn_init();   // uploads the skeleton table to constant memory (blocking; call once per process before capture)
+void kasf_launch_gcn_agg_fwd(int dt, hipStream_t s, const void* uv, const void* xn, void* y, uint32_t* mask, double* stats, int B, int T, int mode);
+void kasf_launch_bn_finalize(hipStream_t s, const double* stats, const float* bn_w, const float* bn_b, float* run_mean, float* run_var, float* coef,
+                             int nodes, double count, int training, float momentum);
+void kasf_launch_gcn_apply(int dt, hipStream_t s, const void* x_in, const void* xn, const void* y, const float* coef, const float* ls1, void* out, int B,
+                           int T, int mode);
+void kasf_launch_gcn_bwd1(int dt, hipStream_t s, const void* g, const void* xn, const void* y, const float* coef, const float* ls1, void* r,
+                          float* dls1, double* bstats, int B, int T, int mode);
+void kasf_launch_gcn_bwd_finalize(hipStream_t s, const double* bstats, float* coef, float* d_bn_w, float* d_bn_b, int nodes, double count);
+void kasf_launch_gcn_bwd2(int dt, hipStream_t s, const void* r, const void* y, const float* coef, const uint32_t* mask, void* duv, int B, int T,
+                          int mode);
+
+// ---- k_misc.hip ----
+void kasf_launch_prologue_fwd(int dt, hipStream_t s, const float* x, const float* params, const KasfProOff* off, void* xj, void* xb, void* xl,
+                              float* bone3, float* limb3, int64_t frames);
+void kasf_launch_embed_bwd(int dt, hipStream_t s, const void* g, const float* in3, const float* W, float* dW, float* db, float* dpos, float* din3,
+                           int64_t frames);
+void kasf_launch_refusion_bwd(hipStream_t s, const float* x, const float* dlimb3, const float* params, float* grads, const KasfProOff* off,
+                              int64_t frames);
+void kasf_launch_gate_fwd(int dt, hipStream_t s, const void* xa, const void* xg, const void* xb, const float* W, const float* b, void* out,
+                          float* alpha, int64_t M, int adaptive);
+void kasf_launch_gate_bwd(int dt, hipStream_t s, const void* g, const void* xa, const void* xg, const void* xb, const float* W, const float* alpha,
+                          void* ga, void* gg, void* gb, float* dW, float* db, int64_t M, int adaptive);
+void kasf_launch_head_fwd(int dt, hipStream_t s, const void* rep, const float* W, const float* b, float* out, int64_t M);
+void kasf_launch_head_bwd(int dt, hipStream_t s, const float* dy, const void* rep, const float* W, void* dpre, float* dW, float* db, int64_t M);
+void kasf_launch_cast_to_f32(int dt, hipStream_t s, const void* src, float* dst, int64_t n);
+void kasf_launch_cast_from_f32(int dt, hipStream_t s, const float* src, void* dst, int64_t n);
+void kasf_launch_add_inplace(int dt, hipStream_t s, void* dst, const void* a, int64_t n);   // dst += a
+// in: dW = unscaled G = g^T A, db = colsum(g).  out: dls[n] = sum_k W[n][k] G[n][k] + bias[n] db[n];  dW *= ls[n];  db *= ls[n]
+void kasf_launch_finalize_ls(hipStream_t s, float* dW, const float* W, const float* bias, const float* ls, float* db, float* dls, int N, int K);
+void kasf_launch_loss3(hipStream_t s, const float* pred, const float* tgt, float* dpred, float* losses, int B, int T, float lambda_n, float lambda_v,
+                       float grad_scale);
+void kasf_launch_adamw(hipStream_t s, float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float wd,
+                       float bc1, float bc2, float grad_scale);

@@ -1,0 +1,100 @@
+// Tile-level helpers shared by the GEMM-family and fused-MLP kernels.
+#pragma once
+#include "common.h"
+
+// wave w of a 256-thread workgroup owns output features [64*(w&1), +64) x tokens [64*(w>>1), +64)
+__device__ __forceinline__ int wave_n0() { return ((threadIdx.x >> 6) & 1) * 64; }
+__device__ __forceinline__ int wave_m0() { return (threadIdx.x >> 7) * 64; }
+template <int BM> __device__ __forceinline__ int wave_m0_bm() { return (threadIdx.x >> 7) * (BM / 2); }
+
+template <typename T, int NT, int MT, typename F>
+__device__ __forceinline__ void acc_to_tile(T* sC, f32x4 (&acc)[NT][MT], int wn0, int wm0, F f) {
+    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int n = wn0 + nt * 16 + g * 4, m = wm0 + mt * 16 + i;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = f(acc[nt][mt][r], n + r);
+            store4(sC + Tile<T>::off4(m, n), v);
+        }
+}
+
+
+// LayerNorm backward over the BM x 128 tile of d(LN output) held in sC (swizzled, type T):
+//   out = [resid +] [out +] rstd * (dxh - mean(dxh) - xhat * mean(dxh * xhat)),  dxh = (sC [+ dxn_add]) * gamma
+// and dgamma += sum_m d*xhat, dbeta += sum_m d (block partials -> fp32 atomics).  xhat/rstd are
+// recomputed from X.  `red` is >= 16 KB of LDS that is free at this point (must not alias sC).
+template <typename T, int BM>
+__device__ __forceinline__ void lnbwd_rows(const T* sC, const T* __restrict__ X, const float* __restrict__ gamma, const T* __restrict__ dxn_add,
+                                           const T* __restrict__ resid, T* __restrict__ out, int accumulate, float* __restrict__ dgamma,
+                                           float* __restrict__ dbeta, int64_t row0, int64_t M, float* red) {
+    const int sub = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    float gm[8], dg[8], db[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { gm[i] = gamma[sub * 8 + i]; dg[i] = 0.f; db[i] = 0.f; }
+    for (int r = rl; r < BM; r += 16) {
+        const int64_t row = row0 + r;
+        if (row >= M) break;        // uniform across the 16 lanes that share a row
+        float d[8], x[8];
+        tile_load8(sC, r, sub * 8, d);
+        if (dxn_add != nullptr) {
+            float a[8];
+            load8(dxn_add + row * 128 + sub * 8, a);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) d[i] += a[i];
+        }
+        load8(X + row * 128 + sub * 8, x);
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += x[i];
+        const float mean = reduce16(s) * (1.0f / 128.0f);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { x[i] -= mean; q += x[i] * x[i]; }
+        const float rstd = rsqrtf(reduce16(q) * (1.0f / 128.0f) + KASF_LN_EPS);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            x[i] *= rstd;                       // xhat
+            dg[i] += d[i] * x[i];
+            db[i] += d[i];
+            d[i] *= gm[i];                      // dxhat
+            s1 += d[i];
+            s2 += d[i] * x[i];
+        }
+        s1 = reduce16(s1) * (1.0f / 128.0f);
+        s2 = reduce16(s2) * (1.0f / 128.0f);
+        float o[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = rstd * (d[i] - s1 - x[i] * s2);
+        if (resid != nullptr) {
+            float a[8];
+            load8(resid + row * 128 + sub * 8, a);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] += a[i];
+        }
+        if (accumulate) {
+            float a[8];
+            load8(out + row * 128 + sub * 8, a);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] += a[i];
+        }
+        store8(out + row * 128 + sub * 8, o);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        red[rl * 128 + sub * 8 + i] = dg[i];
+        red[2048 + rl * 128 + sub * 8 + i] = db[i];
+    }
+    __syncthreads();
+    {
+        const int c = threadIdx.x & 127, which = threadIdx.x >> 7;
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += red[which * 2048 + k * 128 + c];
+        atomicAdd((which ? dbeta : dgamma) + c, s);
+    }
+}

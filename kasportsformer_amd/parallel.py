@@ -1,0 +1,46 @@
+"""Single-node data parallelism: one process per GPU, replicated weights, RCCL all-reduce over xGMI.
+
+Replaces the reference's ``nn.DataParallel`` (train_and_evaluate_sp.py:262-263).  Clips are independent
+except for BatchNorm batch statistics, which the reference already computes per replica; the only
+exchange step is the gradient all-reduce.  Gradients live in ONE flat fp32 array laid out layer by layer,
+so each backward stage finalises a contiguous range that is all-reduced (sum) asynchronously while the
+next layer's backward kernels run; 1/world_size is folded into the optimizer step.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+class DataParallel:
+    def __init__(self, model, process_group=None, overlap=True):
+        if not dist.is_initialized():
+            raise RuntimeError("init torch.distributed first (backend 'nccl' = RCCL on ROCm; 'gloo' for CPU rehearsal)")
+        self.model, self.group, self.overlap = model, process_group, overlap
+        self.world = dist.get_world_size(process_group)
+        self._pending = []
+        self.sync_from_rank0()
+        model.grad_stage_hook = self._on_stage if overlap else None
+
+    def sync_from_rank0(self):
+        """Broadcast parameters and BatchNorm buffers (DataParallel keeps replica 0's buffers)."""
+        m = self.model
+        for t in (m._flat, m._flat_buffers, m._nbt):
+            dist.broadcast(t, src=0, group=self.group)
+        m.mark_weights_dirty()
+
+    def _on_stage(self, stage, grad_slice):
+        self._pending.append(dist.all_reduce(grad_slice, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish_gradients(self):
+        """Call after loss.backward(): waits for the bucketed all-reduces (or runs one when overlap is off)."""
+        m = self.model
+        if self.overlap:
+            for w in self._pending:
+                w.wait()
+            self._pending = []
+        elif m.flat_grad is not None:
+            dist.all_reduce(m.flat_grad[:m.n_live], op=dist.ReduceOp.SUM, group=self.group)
+
+    def __call__(self, x, return_rep=False):
+        return self.model(x, return_rep)

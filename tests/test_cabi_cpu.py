@@ -1,0 +1,107 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol declared in
+include/kasf.h, its parameter layout covers exactly the reference's state_dict, and the host module keeps
+the reference's constructor / state_dict contract.  No compute is launched (there is no GPU here)."""
+import ctypes as C
+import json
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_are_exported():
+    from kasportsformer_amd import _lib
+    lib = _lib.load()
+    hdr = open(os.path.join(ROOT, "include", "kasf.h")).read()
+    declared = set(re.findall(r"\b(kasf_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"kasf_ws_name"}                                   # mentioned in a comment only
+    assert len(declared) >= 25
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/kasf.h but not exported"
+        assert name in _lib.SIGNATURES, f"{name} has no ctypes prototype"
+    assert lib.kasf_version() == 1
+
+
+def test_layout_covers_reference_state_dict(golden_dir):
+    from kasportsformer_amd import _lib
+    lib = _lib.load()
+    man = json.load(open(os.path.join(golden_dir, "state_dict_manifest.json")))
+    cfg = _lib.KasfConfig(26, 27, 8, 4, 1, 1)
+    h = C.c_void_p()
+    _lib.check(lib.kasf_model_create_layout_only(C.byref(cfg), C.byref(h)))
+    params = {n: (o, s) for n, o, s in _lib.param_entries(h)}
+    bufs = {n: (o, s) for n, o, s in _lib.buffer_entries(h)}
+    ref = {e[0]: tuple(e[1]) for e in man["entries"]}
+    nbt = {k for k in ref if k.endswith("num_batches_tracked")}
+    assert set(params) | set(bufs) | nbt == set(ref)
+    for n, (o, s) in {**params, **bufs}.items():
+        assert tuple(s) == ref[n], n
+    # slices do not overlap and are 16-byte aligned
+    spans = sorted((o, o + int(torch.Size(s).numel())) for o, s in params.values())
+    assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:])) and all(o % 4 == 0 for o, _ in spans)
+    live = lib.kasf_param_live_count(h)
+    dead = {n for n, (o, _) in params.items() if o >= live}
+    assert dead == set(man["grad_none"]) and len(dead) == 208
+    assert sum(int(torch.Size(s).numel()) for _, s in params.values()) == man["n_params"]
+    # backward stages finalise disjoint gradient ranges that tile [0, live)
+    b, e = C.c_int64(), C.c_int64()
+    ranges = []
+    for st in range(lib.kasf_backward_stages(h)):
+        _lib.check(lib.kasf_stage_grad_range(h, st, C.byref(b), C.byref(e)))
+        if e.value > b.value:
+            ranges.append((b.value, e.value))
+    ranges.sort()
+    assert ranges[0][0] == 0 and ranges[-1][1] == live and all(a[1] == c[0] for a, c in zip(ranges, ranges[1:]))
+    assert lib.kasf_workspace_bytes(h, 256, 1) > lib.kasf_workspace_bytes(h, 256, 0) > 0
+    lib.kasf_model_destroy(h)
+
+
+def test_host_module_contract(golden_dir):
+    import kasportsformer_amd as K
+    man = json.load(open(os.path.join(golden_dir, "state_dict_manifest.json")))
+    m = K.KASportsFormer(n_layers=26, dim_in=3, dim_feat=128, dim_rep=512, dim_out=3, mlp_ratio=4, num_heads=8, n_frames=27)
+    sd = m.state_dict()
+    assert [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in sd.items()] == man["entries"]
+    assert sum(p.numel() for p in m.parameters()) == 29365668
+    # parameters are views of one flat array: an in-place optimizer update is visible to the kernels
+    w = m.layers_with_bone[3].att_spatial.mixer.qkv.weight
+    off = m._p_entries["layers_with_bone.3.att_spatial.mixer.qkv.weight"][0]
+    with torch.no_grad():
+        w.add_(1.0)
+    assert torch.equal(m._flat[off:off + w.numel()].view_as(w), w.detach())
+    # load_state_dict keeps the flat storage
+    from oracle import kasf_oracle as O
+    fill = O.name_seeded_fill(sd)
+    m.load_state_dict(fill, strict=True)
+    assert torch.equal(m._flat[off:off + w.numel()].view_as(w), fill["layers_with_bone.3.att_spatial.mixer.qkv.weight"])
+    # same default init as the reference's constructor order under the same seed (oracle mirrors it)
+    torch.manual_seed(114514)
+    a = K.KASportsFormer(n_layers=1, num_heads=8)
+    torch.manual_seed(114514)
+    b = O.KASportsFormerOracle(n_layers=1, num_heads=8)
+    for (n1, p1), (n2, p2) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert n1 == n2 and torch.equal(p1, p2), n1
+
+
+def test_unsupported_configurations_raise_like_the_reference():
+    import kasportsformer_amd as K
+    from torch import nn
+    with pytest.raises(NotImplementedError):
+        K.KASportsFormer(num_heads=4)                      # reference default; every yaml overrides to 8
+    with pytest.raises(NotImplementedError):
+        K.KASportsFormer(num_heads=8, drop=0.1)
+    with pytest.raises(NotImplementedError):
+        K.KASportsFormer(num_heads=8, act_layer=nn.ReLU)
+    m = K.KASportsFormer(n_layers=1, num_heads=8, use_tcn=False, graph_only=False, temporal_connection_len=1)   # dead kwargs accepted
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(2, 27, 17, 3))                       # no CPU fallback
+    args = dict(model_name="KASportsFormer", n_layers=1, dim_in=3, dim_feat=128, dim_rep=512, dim_out=3, mlp_ratio=4, act_layer="gelu",
+                attn_drop=0.0, drop=0.0, drop_path=0.0, use_layer_scale=True, layer_scale_init_value=1e-5, use_adaptive_fusion=True,
+                num_heads=8, qkv_bias=False, qkv_scale=None, hierarchical=False, num_joints=17, use_temporal_similarity=True,
+                temporal_connection_len=1, use_tcn=False, graph_only=False, neighbour_num=4, n_frames=27)
+    assert isinstance(K.load_model(args), K.KASportsFormer)
+    with pytest.raises(Exception):
+        K.load_model(dict(args, model_name="MotionAGFormer"))

@@ -1,0 +1,201 @@
+"""GPU parity of the single-operator C-ABI entry points (include/kasf.h, kasf_op_*) against plain fp32
+torch math of the same op (the per-module oracle).  fp32 mode must hold 1e-3 (north_star tolerance,
+observed ~1e-6); bf16 mode is checked against the same math on bf16-rounded operands."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.gpu_util import DT, ptr, rel_err, stream
+
+pytestmark = pytest.mark.gpu
+TOL = {"fp32": 1e-4, "bf16": 3e-2}
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from kasportsformer_amd import _lib
+    return _lib.load()
+
+
+def _rand(*shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def _dev(t, cd):
+    return t.cuda().to(DT[cd][1]).contiguous()
+
+
+def _back(t):
+    return t.float().cpu()
+
+
+def _ln(x, g, b):
+    return F.layer_norm(x, (128,), g, b, 1e-5)
+
+
+@pytest.mark.parametrize("cd", ["fp32", "bf16"])
+@pytest.mark.parametrize("use_ln,act,N", [(True, 0, 384), (False, 0, 128), (True, 1, 512)])
+def test_linear(lib, cd, use_ln, act, N):
+    from kasportsformer_amd import _lib
+    M = 300
+    a, w, bias = _rand(M, 128, seed=1), _rand(N, 128, seed=2, scale=1 / math.sqrt(128)), _rand(N, seed=3, scale=0.1)
+    g, b = torch.rand(128) + 0.5, _rand(128, seed=4, scale=0.1)
+    ad, wd = _dev(a, cd), _dev(w, cd)
+    y = torch.empty(M, N, device="cuda", dtype=DT[cd][1])
+    xn = torch.empty(M, 128, device="cuda", dtype=DT[cd][1])
+    _lib.check(lib.kasf_op_linear(DT[cd][0], ptr(ad), ptr(wd), ptr(bias.cuda()), ptr(y), M, N, ptr(g.cuda()) if use_ln else None,
+                                  ptr(b.cuda()) if use_ln else None, ptr(xn) if use_ln else None, act, stream()))
+    torch.cuda.synchronize()
+    ar, wr = _back(ad), _back(wd)
+    h = _ln(ar, g, b) if use_ln else ar
+    ref = h @ wr.T + bias
+    if act:
+        ref = torch.tanh(ref)
+    assert rel_err(_back(y), ref) < TOL[cd]
+    if use_ln:
+        assert rel_err(_back(xn), h) < TOL[cd]
+
+
+def _mlp_params(seed=10):
+    return dict(W1=_rand(512, 128, seed=seed, scale=1 / math.sqrt(128)), b1=_rand(512, seed=seed + 1, scale=0.1),
+                W2=_rand(128, 512, seed=seed + 2, scale=1 / math.sqrt(512)), b2=_rand(128, seed=seed + 3, scale=0.1),
+                ls=torch.rand(128) + 0.5, g=torch.rand(128) + 0.5, b=_rand(128, seed=seed + 4, scale=0.1))
+
+
+def _mlp_ref(x, p):
+    return x + p["ls"] * (F.gelu(_ln(x, p["g"], p["b"]) @ p["W1"].T + p["b1"]) @ p["W2"].T + p["b2"])
+
+
+@pytest.mark.parametrize("cd", ["fp32", "bf16"])
+@pytest.mark.parametrize("M", [459, 1000])
+def test_mlp_forward(lib, cd, M):
+    from kasportsformer_amd import _lib
+    p = _mlp_params()
+    x = _rand(M, 128, seed=5)
+    xd, w1, w2 = _dev(x, cd), _dev(p["W1"], cd), _dev(p["W2"], cd)
+    out = torch.empty_like(xd)
+    _lib.check(lib.kasf_op_mlp_fwd(DT[cd][0], ptr(xd), ptr(p["g"].cuda()), ptr(p["b"].cuda()), ptr(w1), ptr(p["b1"].cuda()), ptr(w2),
+                                   ptr(p["b2"].cuda()), ptr(p["ls"].cuda()), ptr(out), M, stream()))
+    torch.cuda.synchronize()
+    pr = dict(p, W1=_back(w1), W2=_back(w2))
+    assert rel_err(_back(out), _mlp_ref(_back(xd), pr)) < TOL[cd]
+
+
+@pytest.mark.parametrize("cd", ["fp32", "bf16"])
+def test_mlp_backward_and_wgrad(lib, cd):
+    from kasportsformer_amd import _lib
+    M = 459
+    p = _mlp_params(seed=20)
+    x, gout = _rand(M, 128, seed=6), _rand(M, 128, seed=7)
+    xd, gd, w1 = _dev(x, cd), _dev(gout, cd), _dev(p["W1"], cd)
+    w2ts = _dev((p["ls"][:, None] * p["W2"]).T.contiguous(), cd)       # [512,128]
+    w1t = _dev(p["W1"].T.contiguous(), cd)                              # [128,512]
+    H = torch.empty(M, 512, device="cuda", dtype=DT[cd][1])
+    dZ, gin = torch.empty_like(H), torch.empty_like(xd)
+    dg, db = torch.zeros(128, device="cuda"), torch.zeros(128, device="cuda")
+    _lib.check(lib.kasf_op_mlp_bwd(DT[cd][0], ptr(xd), ptr(gd), ptr(p["g"].cuda()), ptr(p["b"].cuda()), ptr(w1), ptr(p["b1"].cuda()), ptr(w2ts),
+                                   ptr(w1t), ptr(H), ptr(dZ), ptr(gin), ptr(dg), ptr(db), M, stream()))
+    dW1, db1 = torch.zeros(512, 128, device="cuda"), torch.zeros(512, device="cuda")
+    dW2, gsum = torch.zeros(128, 512, device="cuda"), torch.zeros(128, device="cuda")
+    _lib.check(lib.kasf_op_wgrad(DT[cd][0], ptr(dZ), 512, ptr(xd), 128, ptr(p["g"].cuda()), ptr(p["b"].cuda()), ptr(dW1), ptr(db1), M, stream()))
+    _lib.check(lib.kasf_op_wgrad(DT[cd][0], ptr(gd), 128, ptr(H), 512, None, None, ptr(dW2), ptr(gsum), M, stream()))
+    torch.cuda.synchronize()
+    # reference by autograd on the rounded operands
+    xr = _back(xd).requires_grad_(True)
+    pr = {k: (v.clone().requires_grad_(True) if k in ("W1", "b1", "W2", "g", "b") else v) for k, v in p.items()}
+    pr["W1"] = _back(w1).requires_grad_(True)
+    gr = _back(gd)
+    z = _ln(xr, pr["g"], pr["b"]) @ pr["W1"].T + pr["b1"]
+    h = F.gelu(z)
+    out = xr + p["ls"] * (h @ pr["W2"].T + p["b2"])
+    out.backward(gr)
+    tol = TOL[cd]
+    assert rel_err(_back(H), h) < tol
+    assert rel_err(_back(gin), xr.grad) < tol
+    assert rel_err(_back(dg), pr["g"].grad) < tol and rel_err(_back(db), pr["b"].grad) < tol
+    assert rel_err(_back(dW1), pr["W1"].grad) < tol and rel_err(_back(db1), pr["b1"].grad) < tol
+    # unscaled G2 = g^T H: dW2 = ls[:,None] * G2
+    assert rel_err(p["ls"][:, None] * _back(dW2), pr["W2"].grad) < tol
+    assert rel_err(_back(gsum), gr.sum(0)) < tol
+
+
+@pytest.mark.parametrize("cd", ["fp32", "bf16"])
+@pytest.mark.parametrize("Kd", [128, 384, 512])
+def test_dgrad_lnbwd(lib, cd, Kd):
+    from kasportsformer_amd import _lib
+    M = 333
+    x, dy, add, resid = _rand(M, 128, seed=8), _rand(M, Kd, seed=9), _rand(M, 128, seed=10), _rand(M, 128, seed=11)
+    W = _rand(Kd, 128, seed=12, scale=1 / math.sqrt(128))      # forward weight [out=Kd, in=128]
+    g, b = torch.rand(128) + 0.5, _rand(128, seed=13, scale=0.1)
+    xd, dyd, addd, rd = _dev(x, cd), _dev(dy, cd), _dev(add, cd), _dev(resid, cd)
+    wt = _dev(W.T.contiguous(), cd)                              # [128, Kd]
+    out = torch.empty_like(xd)
+    dg, db = torch.zeros(128, device="cuda"), torch.zeros(128, device="cuda")
+    _lib.check(lib.kasf_op_dgrad_lnbwd(DT[cd][0], ptr(dyd), Kd, ptr(wt), ptr(addd), ptr(xd), ptr(g.cuda()), ptr(rd), ptr(out), 0, ptr(dg), ptr(db),
+                                       M, stream()))
+    torch.cuda.synchronize()
+    xr = _back(xd).requires_grad_(True)
+    gp, bp = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    xn = _ln(xr, gp, bp)
+    dxn = _back(dyd) @ _back(wt).T + _back(addd)
+    xn.backward(dxn)
+    assert rel_err(_back(out), xr.grad + _back(rd)) < TOL[cd]
+    assert rel_err(_back(dg), gp.grad) < TOL[cd] and rel_err(_back(db), bp.grad) < TOL[cd]
+
+
+@pytest.mark.parametrize("cd", ["fp32", "bf16"])
+@pytest.mark.parametrize("mode,T", [(0, 27), (1, 27), (1, 81), (1, 9)])
+def test_attention_core(lib, cd, mode, T):
+    from kasportsformer_amd import _lib
+    from oracle.kasf_oracle import attention_core, _heads
+    B = 2
+    qkv = _rand(B, T, 17, 384, seed=14)
+    do = _rand(B, T, 17, 128, seed=15)
+    qd, dod = _dev(qkv, cd), _dev(do, cd)
+    o = torch.empty(B, T, 17, 128, device="cuda", dtype=DT[cd][1])
+    dqkv = torch.zeros_like(qd)
+    es = qd.element_size()
+    base = qd.data_ptr()
+    _lib.check(lib.kasf_op_attention_fwd(DT[cd][0], base, 384, base + 128 * es, base + 256 * es, 384, ptr(o), B, T, mode, stream()))
+    db = dqkv.data_ptr()
+    _lib.check(lib.kasf_op_attention_bwd(DT[cd][0], base, 384, base + 128 * es, base + 256 * es, 384, ptr(dod), db, 384, db + 128 * es,
+                                         db + 256 * es, 384, B, T, mode, stream()))
+    torch.cuda.synchronize()
+    qr = _back(qd).requires_grad_(True)
+    q, k, v = _heads(qr, 3, 8)
+    ref = attention_core(q, k, v, "spatial" if mode == 0 else "temporal", 0.25)
+    ref.backward(_back(dod))
+    assert rel_err(_back(o), ref) < TOL[cd]
+    assert rel_err(_back(dqkv), qr.grad) < TOL[cd]
+
+
+def test_loss3_and_adamw(lib):
+    import kasportsformer_amd as K
+    from oracle import kasf_oracle as O
+    pred = _rand(3, 27, 17, 3, seed=16).cuda().requires_grad_(True)
+    tgt = _rand(3, 27, 17, 3, seed=17).cuda()
+    total, parts = K.loss3(pred, tgt)
+    total.backward()
+    pr = pred.detach().cpu().requires_grad_(True)
+    ref, ref_parts = O.loss_total(pr, tgt.cpu())
+    ref.backward()
+    assert abs(total.item() - ref.item()) < 1e-5 * max(1.0, abs(ref.item()))
+    for a, b in zip(parts[1:].cpu().tolist(), ref_parts):
+        assert abs(a - b.item()) < 1e-5
+    assert rel_err(pred.grad, pr.grad) < 1e-4
+    # AdamW vs torch.optim.AdamW, 3 steps
+    from kasportsformer_amd import _lib
+    n = 4096
+    p0, gs = _rand(n, seed=18), [_rand(n, seed=19 + i) for i in range(3)]
+    pt = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([pt], lr=5e-4, weight_decay=0.01)
+    pd, m, v = p0.cuda(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    for i, g in enumerate(gs):
+        pt.grad = g.clone()
+        opt.step()
+        _lib.check(lib.kasf_adamw_step(ptr(pd), ptr(g.cuda()), ptr(m), ptr(v), n, 5e-4, 0.9, 0.999, 1e-8, 0.01, i + 1, 1.0, stream()))
+    torch.cuda.synchronize()
+    assert (pd.cpu() - pt.detach()).abs().max() < 1e-6
