@@ -97,7 +97,8 @@ def test_backward_matches_oracle(cd, tol):
     torch.cuda.synchronize()
     assert abs(loss.item() - loss_ref.item()) < (1e-4 if cd == "fp32" else 5e-2) * max(1.0, abs(loss_ref.item()))
     ref_grads = dict(oracle.named_parameters())
-    worst, none_mismatch = {}, []
+    gmax = max(float(q.grad.abs().max()) for q in ref_grads.values() if q.grad is not None)
+    worst, none_mismatch, dots = {}, [], [0.0, 0.0, 0.0]
     for n, p in model.named_parameters():
         r = ref_grads[n].grad
         if (r is None) != (p.grad is None):
@@ -105,9 +106,16 @@ def test_backward_matches_oracle(cd, tol):
             continue
         if r is None:
             continue
-        worst[n] = rel_err(p.grad, r)
+        g = p.grad.detach().double().cpu()
+        if cd == "fp32":
+            worst[n] = rel_err(g, r)
+        else:   # bf16: tiny gradients (limb-refusion MLPs behind 2 x 6 blocks) sit below bf16 noise -> floor the scale
+            worst[n] = float((g - r.double()).abs().max() / max(float(r.abs().max()), 0.02 * gmax))
+        dots[0] += float((g * r.double()).sum()); dots[1] += float((g * g).sum()); dots[2] += float((r.double() ** 2).sum())
     assert not none_mismatch, none_mismatch
     assert sum(1 for p in model.parameters() if p.grad is None) == 16      # 8 dead norm1_limb tensors per layer
+    cosine = dots[0] / (dots[1] ** 0.5 * dots[2] ** 0.5)
+    assert cosine > (0.999999 if cd == "fp32" else 0.995), cosine
     bad = sorted(((v, k) for k, v in worst.items() if not v < tol), reverse=True)
     assert not bad, f"{len(bad)} gradients above {tol}; worst: {bad[:12]}"
 

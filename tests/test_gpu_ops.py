@@ -24,8 +24,28 @@ def _rand(*shape, seed, scale=1.0):
     return torch.randn(*shape, generator=g) * scale
 
 
+_KEEP = []
+
+
+@pytest.fixture(autouse=True)
+def _keepalive():
+    """Device copies made by _f32()/_dev() must outlive the (asynchronous) kernel launches."""
+    _KEEP.clear()
+    yield
+    torch.cuda.synchronize()
+    _KEEP.clear()
+
+
 def _dev(t, cd):
-    return t.cuda().to(DT[cd][1]).contiguous()
+    d = t.cuda().to(DT[cd][1]).contiguous()
+    _KEEP.append(d)
+    return d
+
+
+def _f32(t):
+    d = t.float().cuda().contiguous()
+    _KEEP.append(d)
+    return d
 
 
 def _back(t):
@@ -46,8 +66,8 @@ def test_linear(lib, cd, use_ln, act, N):
     ad, wd = _dev(a, cd), _dev(w, cd)
     y = torch.empty(M, N, device="cuda", dtype=DT[cd][1])
     xn = torch.empty(M, 128, device="cuda", dtype=DT[cd][1])
-    _lib.check(lib.kasf_op_linear(DT[cd][0], ptr(ad), ptr(wd), ptr(bias.cuda()), ptr(y), M, N, ptr(g.cuda()) if use_ln else None,
-                                  ptr(b.cuda()) if use_ln else None, ptr(xn) if use_ln else None, act, stream()))
+    _lib.check(lib.kasf_op_linear(DT[cd][0], ptr(ad), ptr(wd), ptr(_f32(bias)), ptr(y), M, N, ptr(_f32(g)) if use_ln else None,
+                                  ptr(_f32(b)) if use_ln else None, ptr(xn) if use_ln else None, act, stream()))
     torch.cuda.synchronize()
     ar, wr = _back(ad), _back(wd)
     h = _ln(ar, g, b) if use_ln else ar
@@ -77,8 +97,8 @@ def test_mlp_forward(lib, cd, M):
     x = _rand(M, 128, seed=5)
     xd, w1, w2 = _dev(x, cd), _dev(p["W1"], cd), _dev(p["W2"], cd)
     out = torch.empty_like(xd)
-    _lib.check(lib.kasf_op_mlp_fwd(DT[cd][0], ptr(xd), ptr(p["g"].cuda()), ptr(p["b"].cuda()), ptr(w1), ptr(p["b1"].cuda()), ptr(w2),
-                                   ptr(p["b2"].cuda()), ptr(p["ls"].cuda()), ptr(out), M, stream()))
+    _lib.check(lib.kasf_op_mlp_fwd(DT[cd][0], ptr(xd), ptr(_f32(p["g"])), ptr(_f32(p["b"])), ptr(w1), ptr(_f32(p["b1"])), ptr(w2),
+                                   ptr(_f32(p["b2"])), ptr(_f32(p["ls"])), ptr(out), M, stream()))
     torch.cuda.synchronize()
     pr = dict(p, W1=_back(w1), W2=_back(w2))
     assert rel_err(_back(out), _mlp_ref(_back(xd), pr)) < TOL[cd]
@@ -96,11 +116,11 @@ def test_mlp_backward_and_wgrad(lib, cd):
     H = torch.empty(M, 512, device="cuda", dtype=DT[cd][1])
     dZ, gin = torch.empty_like(H), torch.empty_like(xd)
     dg, db = torch.zeros(128, device="cuda"), torch.zeros(128, device="cuda")
-    _lib.check(lib.kasf_op_mlp_bwd(DT[cd][0], ptr(xd), ptr(gd), ptr(p["g"].cuda()), ptr(p["b"].cuda()), ptr(w1), ptr(p["b1"].cuda()), ptr(w2ts),
+    _lib.check(lib.kasf_op_mlp_bwd(DT[cd][0], ptr(xd), ptr(gd), ptr(_f32(p["g"])), ptr(_f32(p["b"])), ptr(w1), ptr(_f32(p["b1"])), ptr(w2ts),
                                    ptr(w1t), ptr(H), ptr(dZ), ptr(gin), ptr(dg), ptr(db), M, stream()))
     dW1, db1 = torch.zeros(512, 128, device="cuda"), torch.zeros(512, device="cuda")
     dW2, gsum = torch.zeros(128, 512, device="cuda"), torch.zeros(128, device="cuda")
-    _lib.check(lib.kasf_op_wgrad(DT[cd][0], ptr(dZ), 512, ptr(xd), 128, ptr(p["g"].cuda()), ptr(p["b"].cuda()), ptr(dW1), ptr(db1), M, stream()))
+    _lib.check(lib.kasf_op_wgrad(DT[cd][0], ptr(dZ), 512, ptr(xd), 128, ptr(_f32(p["g"])), ptr(_f32(p["b"])), ptr(dW1), ptr(db1), M, stream()))
     _lib.check(lib.kasf_op_wgrad(DT[cd][0], ptr(gd), 128, ptr(H), 512, None, None, ptr(dW2), ptr(gsum), M, stream()))
     torch.cuda.synchronize()
     # reference by autograd on the rounded operands
@@ -134,7 +154,7 @@ def test_dgrad_lnbwd(lib, cd, Kd):
     wt = _dev(W.T.contiguous(), cd)                              # [128, Kd]
     out = torch.empty_like(xd)
     dg, db = torch.zeros(128, device="cuda"), torch.zeros(128, device="cuda")
-    _lib.check(lib.kasf_op_dgrad_lnbwd(DT[cd][0], ptr(dyd), Kd, ptr(wt), ptr(addd), ptr(xd), ptr(g.cuda()), ptr(rd), ptr(out), 0, ptr(dg), ptr(db),
+    _lib.check(lib.kasf_op_dgrad_lnbwd(DT[cd][0], ptr(dyd), Kd, ptr(wt), ptr(addd), ptr(xd), ptr(_f32(g)), ptr(rd), ptr(out), 0, ptr(dg), ptr(db),
                                        M, stream()))
     torch.cuda.synchronize()
     xr = _back(xd).requires_grad_(True)
@@ -196,6 +216,6 @@ def test_loss3_and_adamw(lib):
     for i, g in enumerate(gs):
         pt.grad = g.clone()
         opt.step()
-        _lib.check(lib.kasf_adamw_step(ptr(pd), ptr(g.cuda()), ptr(m), ptr(v), n, 5e-4, 0.9, 0.999, 1e-8, 0.01, i + 1, 1.0, stream()))
+        _lib.check(lib.kasf_adamw_step(ptr(pd), ptr(_f32(g)), ptr(m), ptr(v), n, 5e-4, 0.9, 0.999, 1e-8, 0.01, i + 1, 1.0, stream()))
     torch.cuda.synchronize()
     assert (pd.cpu() - pt.detach()).abs().max() < 1e-6
