@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the KASportsFormer hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one full training pass of the path over one batch already resident in HBM: forward, fused
+3-term loss, backward, (N>1: bucketed RCCL all-reduce of the flat gradient, overlapped with backward),
+fused AdamW.  Workload (BASELINE.json configs[1]): SportsPose-GT 27-frame clips, bf16 compute, batch 256
+per GPU, the shipped 26-layer model, synthetic inputs, reference default init under seed 114514.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BATCH_PER_GPU, T, LAYERS = 256, 27, 26
+PEAK_BF16_TFLOPS = 2500.0            # dense bf16 MFMA peak (MI355X_MICROARCH.md)
+FLOP_PER_CLIP_TRAIN = 82.31e9        # 3 x 27.44 GFLOP forward
+MLP_FLOP_PER_TOKEN_FWD = 262144      # fc1 + fc2 (2 x 2 x 128 x 512)
+
+
+def time_kernel(fn, iters=20, warmup=3):
+    for _ in range(warmup):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def kernel_rooflines(M):
+    """Times the MLP kernels (the dominant launches: ~69 % of the path's FLOPs) in isolation on torch's
+    current stream, the stream the library launches on."""
+    from kasportsformer_amd import _lib
+    lib = _lib.load()
+    dev = "cuda"
+    g = torch.Generator(device="cpu").manual_seed(0)
+    bf = torch.bfloat16
+    x = torch.randn(M, 128, generator=g).to(dev, bf)
+    gout = torch.randn(M, 128, generator=g).to(dev, bf)
+    w1 = (torch.randn(512, 128, generator=g) / 11.3).to(dev, bf)
+    w2 = (torch.randn(128, 512, generator=g) / 22.6).to(dev, bf)
+    w2ts, w1t = w2.t().contiguous(), w1.t().contiguous()
+    b1, b2 = torch.zeros(512, device=dev), torch.zeros(128, device=dev)
+    ls, gam, bet = torch.ones(128, device=dev), torch.ones(128, device=dev), torch.zeros(128, device=dev)
+    out, gin = torch.empty_like(x), torch.empty_like(x)
+    H, dZ = torch.empty(M, 512, device=dev, dtype=bf), torch.empty(M, 512, device=dev, dtype=bf)
+    dg, db = torch.zeros(128, device=dev), torch.zeros(128, device=dev)
+    dW1, db1 = torch.zeros(512, 128, device=dev), torch.zeros(512, device=dev)
+    dW2, gs = torch.zeros(128, 512, device=dev), torch.zeros(128, device=dev)
+    st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    fwd = lambda: lib.kasf_op_mlp_fwd(1, p(x), p(gam), p(bet), p(w1), p(b1), p(w2), p(b2), p(ls), p(out), M, st())
+    bwd = lambda: lib.kasf_op_mlp_bwd(1, p(x), p(gout), p(gam), p(bet), p(w1), p(b1), p(w2ts), p(w1t), p(H), p(dZ), p(gin), p(dg), p(db), M, st())
+    wg1 = lambda: lib.kasf_op_wgrad(1, p(dZ), 512, p(x), 128, p(gam), p(bet), p(dW1), p(db1), M, st())
+    wg2 = lambda: lib.kasf_op_wgrad(1, p(gout), 128, p(H), 512, None, None, p(dW2), p(gs), M, st())
+    res = {}
+    for name, fn, flop in (("k_mlp_fwd", fwd, MLP_FLOP_PER_TOKEN_FWD * M), ("k_mlp_bwd", bwd, MLP_FLOP_PER_TOKEN_FWD * M),
+                           ("k_wgrad_fc1", wg1, MLP_FLOP_PER_TOKEN_FWD // 2 * M), ("k_wgrad_fc2", wg2, MLP_FLOP_PER_TOKEN_FWD // 2 * M)):
+        t = time_kernel(fn)
+        res[name] = {"seconds": t, "achieved_tflops": flop / t / 1e12, "algorithmic_flop": flop}
+    return res
+
+
+def cpu_baseline(batch=8, steps=2):
+    """Bounded sample of the SAME workload on the host cores: the CPU oracle (PyTorch fp32 restatement,
+    verified equal to the reference on the golden fixtures) doing forward + 3-term loss + backward + AdamW."""
+    from oracle import kasf_oracle as O
+    torch.manual_seed(114514)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 32))           # the GPU box gives this job a CPU share; do not oversubscribe it
+    torch.set_num_threads(cores)
+    print(f"[bench] cpu_baseline: {cores} threads (os.cpu_count()={os.cpu_count()})", file=sys.stderr, flush=True)
+    m = O.KASportsFormerOracle(n_layers=LAYERS, num_heads=8, n_frames=T).train()
+    opt = torch.optim.AdamW(m.parameters(), lr=5e-4, weight_decay=0.01)
+    x, y = O.synthetic_clips(batch, T)
+    times = []
+    for i in range(steps + 1):
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        loss, _ = O.loss_total(m(x), y)
+        loss.backward()
+        opt.step()
+        times.append(time.perf_counter() - t0)
+        print(f"[bench] cpu_baseline step {i}: {times[-1]:.2f} s", file=sys.stderr, flush=True)
+    dt = sum(times[1:]) / steps
+    return {"value": batch / dt, "unit": "pose-clips/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} timed train steps (1 warm-up) of the 26-layer fp32 CPU oracle at batch {batch}, T={T}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="clips per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    import kasportsformer_amd as K
+    from oracle import kasf_oracle as O      # synthetic input generator only (checker-side data recipe)
+
+    torch.manual_seed(114514)                # configs/*.yaml:17
+    model = K.KASportsFormer(n_layers=LAYERS, num_heads=8, n_frames=T, compute_dtype="bf16").cuda().train()
+    model.attach_param_grads = False
+    opt = K.FusedAdamW(model, lr=5e-4, weight_decay=0.01)
+    dp = None
+    if world > 1:
+        dp = K.DataParallel(model)
+        opt.grad_scale = 1.0 / world
+    x, y = O.synthetic_clips(args.batch, T, seed=1234 + rank)
+    x, y = x.cuda(), y.cuda()
+
+    def step():
+        opt.zero_grad()
+        loss, parts = K.loss3(model(x), y)
+        loss.backward()
+        if dp is not None:
+            dp.finish_gradients()
+        opt.step()
+        return parts
+
+    def log(msg):
+        if rank == 0:
+            print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+    log(f"model on GPU; ws(train,B={args.batch}) = {model._lib.kasf_workspace_bytes(model._device_handle(), args.batch, 1) / 1e9:.1f} GB")
+    for i in range(args.warmup):
+        step()
+        torch.cuda.synchronize()
+        log(f"warm-up step {i} done")
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        parts = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    loss_val = float(parts[0].item())
+    log(f"timed {args.steps} steps in {dt:.3f} s")
+
+    if rank == 0:
+        clips = args.batch * world * args.steps
+        value = clips / dt
+        out = {
+            "metric": "pose-clips/sec (27f x 17j) training step: fwd + 3-term loss + bwd + AdamW", "value": value, "unit": "pose-clips/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "SportsPose-GT 27-frame bf16 training, batch=256 per GPU (BASELINE.json configs[1])", "n_layers": LAYERS,
+                       "batch_per_gpu": args.batch, "global_batch": args.batch * world, "n_frames": T, "tokens_per_step_per_gpu": args.batch * T * 17,
+                       "parallelism": f"dp{world}" if world > 1 else "single", "init": "reference default init, seed 114514"},
+            "final_loss": loss_val,
+            "model_mfma_frac": value / world * FLOP_PER_CLIP_TRAIN / (PEAK_BF16_TFLOPS * 1e12),
+        }
+        if not args.no_kernel_roofline:
+            ks = kernel_rooflines(args.batch * T * 17)
+            log("kernel rooflines done")
+            dom = max(ks, key=lambda k: ks[k]["seconds"])
+            out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ks[dom]["achieved_tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                               "frac": ks[dom]["achieved_tflops"] / PEAK_BF16_TFLOPS, "traffic": None,
+                               "launch_ms": ks[dom]["seconds"] * 1e3, "algorithmic_flop_per_launch": ks[dom]["algorithmic_flop"]}
+            out["kernels"] = {k: {"ms": v["seconds"] * 1e3, "tflops": v["achieved_tflops"]} for k, v in ks.items()}
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
