@@ -64,7 +64,7 @@ def kernel_rooflines(M):
     p = lambda t: C.c_void_p(t.data_ptr())
     fwd = lambda: lib.kasf_op_mlp_fwd(1, p(x), p(gam), p(bet), p(w1), p(b1), p(w2), p(b2), p(ls), p(out), M, st())
     bwd = lambda: lib.kasf_op_mlp_bwd(1, p(x), p(gout), p(gam), p(bet), p(w1), p(b1), p(w2ts), p(w1t), p(H), p(dZ), p(gin), p(dg), p(db), M, st())
-    wg1 = lambda: lib.kasf_op_wgrad(1, p(dZ), 512, p(x), 128, p(gam), p(bet), p(dW1), p(db1), M, st())
+    wg1 = lambda: lib.kasf_op_wgrad(1, p(dZ), 512, p(x), 128, None, None, p(dW1), p(db1), M, st())   # engine path: X = LN(x) emitted by k_mlp_bwd
     wg2 = lambda: lib.kasf_op_wgrad(1, p(gout), 128, p(H), 512, None, None, p(dW2), p(gs), M, st())
     res = {}
     for name, fn, flop in (("k_mlp_fwd", fwd, MLP_FLOP_PER_TOKEN_FWD * M), ("k_mlp_bwd", bwd, MLP_FLOP_PER_TOKEN_FWD * M),

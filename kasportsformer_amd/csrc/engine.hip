@@ -39,7 +39,7 @@ struct Plan {
     int64_t total = 0, stats_begin = 0, stats_bytes = 0, bstats_begin = 0, bstats_bytes = 0;
     int64_t x3, bone3, limb3, xj, xb, xl, rep, uv;
     std::vector<LayerWs> layers;
-    int64_t g_layer, g_prev, ga, gg, gb, t1, t2, g_limb, g_bone, hbuf, dzbuf, d_o, dqkv, rbuf, duv, dlimb3;
+    int64_t g_layer, g_prev, ga, gg, gb, t1, t2, g_limb, g_bone, hbuf, dzbuf, d_o, dqkv, rbuf, duv, dlimb3, xn_a, xn_b;
     std::vector<WsEntry> entries;
 };
 
@@ -289,6 +289,8 @@ void build_plan(const kasf_model* m, int B, bool train, bool names, Plan& p) {
         p.rbuf = take(M * 128, 0, "gcn_r");
         p.duv = take(M * 256, 0, "gcn_duv");
         p.dlimb3 = take(M * 3, 1, "dlimb3");
+        p.xn_a = take(M * 128, 0, "scratch_xn_a");
+        p.xn_b = take(M * 128, 0, "scratch_xn_b");
     }
     p.total = cur;
 }
@@ -342,8 +344,8 @@ void block_backward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void*
     void* g_mid = c.w(p.t2);
     // ---- MLP half ----
     kasf_launch_mlp_bwd(c.dt, c.s, c.w(w.x_mid), g_out, P + o.n2w, P + o.n2b, c.pk(o.p_fc1), P + o.fc1b, c.pk(o.p_fc2Ts), c.pk(o.p_fc1T), c.w(p.hbuf),
-                        c.w(p.dzbuf), g_mid, G + o.n2w, G + o.n2b, c.M);
-    kasf_launch_wgrad(c.dt, c.s, c.w(p.dzbuf), 512, 512, c.w(w.x_mid), 128, 128, P + o.n2w, P + o.n2b, G + o.fc1w, 128, G + o.fc1b, c.M);
+                        c.w(p.dzbuf), c.w(p.xn_a), g_mid, G + o.n2w, G + o.n2b, c.M);
+    kasf_launch_wgrad(c.dt, c.s, c.w(p.dzbuf), 512, 512, c.w(p.xn_a), 128, 128, nullptr, nullptr, G + o.fc1w, 128, G + o.fc1b, c.M);
     kasf_launch_wgrad(c.dt, c.s, g_out, 128, 128, c.w(p.hbuf), 512, 512, nullptr, nullptr, G + o.fc2w, 512, G + o.fc2b, c.M);
     kasf_launch_finalize_ls(c.s, G + o.fc2w, P + o.fc2w, P + o.fc2b, P + o.ls2, G + o.fc2b, G + o.ls2, 128, 512);
     // ---- mixer half ----
@@ -368,17 +370,20 @@ void block_backward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void*
         char* dq = (char*)c.w(p.dqkv);
         kasf_launch_attn_bwd(c.dt, c.s, q, 384, q + 128 * c.es, q + 256 * c.es, 384, c.w(p.d_o), dq, 384, dq + 128 * c.es, dq + 256 * c.es, 384, c.B, c.T,
                              o.mode);
-        kasf_launch_dgrad_lnbwd(c.dt, c.s, dq, 384, c.pk(o.p_mixT), nullptr, x_in, P + o.n1w, g_mid, dst, accumulate, G + o.n1w, G + o.n1b, c.M);
-        kasf_launch_wgrad(c.dt, c.s, dq, 384, 384, x_in, 128, 128, P + o.n1w, P + o.n1b, G + o.mix_w, 128, nullptr, c.M);
+        kasf_launch_dgrad_lnbwd(c.dt, c.s, dq, 384, c.pk(o.p_mixT), nullptr, x_in, P + o.n1w, g_mid, dst, accumulate, G + o.n1w, G + o.n1b, c.M,
+                                c.w(p.xn_a), P + o.n1b);
+        kasf_launch_wgrad(c.dt, c.s, dq, 384, 384, c.w(p.xn_a), 128, 128, nullptr, nullptr, G + o.mix_w, 128, nullptr, c.M);
     } else {
         const char* kv = (const char*)c.w(w.kv);
         char* dq = (char*)c.w(p.dqkv);
         char* dkv = dq + c.M * 128 * c.es;
         kasf_launch_attn_bwd(c.dt, c.s, c.w(w.qkv), 128, kv, kv + 128 * c.es, 256, c.w(p.d_o), dq, 128, dkv, dkv + 128 * c.es, 256, c.B, c.T, o.mode);
-        kasf_launch_dgrad_lnbwd(c.dt, c.s, dq, 128, c.pk(o.p_mixT), nullptr, x_in, P + o.n1w, g_mid, dst, accumulate, G + o.n1w, G + o.n1b, c.M);
-        kasf_launch_dgrad_lnbwd(c.dt, c.s, dkv, 256, c.pk(o.p_kvT), nullptr, x_limb, P + o.n1lw, nullptr, c.w(p.g_limb), 1, G + o.n1lw, G + o.n1lb, c.M);
-        kasf_launch_wgrad(c.dt, c.s, dq, 128, 128, x_in, 128, 128, P + o.n1w, P + o.n1b, G + o.mix_w, 128, nullptr, c.M);
-        kasf_launch_wgrad(c.dt, c.s, dkv, 256, 256, x_limb, 128, 128, P + o.n1lw, P + o.n1lb, G + o.kv_w, 128, nullptr, c.M);
+        kasf_launch_dgrad_lnbwd(c.dt, c.s, dq, 128, c.pk(o.p_mixT), nullptr, x_in, P + o.n1w, g_mid, dst, accumulate, G + o.n1w, G + o.n1b, c.M,
+                                c.w(p.xn_a), P + o.n1b);
+        kasf_launch_dgrad_lnbwd(c.dt, c.s, dkv, 256, c.pk(o.p_kvT), nullptr, x_limb, P + o.n1lw, nullptr, c.w(p.g_limb), 1, G + o.n1lw, G + o.n1lb, c.M,
+                                c.w(p.xn_b), P + o.n1lb);
+        kasf_launch_wgrad(c.dt, c.s, dq, 128, 128, c.w(p.xn_a), 128, 128, nullptr, nullptr, G + o.mix_w, 128, nullptr, c.M);
+        kasf_launch_wgrad(c.dt, c.s, dkv, 256, 256, c.w(p.xn_b), 128, 128, nullptr, nullptr, G + o.kv_w, 128, nullptr, c.M);
     }
 }
 
@@ -566,9 +571,8 @@ int kasf_backward(const kasf_model* m, const float* params, const void* packed, 
             const void* x_final = c.w(p.layers[L - 1].gate_out);
             kasf_launch_head_bwd(c.dt, c.s, dout, c.w(p.rep), params + t.head_w, c.w(p.hbuf), grads + t.head_w, grads + t.head_b, c.M);
             kasf_launch_dgrad_lnbwd(c.dt, c.s, c.w(p.hbuf), 512, c.pk(t.p_fcT), nullptr, x_final, params + t.norm_w, nullptr, gbuf(0), 0, grads + t.norm_w,
-                                    grads + t.norm_b, c.M);
-            kasf_launch_wgrad(c.dt, c.s, c.w(p.hbuf), 512, 512, x_final, 128, 128, params + t.norm_w, params + t.norm_b, grads + t.fc_w, 128, grads + t.fc_b,
-                              c.M);
+                                    grads + t.norm_b, c.M, c.w(p.xn_a), params + t.norm_b);
+            kasf_launch_wgrad(c.dt, c.s, c.w(p.hbuf), 512, 512, c.w(p.xn_a), 128, 128, nullptr, nullptr, grads + t.fc_w, 128, grads + t.fc_b, c.M);
         } else if (st <= L) {
             const int l = L - st;
             const LayerOff& lo = m->layers[l];
@@ -641,7 +645,7 @@ int kasf_op_mlp_fwd(int32_t dtype, const void* x, const float* ln_g, const float
 int kasf_op_mlp_bwd(int32_t dtype, const void* x, const void* g, const float* ln_g, const float* ln_b, const void* w1, const float* b1,
                     const void* w2t_scaled, const void* w1t, void* hbuf, void* dzbuf, void* g_in, float* dgamma, float* dbeta, int64_t M, void* stream) {
     OP_DT_CHECK(dtype);
-    kasf_launch_mlp_bwd(dtype, (hipStream_t)stream, x, g, ln_g, ln_b, w1, b1, w2t_scaled, w1t, hbuf, dzbuf, g_in, dgamma, dbeta, M);
+    kasf_launch_mlp_bwd(dtype, (hipStream_t)stream, x, g, ln_g, ln_b, w1, b1, w2t_scaled, w1t, hbuf, dzbuf, nullptr, g_in, dgamma, dbeta, M);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -14,111 +14,142 @@
 
 namespace {
 
+template <typename T> __device__ __forceinline__ void add_bias4(float (&v)[4], const float* bias) {
+    if (bias != nullptr) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(bias);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += b[r];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
-template <typename T, bool LN, int ACT>
+// C[M x N] = act(LN?(A)[M x 128] . W[N x 128]^T + bias).  One workgroup = BM tokens; the weight is
+// streamed 128 rows at a time by LDS-direct loads into NBUF tiles (block nb+1 lands while block nb
+// is multiplied); the epilogue goes straight from the accumulators to HBM.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int BM, int NBUF, bool LN, int ACT>
 __global__ __launch_bounds__(256) void k_linear(const T* __restrict__ A, int64_t lda, const T* __restrict__ W, int64_t ldw,
                                                 const float* __restrict__ bias, T* __restrict__ C, int64_t ldc, int64_t M, int N,
                                                 const float* __restrict__ ln_g, const float* __restrict__ ln_b, T* __restrict__ xn_out) {
+    constexpr int MT = BM / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* sA = reinterpret_cast<T*>(smem);
-    T* sB = sA + 128 * 128;
-    const int64_t row0 = (int64_t)blockIdx.x * 128;
-    stage_rows<T, 128, LN>(sA, A, lda, row0, M, ln_g, ln_b, xn_out);
-    for (int n0 = 0; n0 < N; n0 += 128) {
+    T* sW = sA + BM * 128;
+    const int64_t row0 = (int64_t)blockIdx.x * BM;
+    const int wn0 = wave_n0(), wm0 = wave_m0_bm<BM>();
+    stage_tile_async<T, 128>(sW, W, ldw, 128);
+    stage_rows<T, BM, LN>(sA, A, lda, row0, M, ln_g, ln_b, xn_out);
+    const int NB = N / 128;
+    for (int nb = 0; nb < NB; ++nb) {
+        const T* cur = sW + (nb % NBUF) * 128 * 128;
+        wait_async();
         __syncthreads();
-        stage_w<T>(sB, W + (int64_t)n0 * ldw, ldw);
-        __syncthreads();
-        f32x4 acc[4][4];
+        if (NBUF == 2 && nb + 1 < NB) stage_tile_async<T, 128>(sW + ((nb + 1) & 1) * 128 * 128, W + (int64_t)(nb + 1) * 128 * ldw, ldw, 128);
+        f32x4 acc[4][MT];
         zero_acc(acc);
-        mma_k128<4, 4>(sB, wave_n0(), sA, wave_m0(), acc);
-        __syncthreads();
-        acc_to_tile<T>(sB, acc, wave_n0(), wave_m0(), [&](float v, int n) {
-            if (bias != nullptr) v += bias[n0 + n];
-            if (ACT == 1) v = tanhf(v);
-            return v;
-        });
-        __syncthreads();
-        for (int idx = threadIdx.x; idx < 128 * 16; idx += 256) {
-            const int r = idx >> 4, sub = idx & 15;
-            if (row0 + r < M) {
-                float v[8];
-                tile_load8(sB, r, sub * 8, v);
-                store8(C + (row0 + r) * ldc + n0 + sub * 8, v);
+        mma_k128<4, MT>(cur, wn0, sA, wm0, acc);
+        const int n0 = nb * 128;
+        acc_foreach<4, MT>(acc, wn0, wm0, row0, M, [&](float (&v)[4], int64_t row, int n) {
+            add_bias4<T>(v, bias != nullptr ? bias + n0 + n : nullptr);
+            if (ACT == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
             }
+            store4(C + row * ldc + n0 + n, v);
+        });
+        if (NBUF == 1 && nb + 1 < NB) {
+            __syncthreads();
+            stage_tile_async<T, 128>(sW, W + (int64_t)(nb + 1) * 128 * ldw, ldw, 128);
         }
     }
 }
 
-template <typename T>
+template <typename T, int BM>
 __global__ __launch_bounds__(256) void k_linear_res(const T* __restrict__ A, const T* __restrict__ W, const float* __restrict__ bias,
                                                     const float* __restrict__ ls, const T* __restrict__ resid, T* __restrict__ C, int64_t M) {
+    constexpr int MT = BM / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* sA = reinterpret_cast<T*>(smem);
-    T* sB = sA + 128 * 128;
-    const int64_t row0 = (int64_t)blockIdx.x * 128;
-    stage_rows<T, 128, false>(sA, A, 128, row0, M, nullptr, nullptr, nullptr);
-    stage_w<T>(sB, W, 128);
+    T* sW = sA + BM * 128;
+    const int64_t row0 = (int64_t)blockIdx.x * BM;
+    const int wn0 = wave_n0(), wm0 = wave_m0_bm<BM>();
+    const int nvalid = (int)((M - row0) < BM ? (M - row0) : BM);
+    stage_tile_async<T, 128>(sW, W, 128, 128);
+    stage_tile_async<T, BM>(sA, A + row0 * 128, 128, nvalid);
+    wait_async();
     __syncthreads();
-    f32x4 acc[4][4];
+    f32x4 acc[4][MT];
     zero_acc(acc);
-    mma_k128<4, 4>(sB, wave_n0(), sA, wave_m0(), acc);
-    __syncthreads();
-    acc_to_tile<T>(sB, acc, wave_n0(), wave_m0(), [&](float v, int n) { return (v + bias[n]) * ls[n]; });
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < 128 * 16; idx += 256) {
-        const int r = idx >> 4, sub = idx & 15;
-        if (row0 + r < M) {
-            float v[8], x[8];
-            tile_load8(sB, r, sub * 8, v);
-            load8(resid + (row0 + r) * 128 + sub * 8, x);
+    mma_k128<4, MT>(sW, wn0, sA, wm0, acc);
+    acc_foreach<4, MT>(acc, wn0, wm0, row0, M, [&](float (&v)[4], int64_t row, int n) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(bias + n), l = *reinterpret_cast<const f32x4*>(ls + n);
+        float x[4];
+        load4(resid + row * 128 + n, x);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] += x[i];
-            store8(C + (row0 + r) * 128 + sub * 8, v);
-        }
-    }
+        for (int r = 0; r < 4; ++r) v[r] = x[r] + l[r] * (v[r] + b[r]);
+        store4(C + row * 128 + n, v);
+    });
 }
 
 // dxn = dY[M x Kd] . Wt[128 x Kd]^T (+ dxn_add);  out = (resid?) + (accumulate? out) + LNbwd(dxn; x, gamma)
 // dgamma += sum_m dxn*xhat, dbeta += sum_m dxn  (block partials -> fp32 atomics)
-template <typename T>
+template <typename T, int BM, int NBUF>
 __global__ __launch_bounds__(256) void k_dgrad_lnbwd(const T* __restrict__ dY, int Kd, const T* __restrict__ Wt, const T* __restrict__ dxn_add,
                                                      const T* __restrict__ X, const float* __restrict__ gamma, const T* __restrict__ resid,
                                                      T* __restrict__ out, int accumulate, float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta, int64_t M) {
+                                                     float* __restrict__ dbeta, int64_t M, T* __restrict__ xn_out, const float* __restrict__ beta) {
+    constexpr int MT = BM / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    T* sA = reinterpret_cast<T*>(smem);
-    T* sB = sA + 128 * 128;
-    const int64_t row0 = (int64_t)blockIdx.x * 128;
-    f32x4 acc[4][4];
+    T* sA = reinterpret_cast<T*>(smem);                 // [NBUF][BM][128]
+    T* sW = sA + NBUF * BM * 128;                       // [NBUF][128][128]
+    const int64_t row0 = (int64_t)blockIdx.x * BM;
+    const int wn0 = wave_n0(), wm0 = wave_m0_bm<BM>();
+    const int nvalid = (int)((M - row0) < BM ? (M - row0) : BM);
+    const T* a0 = dY + row0 * Kd;
+    stage_tile_async<T, BM>(sA, a0, Kd, nvalid);
+    stage_tile_async<T, 128>(sW, Wt, Kd, 128);
+    f32x4 acc[4][MT];
     zero_acc(acc);
-    for (int k0 = 0; k0 < Kd; k0 += 128) {
+    const int KC = Kd / 128;
+    for (int kc = 0; kc < KC; ++kc) {
+        const int cur = kc % NBUF;
+        wait_async();
         __syncthreads();
-        stage_rows<T, 128, false>(sA, dY + k0, Kd, row0, M, nullptr, nullptr, nullptr);
-        stage_w<T>(sB, Wt + k0, Kd);
-        __syncthreads();
-        mma_k128<4, 4>(sB, wave_n0(), sA, wave_m0(), acc);
+        if (NBUF == 2 && kc + 1 < KC) {
+            stage_tile_async<T, BM>(sA + (cur ^ 1) * BM * 128, a0 + (kc + 1) * 128, Kd, nvalid);
+            stage_tile_async<T, 128>(sW + (cur ^ 1) * 128 * 128, Wt + (kc + 1) * 128, Kd, 128);
+        }
+        mma_k128<4, MT>(sW + cur * 128 * 128, wn0, sA + cur * BM * 128, wm0, acc);
+        if (NBUF == 1 && kc + 1 < KC) {
+            __syncthreads();
+            stage_tile_async<T, BM>(sA, a0 + (kc + 1) * 128, Kd, nvalid);
+            stage_tile_async<T, 128>(sW, Wt + (kc + 1) * 128, Kd, 128);
+        }
     }
     __syncthreads();
-    acc_to_tile<T>(sB, acc, wave_n0(), wave_m0(), [](float v, int) { return v; });
+    acc_to_tile<T>(sW, acc, wn0, wm0, [](float v, int) { return v; });
     __syncthreads();
-    lnbwd_rows<T, 128>(sB, X, gamma, dxn_add, resid, out, accumulate, dgamma, dbeta, row0, M, reinterpret_cast<float*>(smem));
+    lnbwd_rows<T, BM>(sW, X, gamma, dxn_add, resid, out, accumulate, dgamma, dbeta, row0, M, reinterpret_cast<float*>(smem), xn_out, beta);
 }
 
 // ---------------------------------------------------------------------------------------------
 // Weight gradient: out[n][k] += sum_m G[m][n0+n] * Xp[m][k0+k] over this workgroup's slice of M,
-// Xp = LN(X) when LN (then ldx == 128).  The reduction index m is the ROW index of both operands
-// in memory, so bf16 fragments are fetched with ds_read_b64_tr_b16 (hardware LDS transpose) from
-// row-major [m][*] tiles padded to 144 elements per row.  grid = (N/128, K/128, splits).
+// Xp = LN(X) when LN (then ldx == 128).  The reduction index m is the ROW index of both operands in
+// memory, so bf16 fragments come from ds_read_b64_tr_b16 (hardware LDS transpose) on row-major
+// [m][128] swizzled tiles.  Full 128-row tiles arrive by LDS-direct loads, double buffered; the ragged
+// tail (and the LayerNorm-ed operand) is staged through registers with zero fill.
+// grid = (N/128, K/128, splits).
 // ---------------------------------------------------------------------------------------------
-constexpr int WG_LD = 144;
 constexpr int WG_BM = 128;
+
+template <typename T> __device__ __forceinline__ int eoff(int row, int col) { return Tile<T>::chunk_off(row, col / Tile<T>::EPC) + (col % Tile<T>::EPC); }
 
 __device__ __forceinline__ bf16x8 frag_tr(const bf16* s, int mbase, int col0) {
     // group of 16 lanes: lane u = 4q+p supplies row (mbase+q), columns col0+4p..; lane u receives column col0+u of 4 rows
     const int u = threadIdx.x & 15, q = u >> 2, p = u & 3;
     typedef __attribute__((address_space(3))) bf16x4 lds_v4;
-    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)(s + (mbase + q) * WG_LD + col0 + 4 * p));
-    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)(s + (mbase + 4 + q) * WG_LD + col0 + 4 * p));
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)(s + eoff<bf16>(mbase + q, col0 + 4 * p)));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)(s + eoff<bf16>(mbase + 4 + q, col0 + 4 * p)));
     return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
@@ -145,8 +176,8 @@ __device__ __forceinline__ void wgrad_mma(const float* sG, const float* sX, int 
         float a[4], b[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            a[t] = sG[(4 * s + g) * WG_LD + wn0 + 16 * t + i];
-            b[t] = sX[(4 * s + g) * WG_LD + wk0 + 16 * t + i];
+            a[t] = sG[eoff<float>(4 * s + g, wn0 + 16 * t + i)];
+            b[t] = sX[eoff<float>(4 * s + g, wk0 + 16 * t + i)];
         }
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
@@ -155,51 +186,88 @@ __device__ __forceinline__ void wgrad_mma(const float* sG, const float* sX, int 
     }
 }
 
+// register-path staging of one [128 x 128] operand tile with zero fill past m_end (and optional LayerNorm)
 template <typename T, bool LN>
+__device__ __forceinline__ void wgrad_stage_sync(T* sT, const T* src, int64_t ld, int64_t m0, int64_t m_end, const float (&gm)[8], const float (&bt)[8]) {
+    const int sub = threadIdx.x & 15, rl = threadIdx.x >> 4;
+#pragma unroll 2
+    for (int r = rl; r < WG_BM; r += 16) {
+        const int64_t row = m0 + r;
+        const bool ok = row < m_end;
+        float x[8];
+        if (ok) load8(src + row * ld + sub * 8, x);
+        else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[i] = 0.f;
+        }
+        if (LN) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s += x[i];
+            const float mean = reduce16(s) * (1.0f / 128.0f);
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { x[i] -= mean; q += x[i] * x[i]; }
+            const float rstd = rsqrtf(reduce16(q) * (1.0f / 128.0f) + KASF_LN_EPS);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[i] = ok ? x[i] * rstd * gm[i] + bt[i] : 0.f;
+        }
+        tile_store8(sT, r, sub * 8, x);
+    }
+}
+
+template <typename T, int NBUF, bool LN>
 __global__ __launch_bounds__(256) void k_wgrad(const T* __restrict__ G, int64_t ldg, const T* __restrict__ X, int64_t ldx,
                                                const float* __restrict__ ln_g, const float* __restrict__ ln_b, float* __restrict__ out,
                                                int64_t ldo, float* __restrict__ dbias, int64_t M, int64_t slice) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    T* sG = reinterpret_cast<T*>(smem);
-    T* sX = sG + WG_BM * WG_LD;
+    T* sG = reinterpret_cast<T*>(smem);                 // [NBUF][128][128]
+    T* sX = sG + NBUF * 128 * 128;                      // [NBUF][128][128]
     const int n0 = blockIdx.x * 128, k0 = blockIdx.y * 128;
     const int64_t m_begin = (int64_t)blockIdx.z * slice, m_end = (m_begin + slice < M) ? m_begin + slice : M;
     const int sub = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const bool want_bias = dbias != nullptr && blockIdx.y == 0;
     float gm[8], bt[8], bsum[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { bsum[i] = 0.f; gm[i] = LN ? ln_g[sub * 8 + i] : 0.f; bt[i] = LN ? ln_b[sub * 8 + i] : 0.f; }
     f32x4 acc[4][4];
     zero_acc(acc);
-    for (int64_t m0 = m_begin; m0 < m_end; m0 += WG_BM) {
-        __syncthreads();
-        for (int r = rl; r < WG_BM; r += 16) {
-            const int64_t row = m0 + r;
-            const bool ok = row < m_end;
-            float v[8], x[8];
-            if (ok) { load8(G + row * ldg + n0 + sub * 8, v); load8(X + row * ldx + k0 + sub * 8, x); }
-            else {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) { v[i] = 0.f; x[i] = 0.f; }
-            }
-            if (LN) {
-                float s = 0.f;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) s += x[i];
-                const float mean = reduce16(s) * (1.0f / 128.0f);
-                float q = 0.f;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) { x[i] -= mean; q += x[i] * x[i]; }
-                const float rstd = rsqrtf(reduce16(q) * (1.0f / 128.0f) + KASF_LN_EPS);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) x[i] = ok ? x[i] * rstd * gm[i] + bt[i] : 0.f;
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) bsum[i] += v[i];
-            store8(sG + r * WG_LD + sub * 8, v);
-            store8(sX + r * WG_LD + sub * 8, x);
+    auto issue = [&](int buf, int64_t m0) {             // full tiles only
+        stage_tile_async<T, 128>(sG + buf * 128 * 128, G + m0 * ldg + n0, ldg, 128);
+        if (!LN) stage_tile_async<T, 128>(sX + buf * 128 * 128, X + m0 * ldx + k0, ldx, 128);
+    };
+    const int64_t ntiles = (m_end - m_begin + WG_BM - 1) / WG_BM;
+    auto full = [&](int64_t t) { return m_begin + (t + 1) * WG_BM <= m_end; };
+    if (ntiles > 0 && full(0)) issue(0, m_begin);
+    for (int64_t t = 0; t < ntiles; ++t) {
+        const int cur = (int)(t % NBUF);
+        const int64_t m0 = m_begin + t * WG_BM;
+        T* cG = sG + cur * 128 * 128;
+        T* cX = sX + cur * 128 * 128;
+        if (!full(t)) {                                  // ragged tail: synchronous, zero filled
+            __syncthreads();
+            wgrad_stage_sync<T, false>(cG, G + n0, ldg, m0, m_end, gm, bt);
+            wgrad_stage_sync<T, LN>(cX, X + k0, ldx, m0, m_end, gm, bt);
+        } else if (LN) {
+            if (NBUF == 1) __syncthreads();
+            wgrad_stage_sync<T, true>(cX, X + k0, ldx, m0, m_end, gm, bt);
         }
+        wait_async();
         __syncthreads();
-        wgrad_mma(sG, sX, wave_n0(), wave_m0(), acc);      // wave_m0() doubles as the k-half here
+        if (NBUF == 2 && t + 1 < ntiles && full(t + 1)) issue(cur ^ 1, m0 + WG_BM);
+        if (want_bias) {
+            for (int r = rl; r < WG_BM; r += 16) {
+                float v[8];
+                tile_load8(cG, r, sub * 8, v);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) bsum[i] += v[i];
+            }
+        }
+        wgrad_mma(cG, cX, wave_n0(), wave_m0(), acc);      // wave_m0() doubles as the k-half here
+        if (NBUF == 1 && t + 1 < ntiles) {
+            __syncthreads();
+            if (full(t + 1)) issue(0, m0 + WG_BM);
+        }
     }
     {   // out[n][k] += acc : lane owns 4 consecutive n (rows of out) for one k -> strided fp32 atomics (L2-resident tile)
         const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
@@ -213,7 +281,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const T* __restrict__ G, int64_t 
                     atomicAdd(out + (int64_t)n * ldo + k, acc[nt][kt][r]);
                 }
     }
-    if (dbias != nullptr && blockIdx.y == 0) {
+    if (want_bias) {
         __syncthreads();
         float* red = reinterpret_cast<float*>(smem);      // [16][128]
 #pragma unroll
@@ -263,8 +331,6 @@ __global__ __launch_bounds__(256) void k_pack(const float* __restrict__ params, 
     }
 }
 
-template <typename T> constexpr size_t tile_bytes() { return 2 * 128 * 128 * sizeof(T); }
-
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -277,17 +343,23 @@ template <typename K> static void set_smem(K k, size_t bytes) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
+// tile shapes per dtype: bf16 keeps two weight tiles in flight; fp32 (parity mode) has twice the bytes and single-buffers
+template <typename T> struct GemmCfg;
+template <> struct GemmCfg<bf16> { static constexpr int BM = 64, NBUF = 2, WG_NBUF = 2; };
+template <> struct GemmCfg<float> { static constexpr int BM = 64, NBUF = 1, WG_NBUF = 1; };
+
 template <typename T>
 static void linear_T(hipStream_t s, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* C, int64_t ldc, int64_t M,
                      int N, const float* ln_g, const float* ln_b, void* xn_out, int act) {
-    const dim3 grid((unsigned)((M + 127) / 128));
-    const size_t sh = tile_bytes<T>();
+    constexpr int BM = GemmCfg<T>::BM, NBUF = GemmCfg<T>::NBUF;
+    const dim3 grid((unsigned)((M + BM - 1) / BM));
+    const size_t sh = (size_t)(BM * 128 + NBUF * 128 * 128) * sizeof(T);
     auto go = [&](auto kern) {
         set_smem(kern, sh);
         hipLaunchKernelGGL(kern, grid, dim3(256), sh, s, (const T*)A, lda, (const T*)W, ldw, bias, (T*)C, ldc, M, N, ln_g, ln_b, (T*)xn_out);
     };
-    if (ln_g != nullptr) { if (act == 1) go(k_linear<T, true, 1>); else go(k_linear<T, true, 0>); }
-    else { if (act == 1) go(k_linear<T, false, 1>); else go(k_linear<T, false, 0>); }
+    if (ln_g != nullptr) { if (act == 1) go(k_linear<T, BM, NBUF, true, 1>); else go(k_linear<T, BM, NBUF, true, 0>); }
+    else { if (act == 1) go(k_linear<T, BM, NBUF, false, 1>); else go(k_linear<T, BM, NBUF, false, 0>); }
 }
 void kasf_launch_linear(int dt, hipStream_t s, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* C, int64_t ldc,
                         int64_t M, int N, const float* ln_g, const float* ln_b, void* xn_out, int act) {
@@ -297,9 +369,11 @@ void kasf_launch_linear(int dt, hipStream_t s, const void* A, int64_t lda, const
 
 template <typename T>
 static void linear_res_T(hipStream_t s, const void* A, const void* W, const float* bias, const float* ls, const void* resid, void* C, int64_t M) {
-    set_smem(k_linear_res<T>, tile_bytes<T>());
-    hipLaunchKernelGGL(k_linear_res<T>, dim3((unsigned)((M + 127) / 128)), dim3(256), tile_bytes<T>(), s, (const T*)A, (const T*)W, bias, ls,
-                       (const T*)resid, (T*)C, M);
+    constexpr int BM = GemmCfg<T>::BM;
+    const size_t sh = (size_t)(BM * 128 + 128 * 128) * sizeof(T);
+    set_smem(k_linear_res<T, BM>, sh);
+    hipLaunchKernelGGL((k_linear_res<T, BM>), dim3((unsigned)((M + BM - 1) / BM)), dim3(256), sh, s, (const T*)A, (const T*)W, bias, ls, (const T*)resid,
+                       (T*)C, M);
 }
 void kasf_launch_linear_res(int dt, hipStream_t s, const void* A, const void* W, const float* bias, const float* ls, const void* resid, void* C,
                             int64_t M) {
@@ -308,36 +382,39 @@ void kasf_launch_linear_res(int dt, hipStream_t s, const void* A, const void* W,
 
 template <typename T>
 static void dgrad_lnbwd_T(hipStream_t s, const void* dY, int Kd, const void* Wt, const void* dxn_add, const void* X, const float* gamma,
-                          const void* resid, void* out, int accumulate, float* dgamma, float* dbeta, int64_t M) {
-    set_smem(k_dgrad_lnbwd<T>, tile_bytes<T>());
-    hipLaunchKernelGGL(k_dgrad_lnbwd<T>, dim3((unsigned)((M + 127) / 128)), dim3(256), tile_bytes<T>(), s, (const T*)dY, Kd, (const T*)Wt,
-                       (const T*)dxn_add, (const T*)X, gamma, (const T*)resid, (T*)out, accumulate, dgamma, dbeta, M);
+                          const void* resid, void* out, int accumulate, float* dgamma, float* dbeta, int64_t M, void* xn_out, const float* beta) {
+    constexpr int BM = GemmCfg<T>::BM, NBUF = GemmCfg<T>::NBUF;
+    const size_t sh = (size_t)NBUF * (BM * 128 + 128 * 128) * sizeof(T);
+    set_smem(k_dgrad_lnbwd<T, BM, NBUF>, sh);
+    hipLaunchKernelGGL((k_dgrad_lnbwd<T, BM, NBUF>), dim3((unsigned)((M + BM - 1) / BM)), dim3(256), sh, s, (const T*)dY, Kd, (const T*)Wt,
+                       (const T*)dxn_add, (const T*)X, gamma, (const T*)resid, (T*)out, accumulate, dgamma, dbeta, M, (T*)xn_out, beta);
 }
 void kasf_launch_dgrad_lnbwd(int dt, hipStream_t s, const void* dY, int Kd, const void* Wt, const void* dxn_add, const void* X, const float* gamma,
-                             const void* resid, void* out, int accumulate, float* dgamma, float* dbeta, int64_t M) {
-    DT_DISPATCH(dt, (dgrad_lnbwd_T<float>(s, dY, Kd, Wt, dxn_add, X, gamma, resid, out, accumulate, dgamma, dbeta, M)),
-                (dgrad_lnbwd_T<bf16>(s, dY, Kd, Wt, dxn_add, X, gamma, resid, out, accumulate, dgamma, dbeta, M)));
+                             const void* resid, void* out, int accumulate, float* dgamma, float* dbeta, int64_t M, void* xn_out, const float* beta) {
+    DT_DISPATCH(dt, (dgrad_lnbwd_T<float>(s, dY, Kd, Wt, dxn_add, X, gamma, resid, out, accumulate, dgamma, dbeta, M, xn_out, beta)),
+                (dgrad_lnbwd_T<bf16>(s, dY, Kd, Wt, dxn_add, X, gamma, resid, out, accumulate, dgamma, dbeta, M, xn_out, beta)));
 }
 
 template <typename T>
 static void wgrad_T(hipStream_t s, const void* G, int64_t ldg, int N, const void* X, int64_t ldx, int K, const float* ln_g, const float* ln_b,
                     float* out, int64_t ldo, float* dbias, int64_t M) {
+    constexpr int NBUF = GemmCfg<T>::WG_NBUF;
     const int tiles = (N / 128) * (K / 128);
-    int splits = (768 + tiles - 1) / tiles;                         // ~3 workgroups per CU in total
+    int splits = (512 + tiles - 1) / tiles;                         // ~2 workgroups per CU in total
     const int64_t max_splits = (M + WG_BM - 1) / WG_BM;
     if (splits > max_splits) splits = (int)max_splits;
     if (splits < 1) splits = 1;
     int64_t slice = (M + splits - 1) / splits;
     slice = (slice + WG_BM - 1) / WG_BM * WG_BM;
     splits = (int)((M + slice - 1) / slice);
-    const size_t sh = 2 * WG_BM * WG_LD * sizeof(T);
+    const size_t sh = (size_t)2 * NBUF * 128 * 128 * sizeof(T);
     const dim3 grid(N / 128, K / 128, splits);
     if (ln_g != nullptr) {
-        set_smem(k_wgrad<T, true>, sh);
-        hipLaunchKernelGGL((k_wgrad<T, true>), grid, dim3(256), sh, s, (const T*)G, ldg, (const T*)X, ldx, ln_g, ln_b, out, ldo, dbias, M, slice);
+        set_smem(k_wgrad<T, NBUF, true>, sh);
+        hipLaunchKernelGGL((k_wgrad<T, NBUF, true>), grid, dim3(256), sh, s, (const T*)G, ldg, (const T*)X, ldx, ln_g, ln_b, out, ldo, dbias, M, slice);
     } else {
-        set_smem(k_wgrad<T, false>, sh);
-        hipLaunchKernelGGL((k_wgrad<T, false>), grid, dim3(256), sh, s, (const T*)G, ldg, (const T*)X, ldx, ln_g, ln_b, out, ldo, dbias, M, slice);
+        set_smem(k_wgrad<T, NBUF, false>, sh);
+        hipLaunchKernelGGL((k_wgrad<T, NBUF, false>), grid, dim3(256), sh, s, (const T*)G, ldg, (const T*)X, ldx, ln_g, ln_b, out, ldo, dbias, M, slice);
     }
 }
 void kasf_launch_wgrad(int dt, hipStream_t s, const void* G, int64_t ldg, int N, const void* X, int64_t ldx, int K, const float* ln_g,

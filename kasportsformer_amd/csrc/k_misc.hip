@@ -167,8 +167,10 @@ __global__ __launch_bounds__(64) void k_refusion_bwd(const float* __restrict__ x
 #pragma unroll
         for (int h = 0; h < 16; ++h) {
             const float z = b1[h] + w1[h][0] * in[0] + w1[h][1] * in[1] + w1[h][2] * in[2] + w1[h][3] * in[3];
-            dw2[h] += d * gelu_f(z);
-            const float dz = d * w2[h] * gelu_grad_f(z);
+            float gz, dgz;
+            gelu_and_grad(z, gz, dgz);
+            dw2[h] += d * gz;
+            const float dz = d * w2[h] * dgz;
             db1[h] += dz;
 #pragma unroll
             for (int k = 0; k < 4; ++k) dw1[h][k] += dz * in[k];

@@ -32,7 +32,8 @@ void kasf_launch_linear(int dt, hipStream_t s, const void* A, int64_t lda, const
 void kasf_launch_linear_res(int dt, hipStream_t s, const void* A, const void* W, const float* bias, const float* ls, const void* resid, void* C,
                             int64_t M);
 void kasf_launch_dgrad_lnbwd(int dt, hipStream_t s, const void* dY, int Kd, const void* Wt, const void* dxn_add, const void* X, const float* gamma,
-                             const void* resid, void* out, int accumulate, float* dgamma, float* dbeta, int64_t M);
+                             const void* resid, void* out, int accumulate, float* dgamma, float* dbeta, int64_t M, void* xn_out = nullptr,
+                             const float* beta = nullptr);   // xn_out: also write LN(x) (operand of the matching weight gradient)
 void kasf_launch_wgrad(int dt, hipStream_t s, const void* G, int64_t ldg, int N, const void* X, int64_t ldx, int K, const float* ln_g,
                        const float* ln_b, float* out, int64_t ldo, float* dbias, int64_t M);
 void kasf_launch_pack(int dt, hipStream_t s, const float* params, void* arena, const KasfPackDesc* desc, const int* tile_start, int ndesc,
@@ -44,7 +45,8 @@ void kasf_launch_mlp_fwd(int dt, hipStream_t s, const void* x, const float* ln_g
                          const float* b2, const float* ls2, void* out, int64_t M);
 // g_in = g + LNbwd(dA), also writes H = GELU(Z) and dZ ([M x 512] each) for the weight-gradient GEMMs
 void kasf_launch_mlp_bwd(int dt, hipStream_t s, const void* x, const void* g, const float* ln_g, const float* ln_b, const void* W1, const float* b1,
-                         const void* W2t_scaled, const void* W1t, void* Hbuf, void* dZbuf, void* g_in, float* dgamma, float* dbeta, int64_t M);
+                         const void* W2t_scaled, const void* W1t, void* Hbuf, void* dZbuf, void* xn_buf, void* g_in, float* dgamma, float* dbeta,
+                         int64_t M);
 
 // ---- k_attn.hip ----
 // mode 0: spatial (groups = B*T frames of 17 tokens), mode 1: temporal (groups = B*17 joint tracks of T tokens)

@@ -7,6 +7,24 @@ __device__ __forceinline__ int wave_n0() { return ((threadIdx.x >> 6) & 1) * 64;
 __device__ __forceinline__ int wave_m0() { return (threadIdx.x >> 7) * 64; }
 template <int BM> __device__ __forceinline__ int wave_m0_bm() { return (threadIdx.x >> 7) * (BM / 2); }
 
+// Epilogue straight from the accumulators: each lane owns 4 consecutive output features of one token, so it
+// issues one 8-byte (bf16) / 16-byte (f32) global access per tile; f(v, row, n) transforms and stores.
+template <int NT, int MT, typename F>
+__device__ __forceinline__ void acc_foreach(f32x4 (&acc)[NT][MT], int wn0, int wm0, int64_t row0, int64_t M, F f) {
+    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int64_t row = row0 + wm0 + mt * 16 + i;
+        if (row < M) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                float v[4] = {acc[nt][mt][0], acc[nt][mt][1], acc[nt][mt][2], acc[nt][mt][3]};
+                f(v, row, wn0 + nt * 16 + g * 4);
+            }
+        }
+    }
+}
+
 template <typename T, int NT, int MT, typename F>
 __device__ __forceinline__ void acc_to_tile(T* sC, f32x4 (&acc)[NT][MT], int wn0, int wm0, F f) {
     const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
@@ -26,16 +44,18 @@ __device__ __forceinline__ void acc_to_tile(T* sC, f32x4 (&acc)[NT][MT], int wn0
 // LayerNorm backward over the BM x 128 tile of d(LN output) held in sC (swizzled, type T):
 //   out = [resid +] [out +] rstd * (dxh - mean(dxh) - xhat * mean(dxh * xhat)),  dxh = (sC [+ dxn_add]) * gamma
 // and dgamma += sum_m d*xhat, dbeta += sum_m d (block partials -> fp32 atomics).  xhat/rstd are
-// recomputed from X.  `red` is >= 16 KB of LDS that is free at this point (must not alias sC).
-template <typename T, int BM>
+// recomputed from X.  `red` is >= NTHR * 64 B of LDS that is free at this point (must not alias sC).
+template <typename T, int BM, int NTHR = 256>
 __device__ __forceinline__ void lnbwd_rows(const T* sC, const T* __restrict__ X, const float* __restrict__ gamma, const T* __restrict__ dxn_add,
                                            const T* __restrict__ resid, T* __restrict__ out, int accumulate, float* __restrict__ dgamma,
-                                           float* __restrict__ dbeta, int64_t row0, int64_t M, float* red) {
+                                           float* __restrict__ dbeta, int64_t row0, int64_t M, float* red, T* __restrict__ xn_out = nullptr,
+                                           const float* __restrict__ beta = nullptr) {
     const int sub = threadIdx.x & 15, rl = threadIdx.x >> 4;
     float gm[8], dg[8], db[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { gm[i] = gamma[sub * 8 + i]; dg[i] = 0.f; db[i] = 0.f; }
-    for (int r = rl; r < BM; r += 16) {
+    constexpr int RS = NTHR / 16;
+    for (int r = rl; r < BM; r += RS) {
         const int64_t row = row0 + r;
         if (row >= M) break;        // uniform across the 16 lanes that share a row
         float d[8], x[8];
@@ -56,6 +76,12 @@ __device__ __forceinline__ void lnbwd_rows(const T* sC, const T* __restrict__ X,
         for (int i = 0; i < 8; ++i) { x[i] -= mean; q += x[i] * x[i]; }
         const float rstd = rsqrtf(reduce16(q) * (1.0f / 128.0f) + KASF_LN_EPS);
         float s1 = 0.f, s2 = 0.f;
+        if (xn_out != nullptr) {                // LN(x) = xhat*gamma+beta: operand of the matching weight-gradient GEMM
+            float xn[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) xn[i] = x[i] * rstd * gm[i] + beta[sub * 8 + i];
+            store8(xn_out + row * 128 + sub * 8, xn);
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             x[i] *= rstd;                       // xhat
@@ -87,14 +113,14 @@ __device__ __forceinline__ void lnbwd_rows(const T* sC, const T* __restrict__ X,
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         red[rl * 128 + sub * 8 + i] = dg[i];
-        red[2048 + rl * 128 + sub * 8 + i] = db[i];
+        red[RS * 128 + rl * 128 + sub * 8 + i] = db[i];
     }
     __syncthreads();
-    {
+    if (threadIdx.x < 256) {
         const int c = threadIdx.x & 127, which = threadIdx.x >> 7;
         float s = 0.f;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) s += red[which * 2048 + k * 128 + c];
+        for (int k = 0; k < RS; ++k) s += red[which * RS * 128 + k * 128 + c];
         atomicAdd((which ? dbeta : dgamma) + c, s);
     }
 }
