@@ -82,7 +82,7 @@ __device__ __forceinline__ float reduce64(float v) {
 // density needed by the derivative.  ~15 VALU instructions instead of ~35 for erff + expf.
 __device__ __forceinline__ void gelu_parts(float x, float& Phi, float& pdf) {
     const float ax = fabsf(x) * 0.70710678118654752f;
-    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));      // v_rcp_f32 (1 ulp); a '/' would expand to the 9-instruction IEEE sequence
     const float e = __expf(-ax * ax);
     const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
     const float erf_abs = fmaf(-poly, e, 1.0f);

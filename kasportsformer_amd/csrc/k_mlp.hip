@@ -17,7 +17,7 @@ namespace {
 // requested (LDS-direct, asynchronous) right after the barrier that opens block b, into the other
 // tile of the ring, and lands while block b is being multiplied: one barrier per block.  With NBUF == 1
 // (fp32 parity mode: tiles are twice as large) the request is issued after the block's MFMAs instead.
-template <typename T, int NBUF, typename NextFn>
+template <typename T, int NBUF, int NTHR, typename NextFn>
 struct WeightRing {
     T* base;
     NextFn next;            // next(b) -> (pointer, ld) of weight block b
@@ -27,7 +27,7 @@ struct WeightRing {
         if (b < nblocks) {
             int64_t ld;
             const T* p = next(b, ld);
-            stage_tile_async<T, 128>(tile(b), p, ld, 128);
+            stage_tile_async<T, 128, NTHR>(tile(b), p, ld, 128);
         }
     }
     // call at the top of block b (after everything written for it is in flight); returns the tile to multiply
@@ -46,17 +46,17 @@ struct WeightRing {
     }
 };
 
-template <typename T, int BM, int NBUF>
-__global__ __launch_bounds__(256) void k_mlp_fwd(const T* __restrict__ X, const float* __restrict__ ln_g, const float* __restrict__ ln_b,
+template <typename T, int BM, int NBUF, int NTHR>
+__global__ __launch_bounds__(NTHR) void k_mlp_fwd(const T* __restrict__ X, const float* __restrict__ ln_g, const float* __restrict__ ln_b,
                                                  const T* __restrict__ W1, const float* __restrict__ b1, const T* __restrict__ W2,
                                                  const float* __restrict__ b2, const float* __restrict__ ls2, T* __restrict__ out, int64_t M) {
-    constexpr int MT = BM / 32;
+    constexpr int MT = BM / (NTHR / 128) / 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* sA = reinterpret_cast<T*>(smem);        // LN(x)          [BM][128]
     T* sH = sA + BM * 128;                     // GELU chunk     [BM][128]
     T* sW = sH + BM * 128;                     // weight ring    [NBUF][128][128]
     const int64_t row0 = (int64_t)blockIdx.x * BM;
-    const int wn0 = wave_n0(), wm0 = wave_m0_bm<BM>();
+    const int wn0 = wave_n0(), wm0 = wave_m0_n<BM, NTHR>();
     // block 2*hc: W1 rows [128*hc, +128) (k = channels); block 2*hc+1: W2[:, 128*hc .. +128) (k = hidden chunk)
     auto nextw = [&](int b, int64_t& ld) -> const T* {
         const int hc = b >> 1;
@@ -64,9 +64,9 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const T* __restrict__ X, const 
         ld = 128;
         return W1 + (int64_t)hc * 128 * 128;
     };
-    WeightRing<T, NBUF, decltype(nextw)> ring{sW, nextw, 8};
+    WeightRing<T, NBUF, NTHR, decltype(nextw)> ring{sW, nextw, 8};
     ring.request(0);
-    stage_rows<T, BM, true>(sA, X, 128, row0, M, ln_g, ln_b, nullptr);
+    stage_rows<T, BM, true, NTHR>(sA, X, 128, row0, M, ln_g, ln_b, nullptr);
     f32x4 acc2[4][MT];
     zero_acc(acc2);
     for (int hc = 0; hc < 4; ++hc) {
@@ -90,13 +90,13 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const T* __restrict__ X, const 
     });
 }
 
-template <typename T, int BM, int NBUF>
-__global__ __launch_bounds__(256) void k_mlp_bwd(const T* __restrict__ X, const T* __restrict__ G, const float* __restrict__ ln_g,
+template <typename T, int BM, int NBUF, int NTHR>
+__global__ __launch_bounds__(NTHR) void k_mlp_bwd(const T* __restrict__ X, const T* __restrict__ G, const float* __restrict__ ln_g,
                                                  const float* __restrict__ ln_b, const T* __restrict__ W1, const float* __restrict__ b1,
                                                  const T* __restrict__ W2ts, const T* __restrict__ W1t, T* __restrict__ Hbuf,
                                                  T* __restrict__ dZbuf, T* __restrict__ xn_buf, T* __restrict__ g_in,
                                                  float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t M) {
-    constexpr int MT = BM / 32;
+    constexpr int MT = BM / (NTHR / 128) / 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* sA = reinterpret_cast<T*>(smem);        // LN(x)        [BM][128]
     T* sG = sA + BM * 128;                     // upstream g   [BM][128]
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(const T* __restrict__ X, const 
     T* sHs = sD + BM * 128;                    // H chunk (copy-out staging) [BM][128]
     T* sW = sHs + BM * 128;                    // weight ring  [NBUF][128][128]
     const int64_t row0 = (int64_t)blockIdx.x * BM;
-    const int wn0 = wave_n0(), wm0 = wave_m0_bm<BM>();
+    const int wn0 = wave_n0(), wm0 = wave_m0_n<BM, NTHR>();
     const int nvalid = (int)((M - row0) < BM ? (M - row0) : BM);
     // per hidden chunk hc: W1 rows (Z), (ls2.W2)^T rows (dH), W1^T columns (dA)
     auto nextw = [&](int b, int64_t& ld) -> const T* {
@@ -113,10 +113,10 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(const T* __restrict__ X, const 
         ld = 128;
         return (which == 0 ? W1 : W2ts) + (int64_t)hc * 128 * 128;
     };
-    WeightRing<T, NBUF, decltype(nextw)> ring{sW, nextw, 12};
+    WeightRing<T, NBUF, NTHR, decltype(nextw)> ring{sW, nextw, 12};
     ring.request(0);
-    stage_tile_async<T, BM>(sG, G + row0 * 128, 128, nvalid);
-    stage_rows<T, BM, true>(sA, X, 128, row0, M, ln_g, ln_b, xn_buf);      // LN(x) is also the fc1 weight-gradient operand
+    stage_tile_async<T, BM, NTHR>(sG, G + row0 * 128, 128, nvalid);
+    stage_rows<T, BM, true, NTHR>(sA, X, 128, row0, M, ln_g, ln_b, xn_buf);      // LN(x) is also the fc1 weight-gradient operand
     f32x4 accA[4][MT];
     zero_acc(accA);
     for (int hc = 0; hc < 4; ++hc) {
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(const T* __restrict__ X, const 
         zero_acc(accH);
         const T* w = ring.open(3 * hc);
         if (hc > 0) {                                   // copy out the previous chunk's H / dZ while this chunk starts
-            for (int idx = threadIdx.x; idx < BM * 16; idx += 256) {
+            for (int idx = threadIdx.x; idx < BM * 16; idx += NTHR) {
                 const int r = idx >> 4, sub = idx & 15;
                 if (row0 + r < M) {
                     float v[8];
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(const T* __restrict__ X, const 
         ring.close(3 * hc + 2);
     }
     __syncthreads();
-    for (int idx = threadIdx.x; idx < BM * 16; idx += 256) {            // last chunk's H / dZ
+    for (int idx = threadIdx.x; idx < BM * 16; idx += NTHR) {           // last chunk's H / dZ
         const int r = idx >> 4, sub = idx & 15;
         if (row0 + r < M) {
             float v[8];
@@ -178,12 +178,13 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(const T* __restrict__ X, const 
     __syncthreads();
     acc_to_tile<T>(sD, accA, wn0, wm0, [](float v, int) { return v; });
     __syncthreads();
-    lnbwd_rows<T, BM>(sD, X, ln_g, (const T*)nullptr, G, g_in, 0, dgamma, dbeta, row0, M, reinterpret_cast<float*>(sW));
+    lnbwd_rows<T, BM, NTHR>(sD, X, ln_g, (const T*)nullptr, G, g_in, 0, dgamma, dbeta, row0, M, reinterpret_cast<float*>(sW));
 }
 
 template <typename T> struct MlpCfg;
-template <> struct MlpCfg<bf16> { static constexpr int BM_F = 128, BM_B = 64, NBUF = 2; };
-template <> struct MlpCfg<float> { static constexpr int BM_F = 64, BM_B = 32, NBUF = 1; };
+// bf16: 8 waves per workgroup (2 per SIMD) so one wave's VALU epilogue (GELU, LayerNorm) overlaps the other's MFMAs
+template <> struct MlpCfg<bf16> { static constexpr int BM_F = 128, BM_B = 64, NBUF = 2, NTHR = 512; };
+template <> struct MlpCfg<float> { static constexpr int BM_F = 64, BM_B = 32, NBUF = 1, NTHR = 256; };
 
 template <typename K> void set_smem(K k, size_t bytes) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -192,19 +193,19 @@ template <typename K> void set_smem(K k, size_t bytes) {
 template <typename T>
 void mlp_fwd_T(hipStream_t s, const void* x, const float* ln_g, const float* ln_b, const void* W1, const float* b1, const void* W2, const float* b2,
                const float* ls2, void* out, int64_t M) {
-    constexpr int BM = MlpCfg<T>::BM_F, NBUF = MlpCfg<T>::NBUF;
+    constexpr int BM = MlpCfg<T>::BM_F, NBUF = MlpCfg<T>::NBUF, NTHR = MlpCfg<T>::NTHR;
     const size_t sh = (size_t)(2 * BM * 128 + NBUF * 128 * 128) * sizeof(T);
-    set_smem(k_mlp_fwd<T, BM, NBUF>, sh);
-    hipLaunchKernelGGL((k_mlp_fwd<T, BM, NBUF>), dim3((unsigned)((M + BM - 1) / BM)), dim3(256), sh, s, (const T*)x, ln_g, ln_b, (const T*)W1, b1,
+    set_smem(k_mlp_fwd<T, BM, NBUF, NTHR>, sh);
+    hipLaunchKernelGGL((k_mlp_fwd<T, BM, NBUF, NTHR>), dim3((unsigned)((M + BM - 1) / BM)), dim3(NTHR), sh, s, (const T*)x, ln_g, ln_b, (const T*)W1, b1,
                        (const T*)W2, b2, ls2, (T*)out, M);
 }
 template <typename T>
 void mlp_bwd_T(hipStream_t s, const void* x, const void* g, const float* ln_g, const float* ln_b, const void* W1, const float* b1, const void* W2ts,
                const void* W1t, void* Hbuf, void* dZbuf, void* xn_buf, void* g_in, float* dgamma, float* dbeta, int64_t M) {
-    constexpr int BM = MlpCfg<T>::BM_B, NBUF = MlpCfg<T>::NBUF;
+    constexpr int BM = MlpCfg<T>::BM_B, NBUF = MlpCfg<T>::NBUF, NTHR = MlpCfg<T>::NTHR;
     const size_t sh = (size_t)(4 * BM * 128 + NBUF * 128 * 128) * sizeof(T);
-    set_smem(k_mlp_bwd<T, BM, NBUF>, sh);
-    hipLaunchKernelGGL((k_mlp_bwd<T, BM, NBUF>), dim3((unsigned)((M + BM - 1) / BM)), dim3(256), sh, s, (const T*)x, (const T*)g, ln_g, ln_b,
+    set_smem(k_mlp_bwd<T, BM, NBUF, NTHR>, sh);
+    hipLaunchKernelGGL((k_mlp_bwd<T, BM, NBUF, NTHR>), dim3((unsigned)((M + BM - 1) / BM)), dim3(NTHR), sh, s, (const T*)x, (const T*)g, ln_g, ln_b,
                        (const T*)W1, b1, (const T*)W2ts, (const T*)W1t, (T*)Hbuf, (T*)dZbuf, (T*)xn_buf, (T*)g_in, dgamma, dbeta, M);
 }
 

@@ -6,6 +6,8 @@
 __device__ __forceinline__ int wave_n0() { return ((threadIdx.x >> 6) & 1) * 64; }
 __device__ __forceinline__ int wave_m0() { return (threadIdx.x >> 7) * 64; }
 template <int BM> __device__ __forceinline__ int wave_m0_bm() { return (threadIdx.x >> 7) * (BM / 2); }
+// NTHR/64 waves as 2 (feature halves) x NTHR/128 (token groups)
+template <int BM, int NTHR> __device__ __forceinline__ int wave_m0_n() { return (threadIdx.x >> 7) * (BM / (NTHR / 128)); }
 
 // Epilogue straight from the accumulators: each lane owns 4 consecutive output features of one token, so it
 // issues one 8-byte (bf16) / 16-byte (f32) global access per tile; f(v, row, n) transforms and stores.
