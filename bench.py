@@ -60,12 +60,13 @@ def kernel_rooflines(M):
     dg, db = torch.zeros(128, device=dev), torch.zeros(128, device=dev)
     dW1, db1 = torch.zeros(512, 128, device=dev), torch.zeros(512, device=dev)
     dW2, gs = torch.zeros(128, 512, device=dev), torch.zeros(128, device=dev)
+    part = torch.empty(256 * 128 * 128, device=dev)
     st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
     p = lambda t: C.c_void_p(t.data_ptr())
     fwd = lambda: lib.kasf_op_mlp_fwd(1, p(x), p(gam), p(bet), p(w1), p(b1), p(w2), p(b2), p(ls), p(out), M, st())
     bwd = lambda: lib.kasf_op_mlp_bwd(1, p(x), p(gout), p(gam), p(bet), p(w1), p(b1), p(w2ts), p(w1t), p(H), p(dZ), p(gin), p(dg), p(db), M, st())
-    wg1 = lambda: lib.kasf_op_wgrad(1, p(dZ), 512, p(x), 128, None, None, p(dW1), p(db1), M, st())   # engine path: X = LN(x) emitted by k_mlp_bwd
-    wg2 = lambda: lib.kasf_op_wgrad(1, p(gout), 128, p(H), 512, None, None, p(dW2), p(gs), M, st())
+    wg1 = lambda: lib.kasf_op_wgrad(1, p(dZ), 512, p(x), 128, None, None, p(dW1), p(db1), M, p(part), part.numel(), st())   # engine path: X = LN(x) emitted by k_mlp_bwd
+    wg2 = lambda: lib.kasf_op_wgrad(1, p(gout), 128, p(H), 512, None, None, p(dW2), p(gs), M, p(part), part.numel(), st())
     res = {}
     for name, fn, flop in (("k_mlp_fwd", fwd, MLP_FLOP_PER_TOKEN_FWD * M), ("k_mlp_bwd", bwd, MLP_FLOP_PER_TOKEN_FWD * M),
                            ("k_wgrad_fc1", wg1, MLP_FLOP_PER_TOKEN_FWD // 2 * M), ("k_wgrad_fc2", wg2, MLP_FLOP_PER_TOKEN_FWD // 2 * M)):

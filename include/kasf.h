@@ -103,9 +103,11 @@ int kasf_op_mlp_fwd(int32_t dtype, const void* x, const float* ln_g, const float
                     const float* ls2, void* out, int64_t M, void* stream);
 int kasf_op_mlp_bwd(int32_t dtype, const void* x, const void* g, const float* ln_g, const float* ln_b, const void* w1, const float* b1,
                     const void* w2t_scaled, const void* w1t, void* hbuf, void* dzbuf, void* g_in, float* dgamma, float* dbeta, int64_t M, void* stream);
-/* dW[N,K] += G^T LN?(X), dbias[N] += colsum(G): G [M,N], X [M,K] */
+/* dW[N,K] += G^T LN?(X), dbias[N] += colsum(G): G [M,N], X [M,K].  partial: optional fp32 scratch of partial_floats
+ * elements (>= 256*128*128 covers every shape of this model): per-split tiles are stored and summed by a second
+ * kernel (bitwise reproducible); NULL -> fp32 atomics on dw. */
 int kasf_op_wgrad(int32_t dtype, const void* g, int32_t N, const void* x, int32_t K, const float* ln_g, const float* ln_b, float* dw, float* dbias,
-                  int64_t M, void* stream);
+                  int64_t M, float* partial, int64_t partial_floats, void* stream);
 /* g_in = [resid] + LNbwd(dY Wt^T [+ add]): dY [M,Kd], Wt [128,Kd] */
 int kasf_op_dgrad_lnbwd(int32_t dtype, const void* dy, int32_t Kd, const void* wt, const void* dxn_add, const void* x, const float* gamma,
                         const void* resid, void* out, int32_t accumulate, float* dgamma, float* dbeta, int64_t M, void* stream);

@@ -237,6 +237,21 @@ __device__ __forceinline__ void stage_rows(T* sA, const T* X, int64_t ld, int64_
 // nvalid-1 (never out of bounds; their results are discarded by the caller).  256 threads.
 // Consumers must execute  wait_async(); __syncthreads();  before reading the tile.
 // ------------------------------------------------------------------------------------------
+// One LDS-direct 16-byte-per-lane load: LDS[lds_base + 16*lane] <- *gsrc.  Issued from inline asm so that hipcc's
+// waitcnt pass does not see a pending LDS write (it would otherwise drain vmcnt(0) before the next ds_read of the
+// staging array and collapse any multi-tile ring to depth one).  M0 carries the wave-uniform LDS byte address and
+// is saved / restored inside the statement (cdna_hip_programming.md 5.7).  Completion: wait_async*() + a barrier.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_base)
+                 : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
+}
+
 template <typename T, int ROWS, int NTHR = 256>
 __device__ __forceinline__ void stage_tile_async(T* sT, const T* src, int64_t ld, int nvalid) {
     constexpr int EPC = Tile<T>::EPC, CPR = Tile<T>::CPR;
@@ -244,16 +259,23 @@ __device__ __forceinline__ void stage_tile_async(T* sT, const T* src, int64_t ld
     constexpr int IPW = ROWS / RPI / (NTHR / 64);        // instructions per wave
     static_assert(IPW >= 1, "tile too small for this workgroup size");
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const unsigned base = __builtin_amdgcn_readfirstlane(lds_addr(sT));
 #pragma unroll
     for (int t = 0; t < IPW; ++t) {
         const int inst = w * IPW + t;
         const int row = inst * RPI + lane / CPR, pc = lane % CPR, c = pc ^ (row & 15);
         const int srow = row < nvalid ? row : nvalid - 1;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (int64_t)srow * ld + c * EPC),
-                                         (__attribute__((address_space(3))) void*)(sT + inst * 64 * EPC), 16, 0, 0);
+        glds16(src + (int64_t)srow * ld + c * EPC, base + (unsigned)inst * 1024u);
     }
 }
 __device__ __forceinline__ void wait_async() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// wait until at most N of this wave's vector-memory operations (LDS-direct loads included, in issue order) are outstanding
+template <int N> __device__ __forceinline__ void wait_async_le() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// workgroup barrier WITHOUT the vmcnt(0)/lgkmcnt(0) drain __syncthreads() adds while LDS-direct loads are in flight
+__device__ __forceinline__ void barrier_keep_async() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
 
 __device__ __forceinline__ void load4(const bf16* p, float (&v)[4]) {
     const bf16x4 t = *reinterpret_cast<const bf16x4*>(p);

@@ -32,6 +32,8 @@ struct BlockOff {
 struct LayerOff { BlockOff blk[6]; int64_t fus_w, fus_b, begin, end; };
 struct TopOff { int64_t norm_w, norm_b, fc_w, fc_b, head_w, head_b, p_fc, p_fcT, begin, end; };
 
+constexpr int64_t WG_PARTIAL_FLOATS = 256 * 128 * 128;     // one 128x128 fp32 tile per workgroup of a <= 256-workgroup wgrad launch
+
 struct BlkWs { int64_t qkv, kv, o, xn, y, mask, x_mid, x_out, stats, bstats, coef; };
 struct LayerWs { BlkWs b[6]; int64_t gate_out, alpha; };
 struct WsEntry { std::string name; int64_t off, numel; int kind; };
@@ -39,7 +41,7 @@ struct Plan {
     int64_t total = 0, stats_begin = 0, stats_bytes = 0, bstats_begin = 0, bstats_bytes = 0;
     int64_t x3, bone3, limb3, xj, xb, xl, rep, uv;
     std::vector<LayerWs> layers;
-    int64_t g_layer, g_prev, ga, gg, gb, t1, t2, g_limb, g_bone, hbuf, dzbuf, d_o, dqkv, rbuf, duv, dlimb3, xn_a, xn_b;
+    int64_t g_layer, g_prev, ga, gg, gb, t1, t2, g_limb, g_bone, hbuf, dzbuf, d_o, dqkv, rbuf, duv, dlimb3, xn_a, xn_b, wg_part;
     std::vector<WsEntry> entries;
 };
 
@@ -291,6 +293,7 @@ void build_plan(const kasf_model* m, int B, bool train, bool names, Plan& p) {
         p.dlimb3 = take(M * 3, 1, "dlimb3");
         p.xn_a = take(M * 128, 0, "scratch_xn_a");
         p.xn_b = take(M * 128, 0, "scratch_xn_b");
+        p.wg_part = take(WG_PARTIAL_FLOATS, 1, "wgrad_partials");
     }
     p.total = cur;
 }
@@ -345,8 +348,8 @@ void block_backward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void*
     // ---- MLP half ----
     kasf_launch_mlp_bwd(c.dt, c.s, c.w(w.x_mid), g_out, P + o.n2w, P + o.n2b, c.pk(o.p_fc1), P + o.fc1b, c.pk(o.p_fc2Ts), c.pk(o.p_fc1T), c.w(p.hbuf),
                         c.w(p.dzbuf), c.w(p.xn_a), g_mid, G + o.n2w, G + o.n2b, c.M);
-    kasf_launch_wgrad(c.dt, c.s, c.w(p.dzbuf), 512, 512, c.w(p.xn_a), 128, 128, nullptr, nullptr, G + o.fc1w, 128, G + o.fc1b, c.M);
-    kasf_launch_wgrad(c.dt, c.s, g_out, 128, 128, c.w(p.hbuf), 512, 512, nullptr, nullptr, G + o.fc2w, 512, G + o.fc2b, c.M);
+    kasf_launch_wgrad(c.dt, c.s, c.w(p.dzbuf), 512, 512, c.w(p.xn_a), 128, 128, nullptr, nullptr, G + o.fc1w, 128, G + o.fc1b, c.M, (float*)c.w(p.wg_part), WG_PARTIAL_FLOATS);
+    kasf_launch_wgrad(c.dt, c.s, g_out, 128, 128, c.w(p.hbuf), 512, 512, nullptr, nullptr, G + o.fc2w, 512, G + o.fc2b, c.M, (float*)c.w(p.wg_part), WG_PARTIAL_FLOATS);
     kasf_launch_finalize_ls(c.s, G + o.fc2w, P + o.fc2w, P + o.fc2b, P + o.ls2, G + o.fc2b, G + o.ls2, 128, 512);
     // ---- mixer half ----
     if (o.kind == KIND_GRAPH) {
@@ -358,12 +361,12 @@ void block_backward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void*
                              c.B, c.T, o.mode);
         kasf_launch_dgrad_lnbwd(c.dt, c.s, c.w(p.duv), 256, c.pk(o.p_mixT), c.w(p.rbuf), x_in, P + o.n1w, g_mid, dst, accumulate, G + o.n1w, G + o.n1b,
                                 c.M);
-        kasf_launch_wgrad(c.dt, c.s, c.w(p.duv), 256, 256, c.w(w.xn), 128, 128, nullptr, nullptr, G + o.mix_w, 128, G + o.uv_b, c.M);
+        kasf_launch_wgrad(c.dt, c.s, c.w(p.duv), 256, 256, c.w(w.xn), 128, 128, nullptr, nullptr, G + o.mix_w, 128, G + o.uv_b, c.M, (float*)c.w(p.wg_part), WG_PARTIAL_FLOATS);
         return;
     }
     // d_o = g_mid . (ls1 . Wproj);  G_proj = g_mid^T o (unscaled) -> finalize: dWproj, dbproj, dls1
     kasf_launch_linear(c.dt, c.s, g_mid, 128, c.pk(o.p_projTs), 128, nullptr, c.w(p.d_o), 128, c.M, 128, nullptr, nullptr, nullptr, 0);
-    kasf_launch_wgrad(c.dt, c.s, g_mid, 128, 128, c.w(w.o), 128, 128, nullptr, nullptr, G + o.proj_w, 128, G + o.proj_b, c.M);
+    kasf_launch_wgrad(c.dt, c.s, g_mid, 128, 128, c.w(w.o), 128, 128, nullptr, nullptr, G + o.proj_w, 128, G + o.proj_b, c.M, (float*)c.w(p.wg_part), WG_PARTIAL_FLOATS);
     kasf_launch_finalize_ls(c.s, G + o.proj_w, P + o.proj_w, P + o.proj_b, P + o.ls1, G + o.proj_b, G + o.ls1, 128, 128);
     if (o.kind == KIND_ATT) {
         const char* q = (const char*)c.w(w.qkv);
@@ -372,7 +375,7 @@ void block_backward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void*
                              o.mode);
         kasf_launch_dgrad_lnbwd(c.dt, c.s, dq, 384, c.pk(o.p_mixT), nullptr, x_in, P + o.n1w, g_mid, dst, accumulate, G + o.n1w, G + o.n1b, c.M,
                                 c.w(p.xn_a), P + o.n1b);
-        kasf_launch_wgrad(c.dt, c.s, dq, 384, 384, c.w(p.xn_a), 128, 128, nullptr, nullptr, G + o.mix_w, 128, nullptr, c.M);
+        kasf_launch_wgrad(c.dt, c.s, dq, 384, 384, c.w(p.xn_a), 128, 128, nullptr, nullptr, G + o.mix_w, 128, nullptr, c.M, (float*)c.w(p.wg_part), WG_PARTIAL_FLOATS);
     } else {
         const char* kv = (const char*)c.w(w.kv);
         char* dq = (char*)c.w(p.dqkv);
@@ -382,8 +385,8 @@ void block_backward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void*
                                 c.w(p.xn_a), P + o.n1b);
         kasf_launch_dgrad_lnbwd(c.dt, c.s, dkv, 256, c.pk(o.p_kvT), nullptr, x_limb, P + o.n1lw, nullptr, c.w(p.g_limb), 1, G + o.n1lw, G + o.n1lb, c.M,
                                 c.w(p.xn_b), P + o.n1lb);
-        kasf_launch_wgrad(c.dt, c.s, dq, 128, 128, c.w(p.xn_a), 128, 128, nullptr, nullptr, G + o.mix_w, 128, nullptr, c.M);
-        kasf_launch_wgrad(c.dt, c.s, dkv, 256, 256, c.w(p.xn_b), 128, 128, nullptr, nullptr, G + o.kv_w, 128, nullptr, c.M);
+        kasf_launch_wgrad(c.dt, c.s, dq, 128, 128, c.w(p.xn_a), 128, 128, nullptr, nullptr, G + o.mix_w, 128, nullptr, c.M, (float*)c.w(p.wg_part), WG_PARTIAL_FLOATS);
+        kasf_launch_wgrad(c.dt, c.s, dkv, 256, 256, c.w(p.xn_b), 128, 128, nullptr, nullptr, G + o.kv_w, 128, nullptr, c.M, (float*)c.w(p.wg_part), WG_PARTIAL_FLOATS);
     }
 }
 
@@ -572,7 +575,7 @@ int kasf_backward(const kasf_model* m, const float* params, const void* packed, 
             kasf_launch_head_bwd(c.dt, c.s, dout, c.w(p.rep), params + t.head_w, c.w(p.hbuf), grads + t.head_w, grads + t.head_b, c.M);
             kasf_launch_dgrad_lnbwd(c.dt, c.s, c.w(p.hbuf), 512, c.pk(t.p_fcT), nullptr, x_final, params + t.norm_w, nullptr, gbuf(0), 0, grads + t.norm_w,
                                     grads + t.norm_b, c.M, c.w(p.xn_a), params + t.norm_b);
-            kasf_launch_wgrad(c.dt, c.s, c.w(p.hbuf), 512, 512, c.w(p.xn_a), 128, 128, nullptr, nullptr, grads + t.fc_w, 128, grads + t.fc_b, c.M);
+            kasf_launch_wgrad(c.dt, c.s, c.w(p.hbuf), 512, 512, c.w(p.xn_a), 128, 128, nullptr, nullptr, grads + t.fc_w, 128, grads + t.fc_b, c.M, (float*)c.w(p.wg_part), WG_PARTIAL_FLOATS);
         } else if (st <= L) {
             const int l = L - st;
             const LayerOff& lo = m->layers[l];
@@ -650,11 +653,11 @@ int kasf_op_mlp_bwd(int32_t dtype, const void* x, const void* g, const float* ln
     return 0;
 }
 int kasf_op_wgrad(int32_t dtype, const void* g, int32_t N, const void* x, int32_t K, const float* ln_g, const float* ln_b, float* dw, float* dbias,
-                  int64_t M, void* stream) {
+                  int64_t M, float* partial, int64_t partial_floats, void* stream) {
     OP_DT_CHECK(dtype);
     if (N % 128 != 0 || K % 128 != 0) return kasf_set_error(2, "N and K must be multiples of 128");
     if (ln_g != nullptr && K != 128) return kasf_set_error(2, "LayerNorm-fused wgrad needs K == 128");
-    kasf_launch_wgrad(dtype, (hipStream_t)stream, g, N, N, x, K, K, ln_g, ln_b, dw, K, dbias, M);
+    kasf_launch_wgrad(dtype, (hipStream_t)stream, g, N, N, x, K, K, ln_g, ln_b, dw, K, dbias, M, partial, partial_floats);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -153,10 +153,11 @@ __device__ __forceinline__ bf16x8 frag_tr(const bf16* s, int mbase, int col0) {
     return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
+template <int ROWS = WG_BM>
 __device__ __forceinline__ void wgrad_mma(const bf16* sG, const bf16* sX, int wn0, int wk0, f32x4 (&acc)[4][4]) {
     const int g = (threadIdx.x & 63) >> 4;
 #pragma unroll
-    for (int s = 0; s < WG_BM / 32; ++s) {
+    for (int s = 0; s < ROWS / 32; ++s) {
         bf16x8 a[4], b[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -169,10 +170,11 @@ __device__ __forceinline__ void wgrad_mma(const bf16* sG, const bf16* sX, int wn
             for (int kt = 0; kt < 4; ++kt) acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[nt], b[kt], acc[nt][kt], 0, 0, 0);
     }
 }
+template <int ROWS = WG_BM>
 __device__ __forceinline__ void wgrad_mma(const float* sG, const float* sX, int wn0, int wk0, f32x4 (&acc)[4][4]) {
     const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
 #pragma unroll 4
-    for (int s = 0; s < WG_BM / 4; ++s) {
+    for (int s = 0; s < ROWS / 4; ++s) {
         float a[4], b[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -219,7 +221,7 @@ __device__ __forceinline__ void wgrad_stage_sync(T* sT, const T* src, int64_t ld
 template <typename T, int NBUF, bool LN>
 __global__ __launch_bounds__(256) void k_wgrad(const T* __restrict__ G, int64_t ldg, const T* __restrict__ X, int64_t ldx,
                                                const float* __restrict__ ln_g, const float* __restrict__ ln_b, float* __restrict__ out,
-                                               int64_t ldo, float* __restrict__ dbias, int64_t M, int64_t slice) {
+                                               int64_t ldo, float* __restrict__ dbias, int64_t M, int64_t slice, float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* sG = reinterpret_cast<T*>(smem);                 // [NBUF][128][128]
     T* sX = sG + NBUF * 128 * 128;                      // [NBUF][128][128]
@@ -269,8 +271,12 @@ __global__ __launch_bounds__(256) void k_wgrad(const T* __restrict__ G, int64_t 
             if (full(t + 1)) issue(0, m0 + WG_BM);
         }
     }
-    {   // out[n][k] += acc : lane owns 4 consecutive n (rows of out) for one k -> strided fp32 atomics (L2-resident tile)
+    {   // lane owns 4 consecutive n (rows of out) for one k
         const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+        // partial != nullptr: plain stores of this split's tile into partial[z][N][K] (N = 128*gridDim.x, K = 128*gridDim.y),
+        // summed afterwards by k_wgrad_reduce (deterministic; plain stores run ~5x the fp32-atomic rate).
+        float* dst = partial != nullptr ? partial + (int64_t)blockIdx.z * (gridDim.x * 128) * (gridDim.y * 128) : out;
+        const int64_t ld = partial != nullptr ? (int64_t)gridDim.y * 128 : ldo;
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -278,7 +284,8 @@ __global__ __launch_bounds__(256) void k_wgrad(const T* __restrict__ G, int64_t 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int n = n0 + wave_n0() + nt * 16 + g * 4 + r, k = k0 + wave_m0() + kt * 16 + i;
-                    atomicAdd(out + (int64_t)n * ldo + k, acc[nt][kt][r]);
+                    if (partial != nullptr) dst[(int64_t)n * ld + k] = acc[nt][kt][r];
+                    else atomicAdd(dst + (int64_t)n * ld + k, acc[nt][kt][r]);
                 }
     }
     if (want_bias) {
@@ -293,6 +300,144 @@ __global__ __launch_bounds__(256) void k_wgrad(const T* __restrict__ G, int64_t 
             for (int k = 0; k < 16; ++k) s += red[k * 128 + threadIdx.x];
             atomicAdd(dbias + n0 + threadIdx.x, s);
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Streaming variant (bf16, no LayerNorm): the reduction over tokens is an HBM stream of G and X, and a
+// CU needs ~50 KB in flight to hide the ~2 us HBM latency.  64-row tiles go through a 4-stage LDS ring
+// filled by LDS-direct loads issued three tiles ahead; each wave waits only for ITS loads of the
+// current tile (counted vmcnt, 8 loads per tile and wave) and the workgroup meets at a raw s_barrier,
+// so two to three tiles stay in flight across every barrier.  The ragged tail goes through registers.
+// ---------------------------------------------------------------------------------------------
+constexpr int WR_BM = 64, WR_ST = 4, WR_IPT = 8;      // rows per tile, ring stages, LDS-direct loads per tile per wave
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_wgrad_ring(const T* __restrict__ G, int64_t ldg, const T* __restrict__ X, int64_t ldx,
+                                                    float* __restrict__ out, int64_t ldo, float* __restrict__ dbias, int64_t M, int64_t slice,
+                                                    float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* ring = reinterpret_cast<T*>(smem);               // [WR_ST][2][64][128]  (G tile, X tile)
+    const int n0 = blockIdx.x * 128, k0 = blockIdx.y * 128;
+    const int64_t m_begin = (int64_t)blockIdx.z * slice, m_end = (m_begin + slice < M) ? m_begin + slice : M;
+    const int sub = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const bool want_bias = dbias != nullptr && blockIdx.y == 0;
+    float bsum[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bsum[i] = 0.f;
+    f32x4 acc[4][4];
+    zero_acc(acc);
+    const int nfull = (int)((m_end - m_begin) / WR_BM);
+    auto issue = [&](int t) {
+        T* st = ring + (t % WR_ST) * 2 * WR_BM * 128;
+        const int64_t m0 = m_begin + (int64_t)t * WR_BM;
+        stage_tile_async<T, WR_BM>(st, G + m0 * ldg + n0, ldg, WR_BM);
+        stage_tile_async<T, WR_BM>(st + WR_BM * 128, X + m0 * ldx + k0, ldx, WR_BM);
+    };
+    auto consume = [&](const T* cG, const T* cX) {
+        if (want_bias) {
+            for (int r = rl; r < WR_BM; r += 16) {
+                float v[8];
+                tile_load8(cG, r, sub * 8, v);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) bsum[i] += v[i];
+            }
+        }
+        wgrad_mma<WR_BM>(cG, cX, wave_n0(), wave_m0(), acc);
+    };
+    for (int t = 0; t < WR_ST - 1 && t < nfull; ++t) issue(t);
+    for (int t = 0; t < nfull; ++t) {
+        const int newer = nfull - 1 - t < WR_ST - 2 ? nfull - 1 - t : WR_ST - 2;     // younger tiles already requested
+        if (newer >= 2) wait_async_le<2 * WR_IPT>();
+        else if (newer == 1) wait_async_le<WR_IPT>();
+        else wait_async_le<0>();
+        barrier_keep_async();                           // tile t complete for every wave; everyone is done with tile t-1
+        if (t + WR_ST - 1 < nfull) issue(t + WR_ST - 1);    // refills the stage tile t-1 used
+        const T* st = ring + (t % WR_ST) * 2 * WR_BM * 128;
+        consume(st, st + WR_BM * 128);
+    }
+    const int64_t m_tail = m_begin + (int64_t)nfull * WR_BM;
+    if (m_tail < m_end) {                               // < 64 leftover rows: register path, zero filled (block-uniform branch)
+        __syncthreads();
+        T* st = ring;
+        for (int r = rl; r < WR_BM; r += 16) {
+            const int64_t row = m_tail + r;
+            float v[8], x[8];
+            if (row < m_end) { load8(G + row * ldg + n0 + sub * 8, v); load8(X + row * ldx + k0 + sub * 8, x); }
+            else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { v[i] = 0.f; x[i] = 0.f; }
+            }
+            tile_store8(st, r, sub * 8, v);
+            tile_store8(st + WR_BM * 128, r, sub * 8, x);
+        }
+        __syncthreads();
+        consume(st, st + WR_BM * 128);
+    }
+    {
+        const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+        float* dst = partial != nullptr ? partial + (int64_t)blockIdx.z * (gridDim.x * 128) * (gridDim.y * 128) : out;
+        const int64_t ld = partial != nullptr ? (int64_t)gridDim.y * 128 : ldo;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = n0 + wave_n0() + nt * 16 + g * 4 + r, k = k0 + wave_m0() + kt * 16 + i;
+                    if (partial != nullptr) dst[(int64_t)n * ld + k] = acc[nt][kt][r];
+                    else atomicAdd(dst + (int64_t)n * ld + k, acc[nt][kt][r]);
+                }
+    }
+    if (want_bias) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);      // [16][128]
+#pragma unroll
+        for (int i = 0; i < 8; ++i) red[rl * 128 + sub * 8 + i] = bsum[i];
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) s += red[k * 128 + threadIdx.x];
+            atomicAdd(dbias + n0 + threadIdx.x, s);
+        }
+    }
+}
+
+// out[n][k] += sum_z partial[z][n][k]   (N*K multiple of 256; out row stride ldo, partial row stride K).
+// A workgroup owns 64 consecutive float4 outputs; its 4 waves each sum every 4th split with 4 independent
+// loads in flight, then the partial sums meet in LDS (fixed order => bitwise reproducible gradients).
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ partial, float* __restrict__ out, int64_t ldo, int N, int K, int splits) {
+    __shared__ f32x4 sPart[4][64];
+    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int64_t e = ((int64_t)blockIdx.x * 64 + lane) * 4, stride = (int64_t)N * K;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    int z = part;
+    for (; z + 12 < splits; z += 16) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(partial + (int64_t)z * stride + e);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(partial + (int64_t)(z + 4) * stride + e);
+        const f32x4 c = *reinterpret_cast<const f32x4*>(partial + (int64_t)(z + 8) * stride + e);
+        const f32x4 d = *reinterpret_cast<const f32x4*>(partial + (int64_t)(z + 12) * stride + e);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { s0[q] += a[q]; s1[q] += b[q]; s2[q] += c[q]; s3[q] += d[q]; }
+    }
+    for (; z < splits; z += 4) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(partial + (int64_t)z * stride + e);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s0[q] += a[q];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s0[q] = (s0[q] + s1[q]) + (s2[q] + s3[q]);
+    sPart[part][lane] = s0;
+    __syncthreads();
+    if (part == 0) {
+        const f32x4 a = sPart[0][lane], b = sPart[1][lane], c = sPart[2][lane], d = sPart[3][lane];
+        const int n = (int)(e / K), k = (int)(e % K);
+        f32x4* o = reinterpret_cast<f32x4*>(out + (int64_t)n * ldo + k);
+        f32x4 cur = *o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cur[q] += (a[q] + b[q]) + (c[q] + d[q]);
+        *o = cur;
     }
 }
 
@@ -397,30 +542,41 @@ void kasf_launch_dgrad_lnbwd(int dt, hipStream_t s, const void* dY, int Kd, cons
 
 template <typename T>
 static void wgrad_T(hipStream_t s, const void* G, int64_t ldg, int N, const void* X, int64_t ldx, int K, const float* ln_g, const float* ln_b,
-                    float* out, int64_t ldo, float* dbias, int64_t M) {
+                    float* out, int64_t ldo, float* dbias, int64_t M, float* partial, int64_t partial_floats) {
     constexpr int NBUF = GemmCfg<T>::WG_NBUF;
     const int tiles = (N / 128) * (K / 128);
-    int splits = (512 + tiles - 1) / tiles;                         // ~2 workgroups per CU in total
+    // one workgroup per CU (the 128 KB of LDS allow only one resident anyway): fewest splits that still fill the chip
+    int splits = (248 + tiles - 1) / tiles;
     const int64_t max_splits = (M + WG_BM - 1) / WG_BM;
     if (splits > max_splits) splits = (int)max_splits;
     if (splits < 1) splits = 1;
     int64_t slice = (M + splits - 1) / splits;
     slice = (slice + WG_BM - 1) / WG_BM * WG_BM;
     splits = (int)((M + slice - 1) / slice);
+    if (partial != nullptr && (int64_t)splits * N * K > partial_floats) partial = nullptr;     // fall back to atomics
     const size_t sh = (size_t)2 * NBUF * 128 * 128 * sizeof(T);
     const dim3 grid(N / 128, K / 128, splits);
-    if (ln_g != nullptr) {
+    if (ln_g == nullptr && sizeof(T) == 2) {
+        const size_t shr = (size_t)WR_ST * 2 * WR_BM * 128 * sizeof(T);
+        set_smem(k_wgrad_ring<T>, shr);
+        hipLaunchKernelGGL(k_wgrad_ring<T>, grid, dim3(256), shr, s, (const T*)G, ldg, (const T*)X, ldx, out, ldo, dbias, M, slice, partial);
+    } else if (ln_g != nullptr) {
         set_smem(k_wgrad<T, NBUF, true>, sh);
-        hipLaunchKernelGGL((k_wgrad<T, NBUF, true>), grid, dim3(256), sh, s, (const T*)G, ldg, (const T*)X, ldx, ln_g, ln_b, out, ldo, dbias, M, slice);
+        hipLaunchKernelGGL((k_wgrad<T, NBUF, true>), grid, dim3(256), sh, s, (const T*)G, ldg, (const T*)X, ldx, ln_g, ln_b, out, ldo, dbias, M, slice,
+                           partial);
     } else {
         set_smem(k_wgrad<T, NBUF, false>, sh);
-        hipLaunchKernelGGL((k_wgrad<T, NBUF, false>), grid, dim3(256), sh, s, (const T*)G, ldg, (const T*)X, ldx, ln_g, ln_b, out, ldo, dbias, M, slice);
+        hipLaunchKernelGGL((k_wgrad<T, NBUF, false>), grid, dim3(256), sh, s, (const T*)G, ldg, (const T*)X, ldx, ln_g, ln_b, out, ldo, dbias, M, slice,
+                           partial);
+    }
+    if (partial != nullptr) {
+        hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((int64_t)N * K / 256)), dim3(256), 0, s, partial, out, ldo, N, K, splits);
     }
 }
 void kasf_launch_wgrad(int dt, hipStream_t s, const void* G, int64_t ldg, int N, const void* X, int64_t ldx, int K, const float* ln_g,
-                       const float* ln_b, float* out, int64_t ldo, float* dbias, int64_t M) {
-    DT_DISPATCH(dt, (wgrad_T<float>(s, G, ldg, N, X, ldx, K, ln_g, ln_b, out, ldo, dbias, M)),
-                (wgrad_T<bf16>(s, G, ldg, N, X, ldx, K, ln_g, ln_b, out, ldo, dbias, M)));
+                       const float* ln_b, float* out, int64_t ldo, float* dbias, int64_t M, float* partial, int64_t partial_floats) {
+    DT_DISPATCH(dt, (wgrad_T<float>(s, G, ldg, N, X, ldx, K, ln_g, ln_b, out, ldo, dbias, M, partial, partial_floats)),
+                (wgrad_T<bf16>(s, G, ldg, N, X, ldx, K, ln_g, ln_b, out, ldo, dbias, M, partial, partial_floats)));
 }
 
 void kasf_launch_pack(int dt, hipStream_t s, const float* params, void* arena, const KasfPackDesc* desc, const int* tile_start, int ndesc,

@@ -35,7 +35,9 @@ void kasf_launch_dgrad_lnbwd(int dt, hipStream_t s, const void* dY, int Kd, cons
                              const void* resid, void* out, int accumulate, float* dgamma, float* dbeta, int64_t M, void* xn_out = nullptr,
                              const float* beta = nullptr);   // xn_out: also write LN(x) (operand of the matching weight gradient)
 void kasf_launch_wgrad(int dt, hipStream_t s, const void* G, int64_t ldg, int N, const void* X, int64_t ldx, int K, const float* ln_g,
-                       const float* ln_b, float* out, int64_t ldo, float* dbias, int64_t M);
+                       const float* ln_b, float* out, int64_t ldo, float* dbias, int64_t M, float* partial = nullptr, int64_t partial_floats = 0);
+// partial: optional fp32 scratch (>= splits*N*K floats): per-split tiles are stored there and summed by a second kernel
+// (deterministic); without it the kernel falls back to fp32 atomics on `out`.
 void kasf_launch_pack(int dt, hipStream_t s, const float* params, void* arena, const KasfPackDesc* desc, const int* tile_start, int ndesc,
                       int total_tiles);
 

@@ -120,8 +120,9 @@ def test_mlp_backward_and_wgrad(lib, cd):
                                    ptr(w1t), ptr(H), ptr(dZ), ptr(gin), ptr(dg), ptr(db), M, stream()))
     dW1, db1 = torch.zeros(512, 128, device="cuda"), torch.zeros(512, device="cuda")
     dW2, gsum = torch.zeros(128, 512, device="cuda"), torch.zeros(128, device="cuda")
-    _lib.check(lib.kasf_op_wgrad(DT[cd][0], ptr(dZ), 512, ptr(xd), 128, ptr(_f32(p["g"])), ptr(_f32(p["b"])), ptr(dW1), ptr(db1), M, stream()))
-    _lib.check(lib.kasf_op_wgrad(DT[cd][0], ptr(gd), 128, ptr(H), 512, None, None, ptr(dW2), ptr(gsum), M, stream()))
+    part = torch.empty(256 * 128 * 128, device="cuda")
+    _lib.check(lib.kasf_op_wgrad(DT[cd][0], ptr(dZ), 512, ptr(xd), 128, ptr(_f32(p["g"])), ptr(_f32(p["b"])), ptr(dW1), ptr(db1), M, None, 0, stream()))
+    _lib.check(lib.kasf_op_wgrad(DT[cd][0], ptr(gd), 128, ptr(H), 512, None, None, ptr(dW2), ptr(gsum), M, ptr(part), part.numel(), stream()))   # split-partials + reduce path
     torch.cuda.synchronize()
     # reference by autograd on the rounded operands
     xr = _back(xd).requires_grad_(True)
