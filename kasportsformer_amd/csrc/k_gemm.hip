@@ -490,7 +490,7 @@ template <typename K> static void set_smem(K k, size_t bytes) {
 
 // tile shapes per dtype: bf16 keeps two weight tiles in flight; fp32 (parity mode) has twice the bytes and single-buffers
 template <typename T> struct GemmCfg;
-template <> struct GemmCfg<bf16> { static constexpr int BM = 64, NBUF = 2, WG_NBUF = 2; };
+template <> struct GemmCfg<bf16> { static constexpr int BM = 64, NBUF = 1, WG_NBUF = 2; };   // 48 KB of LDS -> 3 workgroups per CU
 template <> struct GemmCfg<float> { static constexpr int BM = 64, NBUF = 1, WG_NBUF = 1; };
 
 template <typename T>

@@ -1,0 +1,83 @@
+"""World-size-2 rehearsal of the data-parallel path on CPU (gloo): parameter / BatchNorm-buffer broadcast from
+rank 0 and the bucketed gradient all-reduce driven by the backward stage hook.  The kernels themselves need a
+GPU; here the per-stage gradient slices are filled by hand exactly where kasf_backward would have written them."""
+import ctypes as C
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, overlap, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import kasportsformer_amd as K
+        from kasportsformer_amd import _lib
+        torch.manual_seed(100 + rank)                       # different init per rank: broadcast must fix it
+        m = K.KASportsFormer(n_layers=2, num_heads=8, n_frames=27)
+        m._flat_buffers.uniform_(0, 1)
+        m._nbt.fill_(rank + 5)
+        dp = K.DataParallel(m, overlap=overlap)
+        ref = [torch.zeros_like(m._flat), torch.zeros_like(m._flat_buffers), torch.zeros_like(m._nbt)]
+        for t, src in zip(ref, (m._flat, m._flat_buffers, m._nbt)):
+            t.copy_(src)
+            dist.broadcast(t, src=0)
+        assert all(torch.equal(a, b) for a, b in zip(ref, (m._flat, m._flat_buffers, m._nbt))), "ranks differ after sync_from_rank0"
+        assert m.layers_with_bone[1].att_spatial.mixer.qkv.weight.data_ptr() >= m._flat.data_ptr()   # still views of the flat array
+        # emulate kasf_backward stage by stage: rank r contributes (r+1) * pattern to every live gradient
+        lib = _lib.load()
+        g = torch.zeros(m.n_flat)
+        pattern = torch.arange(m.n_flat, dtype=torch.float32) % 97
+        stages = lib.kasf_backward_stages(m._layout)
+        b, e = C.c_int64(), C.c_int64()
+        covered = torch.zeros(m.n_flat, dtype=torch.bool)
+        for st in range(stages):
+            _lib.check(lib.kasf_stage_grad_range(m._layout, st, C.byref(b), C.byref(e)))
+            if e.value > b.value:
+                g[b.value:e.value] = (rank + 1) * pattern[b.value:e.value]
+                covered[b.value:e.value] = True
+                if m.grad_stage_hook is not None:
+                    m.grad_stage_hook(st, g[b.value:e.value])
+        m.flat_grad = g
+        dp.finish_gradients()
+        assert covered[:m.n_live].all() and not covered[m.n_live:].any()      # dead norm1_limb tail is never reduced
+        expect = sum(r + 1 for r in range(world)) * pattern
+        assert torch.equal(g[:m.n_live], expect[:m.n_live])
+        assert torch.count_nonzero(g[m.n_live:]) == 0
+        q.put((rank, "ok"))
+    except Exception as ex:  # pragma: no cover
+        q.put((rank, repr(ex)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(overlap):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, overlap, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert all(r[1] == "ok" for r in res), res
+
+
+def test_data_parallel_bucketed_allreduce_gloo():
+    _run(overlap=True)
+
+
+def test_data_parallel_single_allreduce_gloo():
+    _run(overlap=False)
