@@ -84,7 +84,13 @@ def cpu_baseline(batch=8, steps=2):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 32))           # the GPU box gives this job a CPU share; do not oversubscribe it
+    try:                                     # cgroup quota (the GPU box shows every host CPU but grants a share)
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = min(cores, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    cores = max(1, min(cores, 64))
     torch.set_num_threads(cores)
     print(f"[bench] cpu_baseline: {cores} threads (os.cpu_count()={os.cpu_count()})", file=sys.stderr, flush=True)
     m = O.KASportsFormerOracle(n_layers=LAYERS, num_heads=8, n_frames=T).train()

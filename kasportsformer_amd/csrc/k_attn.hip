@@ -200,10 +200,11 @@ void bwd_T(hipStream_t s, const void* q, int64_t ldq, const void* k, const void*
 void kasf_launch_attn_fwd(int dt, hipStream_t s, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, void* o, int B, int T,
                           int mode) {
     if (dt == KASF_F32) fwd_T<float>(s, q, ldq, k, v, ldkv, o, B, T, mode);
-    else fwd_T<bf16>(s, q, ldq, k, v, ldkv, o, B, T, mode);
+    else if (!kasf_launch_attn_fwd_mfma(s, q, ldq, k, v, ldkv, o, B, T, mode)) fwd_T<bf16>(s, q, ldq, k, v, ldkv, o, B, T, mode);
 }
 void kasf_launch_attn_bwd(int dt, hipStream_t s, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, const void* d_o, void* dq,
                           int64_t lddq, void* dk, void* dv, int64_t lddkv, int B, int T, int mode) {
     if (dt == KASF_F32) bwd_T<float>(s, q, ldq, k, v, ldkv, d_o, dq, lddq, dk, dv, lddkv, B, T, mode);
-    else bwd_T<bf16>(s, q, ldq, k, v, ldkv, d_o, dq, lddq, dk, dv, lddkv, B, T, mode);
+    else if (!kasf_launch_attn_bwd_mfma(s, q, ldq, k, v, ldkv, d_o, dq, lddq, dk, dv, lddkv, B, T, mode))
+        bwd_T<bf16>(s, q, ldq, k, v, ldkv, d_o, dq, lddq, dk, dv, lddkv, B, T, mode);
 }

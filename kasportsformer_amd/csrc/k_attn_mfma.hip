@@ -1,0 +1,259 @@
+// MFMA attention cores for bf16 mode (reference: modules/selfattention.py:18-41, bone_crossattention.py:19-41).
+// One wave owns one (group, head): group = the 17 joints of a frame (spatial) or the T frames of one joint
+// (temporal); head dim 16 is exactly the K of v_mfma_f32_32x32x16_bf16, so one MFMA yields a 32x32 score tile.
+//
+// Orientation is chosen so that nothing ever moves between lanes:
+//   S^T[key][query] = K . Q^T   (A = K rows, B = Q rows: both are plain 16-byte row loads)
+//   -> D layout: lane = query, registers = keys  => softmax statistics are lane-local (+1 xor-32 exchange)
+//   O^T[d][query]   = V^T . P^T (A = V^T fragments by ds_read_b64_tr_b16 from the row-major V tile in LDS,
+//                                B = P^T straight from this lane's score registers, normalised and cast to bf16)
+//   -> D layout: lane = query, registers = d  => two 8-byte stores per lane, normalisation is lane-local.
+// The accumulator->operand reuse relies on the 32x32 C/D map (row = (reg&3) + 8(reg>>2) + 4(lane>>5)): registers
+// 8s..8s+7 of a tile are k-step s of the next product with key  kappa = 16s + 8(j>>2) + 4(lane>>5) + (j&3),
+// and the transposed LDS reads fetch the other operand in exactly that key order.
+// Backward runs two passes per (group, head): pass 1 with lane = query (softmax statistics, delta, dQ), pass 2
+// with lane = key (S and dP recomputed un-transposed; dK, dV), exchanging only 3 floats per query through LDS.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+__device__ __forceinline__ int64_t tok_of(int G, int i, int T, int mode) {
+    return mode == 0 ? (int64_t)G * KASF_J + i : (int64_t)(G / KASF_J) * T * KASF_J + (int64_t)i * KASF_J + (G % KASF_J);
+}
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
+__device__ __forceinline__ bf16x8 zero8() {
+    bf16x8 z;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) z[i] = (bf16)0.f;
+    return z;
+}
+// position (key or query index inside its 32-tile) held by register `reg` of a 32x32 accumulator in lane half hh
+__device__ __forceinline__ int pos_of(int reg, int hh) { return (reg & 3) + 8 * (reg >> 2) + 4 * hh; }
+
+// natural row fragment: 8 consecutive head channels of position `pos` (zero beyond L); optionally mirrored into the LDS tile
+__device__ __forceinline__ bf16x8 row_frag(const bf16* base, int64_t ld, int G, int pos, int L, int Tn, int mode, int h, int hh, bf16* s_tile) {
+    bf16x8 v = zero8();
+    if (pos < L) v = *reinterpret_cast<const bf16x8*>(base + tok_of(G, pos, Tn, mode) * ld + h * 16 + 8 * hh);
+    if (s_tile != nullptr) *reinterpret_cast<bf16x8*>(s_tile + pos * 16 + 8 * hh) = v;
+    return v;
+}
+// transposed fragment for k-step ks out of a row-major [positions][16] tile: element j of lane half hh = tile[kappa(ks,hh,j)][lane & 15]
+__device__ __forceinline__ bf16x8 tr_frag(const bf16* s_tile, int ks) {
+    const int lane = threadIdx.x & 63, u = lane & 15, hh = lane >> 5, q = u >> 2, p = u & 3;
+    typedef __attribute__((address_space(3))) bf16x4 lds_v4;
+    const int k0 = 16 * ks + 4 * hh;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)(s_tile + (k0 + q) * 16 + 4 * p));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)(s_tile + (k0 + 8 + q) * 16 + 4 * p));
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+// registers 8s..8s+7 of an accumulator tile -> bf16 operand fragment of k-step s
+__device__ __forceinline__ bf16x8 pack8(const f32x16& t, int s) {
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (bf16)t[8 * s + j];
+    return o;
+}
+// lane = position (query or key), registers 0..7 = channels {4hh..4hh+3, 8+4hh..8+4hh+3} of the head
+__device__ __forceinline__ void store_t(bf16* dst, const f32x16& t, int hh) {
+    float a[4] = {t[0], t[1], t[2], t[3]}, b[4] = {t[4], t[5], t[6], t[7]};
+    store4(dst + 4 * hh, a);
+    store4(dst + 8 + 4 * hh, b);
+}
+
+template <int NKT>
+__global__ __launch_bounds__(256) void k_attn_fwd_mfma(const bf16* __restrict__ Q, int64_t ldq, const bf16* __restrict__ K, const bf16* __restrict__ V,
+                                                       int64_t ldkv, bf16* __restrict__ O, int L, int Tn, int mode, int units) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
+    const int unit = blockIdx.x * 4 + wave;
+    if (unit >= units) return;                                   // wave-uniform; no workgroup barrier below
+    const int G = unit >> 3, h = unit & 7;
+    bf16* sV = reinterpret_cast<bf16*>(smem) + wave * (NKT * 32 * 16);
+    bf16x8 kf[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+        kf[kt] = row_frag(K, ldkv, G, 32 * kt + r, L, Tn, mode, h, hh, nullptr);
+        row_frag(V, ldkv, G, 32 * kt + r, L, Tn, mode, h, hh, sV);
+    }
+#pragma unroll
+    for (int qt = 0; qt < NKT; ++qt) {
+        if (32 * qt >= L) break;
+        const int i = 32 * qt + r;
+        const bf16x8 qf = row_frag(Q, ldq, G, i, L, Tn, mode, h, hh, nullptr);
+        f32x16 st[NKT];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            st[kt] = mfma32(kf[kt], qf, zero16());
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const float s = (32 * kt + pos_of(g, hh) < L) ? st[kt][g] * 0.25f : -INFINITY;
+                st[kt][g] = s;
+                mx = fmaxf(mx, s);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) { st[kt][g] = __expf(st[kt][g] - mx); sum += st[kt][g]; }
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.0f / sum;
+        f32x16 ot = zero16();
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+            for (int g = 0; g < 16; ++g) st[kt][g] *= inv;
+            ot = mfma32(tr_frag(sV, 2 * kt), pack8(st[kt], 0), ot);
+            ot = mfma32(tr_frag(sV, 2 * kt + 1), pack8(st[kt], 1), ot);
+        }
+        if (i < L) store_t(O + tok_of(G, i, Tn, mode) * 128 + h * 16, ot, hh);
+    }
+}
+
+template <int NKT>
+__global__ __launch_bounds__(256) void k_attn_bwd_mfma(const bf16* __restrict__ Q, int64_t ldq, const bf16* __restrict__ K, const bf16* __restrict__ V,
+                                                       int64_t ldkv, const bf16* __restrict__ dO, bf16* __restrict__ dQ, int64_t lddq,
+                                                       bf16* __restrict__ dK, bf16* __restrict__ dV, int64_t lddkv, int L, int Tn, int mode, int units) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TILE = NKT * 32 * 16;                           // bf16 elements of one [positions][16] tile
+    constexpr int WAVE_BYTES = 3 * TILE * 2 + NKT * 32 * 16;      // K, Q, dO tiles + [positions][4] fp32 statistics
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
+    const int unit = blockIdx.x * 4 + wave;
+    if (unit >= units) return;
+    const int G = unit >> 3, h = unit & 7;
+    bf16* sK = reinterpret_cast<bf16*>(smem + wave * WAVE_BYTES);
+    bf16* sQ = sK + TILE;
+    bf16* sD = sQ + TILE;
+    f32x4* sStat = reinterpret_cast<f32x4*>(sD + TILE);
+    bf16x8 kf[NKT], vf[NKT], qf[NKT], df[NKT];
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) {
+        const int pos = 32 * t + r;
+        kf[t] = row_frag(K, ldkv, G, pos, L, Tn, mode, h, hh, sK);
+        vf[t] = row_frag(V, ldkv, G, pos, L, Tn, mode, h, hh, nullptr);
+        qf[t] = row_frag(Q, ldq, G, pos, L, Tn, mode, h, hh, sQ);
+        df[t] = row_frag(dO, 128, G, pos, L, Tn, mode, h, hh, sD);
+    }
+    // ---------------- pass 1: lane = query ----------------
+#pragma unroll
+    for (int qt = 0; qt < NKT; ++qt) {
+        if (32 * qt >= L) break;
+        const int i = 32 * qt + r;
+        f32x16 st[NKT], dp[NKT];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            st[kt] = mfma32(kf[kt], qf[qt], zero16());            // S^T[key][query]
+            dp[kt] = mfma32(vf[kt], df[qt], zero16());            // dP^T[key][query] = sum_d V[key][d] dO[query][d]
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const float s = (32 * kt + pos_of(g, hh) < L) ? st[kt][g] * 0.25f : -INFINITY;
+                st[kt][g] = s;
+                mx = fmaxf(mx, s);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) { st[kt][g] = __expf(st[kt][g] - mx); sum += st[kt][g]; }
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.0f / sum;
+        float delta = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) { st[kt][g] *= inv; delta += st[kt][g] * dp[kt][g]; }
+        delta += __shfl_xor(delta, 32);
+        f32x16 dq = zero16();
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+            for (int g = 0; g < 16; ++g) st[kt][g] = st[kt][g] * (dp[kt][g] - delta) * 0.25f;     // dS^T (scale folded)
+            dq = mfma32(tr_frag(sK, 2 * kt), pack8(st[kt], 0), dq);                                // dQ^T[d][query] += K^T . dS^T
+            dq = mfma32(tr_frag(sK, 2 * kt + 1), pack8(st[kt], 1), dq);
+        }
+        if (i < L) store_t(dQ + tok_of(G, i, Tn, mode) * lddq + h * 16, dq, hh);
+        if (hh == 0) sStat[i] = f32x4{mx, inv, delta, 0.f};
+    }
+    // ---------------- pass 2: lane = key ----------------
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+        if (32 * kt >= L) break;
+        const int j = 32 * kt + r;
+        f32x16 dv = zero16(), dk = zero16();
+#pragma unroll
+        for (int qt = 0; qt < NKT; ++qt) {
+            if (32 * qt >= L) break;
+            f32x16 s = mfma32(qf[qt], kf[kt], zero16());          // S[query][key]
+            f32x16 dp = mfma32(df[qt], vf[kt], zero16());         // dP[query][key]
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int i = 32 * qt + pos_of(g, hh);
+                const f32x4 stt = sStat[i < L ? i : 0];
+                const float p = (i < L) ? __expf(s[g] * 0.25f - stt[0]) * stt[1] : 0.f;
+                s[g] = p;                                          // P[query][key]
+                dp[g] = p * (dp[g] - stt[2]) * 0.25f;              // dS[query][key]
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                dv = mfma32(tr_frag(sD, 2 * qt + ks), pack8(s, ks), dv);       // dV^T[d][key] += dO^T . P
+                dk = mfma32(tr_frag(sQ, 2 * qt + ks), pack8(dp, ks), dk);      // dK^T[d][key] += Q^T . dS
+            }
+        }
+        if (j < L) {
+            const int64_t tok = tok_of(G, j, Tn, mode);
+            store_t(dV + tok * lddkv + h * 16, dv, hh);
+            store_t(dK + tok * lddkv + h * 16, dk, hh);
+        }
+    }
+}
+
+template <typename K> void set_smem(K k, size_t bytes) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+}  // namespace
+
+// returns false when the shape is outside the MFMA kernels' range (caller falls back to the VALU kernels)
+bool kasf_launch_attn_fwd_mfma(hipStream_t s, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, void* o, int B, int Tn, int mode) {
+    const int L = mode == 0 ? KASF_J : Tn, groups = mode == 0 ? B * Tn : B * KASF_J, units = groups * 8;
+    if (L > 96) return false;
+    const dim3 grid((units + 3) / 4);
+    if (L <= 32) {
+        hipLaunchKernelGGL(k_attn_fwd_mfma<1>, grid, dim3(256), 4 * 1 * 32 * 16 * 2, s, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldkv, (bf16*)o, L,
+                           Tn, mode, units);
+    } else {
+        hipLaunchKernelGGL(k_attn_fwd_mfma<3>, grid, dim3(256), 4 * 3 * 32 * 16 * 2, s, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldkv, (bf16*)o, L,
+                           Tn, mode, units);
+    }
+    return true;
+}
+bool kasf_launch_attn_bwd_mfma(hipStream_t s, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, const void* d_o, void* dq,
+                               int64_t lddq, void* dk, void* dv, int64_t lddkv, int B, int Tn, int mode) {
+    const int L = mode == 0 ? KASF_J : Tn, groups = mode == 0 ? B * Tn : B * KASF_J, units = groups * 8;
+    if (L > 96) return false;
+    const dim3 grid((units + 3) / 4);
+    if (L <= 32) {
+        const size_t sh = 4 * (3 * 32 * 16 * 2 + 32 * 16);
+        hipLaunchKernelGGL(k_attn_bwd_mfma<1>, grid, dim3(256), sh, s, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldkv, (const bf16*)d_o, (bf16*)dq,
+                           lddq, (bf16*)dk, (bf16*)dv, lddkv, L, Tn, mode, units);
+    } else {
+        const size_t sh = 4 * (3 * 96 * 16 * 2 + 96 * 16);
+        hipLaunchKernelGGL(k_attn_bwd_mfma<3>, grid, dim3(256), sh, s, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldkv, (const bf16*)d_o, (bf16*)dq,
+                           lddq, (bf16*)dk, (bf16*)dv, lddkv, L, Tn, mode, units);
+    }
+    return true;
+}

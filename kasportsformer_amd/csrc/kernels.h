@@ -57,6 +57,11 @@ void kasf_launch_attn_fwd(int dt, hipStream_t s, const void* q, int64_t ldq, con
 void kasf_launch_attn_bwd(int dt, hipStream_t s, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, const void* d_o, void* dq,
                           int64_t lddq, void* dk, void* dv, int64_t lddkv, int B, int T, int mode);
 
+// ---- k_attn_mfma.hip (bf16 only; return false when the shape is outside their range) ----
+bool kasf_launch_attn_fwd_mfma(hipStream_t s, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, void* o, int B, int T, int mode);
+bool kasf_launch_attn_bwd_mfma(hipStream_t s, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, const void* d_o, void* dq,
+                               int64_t lddq, void* dk, void* dv, int64_t lddkv, int B, int T, int mode);
+
 // ---- k_gcn.hip ----
 void kasf_gcn_init();   // uploads the skeleton table to constant memory (blocking; call once per process before capture)
 void kasf_launch_gcn_agg_fwd(int dt, hipStream_t s, const void* uv, const void* xn, void* y, uint32_t* mask, double* stats, int B, int T, int mode);
