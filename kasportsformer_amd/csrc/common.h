@@ -62,12 +62,18 @@ __device__ __forceinline__ void store4(float* p, const float (&v)[4]) {
     *reinterpret_cast<f32x4*>(p) = a;
 }
 
-// reduce over an aligned group of 16 lanes
+// Sum over an aligned group of 16 lanes (one DPP "row"), result in every lane.  Pure VALU (v_add with DPP operand
+// modifiers): quad xor-1, quad xor-2, mirror within 8, mirror within 16.  __shfl_xor would lower to ds_bpermute_b32,
+// i.e. 4 dependent LDS round trips (~100+ cycles each) per reduction -- the LayerNorm paths do 2-6 reductions per row.
+template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
+    const int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false);
+    return v + __builtin_bit_cast(float, t);
+}
 __device__ __forceinline__ float reduce16(float v) {
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 4);
-    v += __shfl_xor(v, 8);
+    v = dpp_add<0xB1>(v);      // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);      // quad_perm [2,3,0,1]
+    v = dpp_add<0x141>(v);     // row_half_mirror
+    v = dpp_add<0x140>(v);     // row_mirror
     return v;
 }
 __device__ __forceinline__ float reduce64(float v) {

@@ -32,7 +32,7 @@ struct BlockOff {
 struct LayerOff { BlockOff blk[6]; int64_t fus_w, fus_b, begin, end; };
 struct TopOff { int64_t norm_w, norm_b, fc_w, fc_b, head_w, head_b, p_fc, p_fcT, begin, end; };
 
-constexpr int64_t WG_PARTIAL_FLOATS = 256 * 128 * 128;     // one 128x128 fp32 tile per workgroup of a <= 256-workgroup wgrad launch
+constexpr int64_t WG_PARTIAL_FLOATS = 2 * 64 * 65536;       // per-split weight-gradient tiles: 256 workgroups x 128x128, or 64 ranges x (dW1 + dW2) of the MLP
 
 struct BlkWs { int64_t qkv, kv, o, xn, y, mask, x_mid, x_out, stats, bstats, coef; };
 struct LayerWs { BlkWs b[6]; int64_t gate_out, alpha; };
@@ -346,10 +346,18 @@ void block_backward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void*
     float* G = c.G;
     void* g_mid = c.w(p.t2);
     // ---- MLP half ----
-    kasf_launch_mlp_bwd(c.dt, c.s, c.w(w.x_mid), g_out, P + o.n2w, P + o.n2b, c.pk(o.p_fc1), P + o.fc1b, c.pk(o.p_fc2Ts), c.pk(o.p_fc1T), c.w(p.hbuf),
-                        c.w(p.dzbuf), c.w(p.xn_a), g_mid, G + o.n2w, G + o.n2b, c.M);
-    kasf_launch_wgrad(c.dt, c.s, c.w(p.dzbuf), 512, 512, c.w(p.xn_a), 128, 128, nullptr, nullptr, G + o.fc1w, 128, G + o.fc1b, c.M, (float*)c.w(p.wg_part), WG_PARTIAL_FLOATS);
-    kasf_launch_wgrad(c.dt, c.s, g_out, 128, 128, c.w(p.hbuf), 512, 512, nullptr, nullptr, G + o.fc2w, 512, G + o.fc2b, c.M, (float*)c.w(p.wg_part), WG_PARTIAL_FLOATS);
+    if (c.dt == KASF_BF16) {
+        // hidden-quarter kernel: dgrad + both weight gradients fused, then the 4-way partial sum + LayerNorm backward
+        kasf_launch_mlp_bwd_q(c.s, c.w(w.x_mid), g_out, P + o.n2w, P + o.n2b, c.pk(o.p_fc1), P + o.fc1b, c.pk(o.p_fc2Ts), c.pk(o.p_fc1T), c.w(p.hbuf),
+                              (float*)c.w(p.wg_part), G + o.fc1w, G + o.fc2w, G + o.fc1b, G + o.fc2b, g_mid, G + o.n2w, G + o.n2b, c.M);
+    } else {
+        kasf_launch_mlp_bwd(c.dt, c.s, c.w(w.x_mid), g_out, P + o.n2w, P + o.n2b, c.pk(o.p_fc1), P + o.fc1b, c.pk(o.p_fc2Ts), c.pk(o.p_fc1T), c.w(p.hbuf),
+                            c.w(p.dzbuf), c.w(p.xn_a), g_mid, G + o.n2w, G + o.n2b, c.M);
+        kasf_launch_wgrad(c.dt, c.s, c.w(p.dzbuf), 512, 512, c.w(p.xn_a), 128, 128, nullptr, nullptr, G + o.fc1w, 128, G + o.fc1b, c.M,
+                          (float*)c.w(p.wg_part), WG_PARTIAL_FLOATS);
+        kasf_launch_wgrad(c.dt, c.s, g_out, 128, 128, c.w(p.hbuf), 512, 512, nullptr, nullptr, G + o.fc2w, 512, G + o.fc2b, c.M, (float*)c.w(p.wg_part),
+                          WG_PARTIAL_FLOATS);
+    }
     kasf_launch_finalize_ls(c.s, G + o.fc2w, P + o.fc2w, P + o.fc2b, P + o.ls2, G + o.fc2b, G + o.ls2, 128, 512);
     // ---- mixer half ----
     if (o.kind == KIND_GRAPH) {

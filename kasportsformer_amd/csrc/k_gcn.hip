@@ -405,7 +405,7 @@ void kasf_launch_gcn_bwd1(int dt, hipStream_t s, const void* g, const void* xn, 
     const int64_t M = (int64_t)B * T * KASF_J;
     const int nodes = mode == 0 ? KASF_J : T;
     unsigned grid = ew_grid(M);
-    if (grid > 1024) grid = 1024;
+    if (grid > 512) grid = 512;                          // block-end atomics on dls1 / BN sums are same-address
     if (dt == KASF_F32) hipLaunchKernelGGL(k_gcn_bwd1<float>, dim3(grid), dim3(256), 0, s, (const float*)g, (const float*)xn, (const float*)y, coef, ls1, (float*)r, dls1, bstats, M, T, mode, nodes);
     else hipLaunchKernelGGL(k_gcn_bwd1<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)g, (const bf16*)xn, (const bf16*)y, coef, ls1, (bf16*)r, dls1, bstats, M, T, mode, nodes);
 }

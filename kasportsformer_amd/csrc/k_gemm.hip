@@ -142,17 +142,6 @@ __global__ __launch_bounds__(256) void k_dgrad_lnbwd(const T* __restrict__ dY, i
 // ---------------------------------------------------------------------------------------------
 constexpr int WG_BM = 128;
 
-template <typename T> __device__ __forceinline__ int eoff(int row, int col) { return Tile<T>::chunk_off(row, col / Tile<T>::EPC) + (col % Tile<T>::EPC); }
-
-__device__ __forceinline__ bf16x8 frag_tr(const bf16* s, int mbase, int col0) {
-    // group of 16 lanes: lane u = 4q+p supplies row (mbase+q), columns col0+4p..; lane u receives column col0+u of 4 rows
-    const int u = threadIdx.x & 15, q = u >> 2, p = u & 3;
-    typedef __attribute__((address_space(3))) bf16x4 lds_v4;
-    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)(s + eoff<bf16>(mbase + q, col0 + 4 * p)));
-    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)(s + eoff<bf16>(mbase + 4 + q, col0 + 4 * p)));
-    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-}
-
 template <int ROWS = WG_BM>
 __device__ __forceinline__ void wgrad_mma(const bf16* sG, const bf16* sX, int wn0, int wk0, f32x4 (&acc)[4][4]) {
     const int g = (threadIdx.x & 63) >> 4;
@@ -577,6 +566,10 @@ void kasf_launch_wgrad(int dt, hipStream_t s, const void* G, int64_t ldg, int N,
                        const float* ln_b, float* out, int64_t ldo, float* dbias, int64_t M, float* partial, int64_t partial_floats) {
     DT_DISPATCH(dt, (wgrad_T<float>(s, G, ldg, N, X, ldx, K, ln_g, ln_b, out, ldo, dbias, M, partial, partial_floats)),
                 (wgrad_T<bf16>(s, G, ldg, N, X, ldx, K, ln_g, ln_b, out, ldo, dbias, M, partial, partial_floats)));
+}
+
+void kasf_launch_wgrad_reduce(hipStream_t s, const float* partial, float* out, int64_t ldo, int N, int K, int splits) {
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((int64_t)N * K / 256)), dim3(256), 0, s, partial, out, ldo, N, K, splits);
 }
 
 void kasf_launch_pack(int dt, hipStream_t s, const float* params, void* arena, const KasfPackDesc* desc, const int* tile_start, int ndesc,

@@ -544,7 +544,7 @@ void kasf_launch_gate_fwd(int dt, hipStream_t s, const void* xa, const void* xg,
 }
 void kasf_launch_gate_bwd(int dt, hipStream_t s, const void* g, const void* xa, const void* xg, const void* xb, const float* W, const float* alpha,
                           void* ga, void* gg, void* gb, float* dW, float* db, int64_t M, int adaptive) {
-    const unsigned grid = ew_grid(M * 16, 1024);
+    const unsigned grid = ew_grid(M * 16, 256);         // each block ends with 1,155 same-address atomics: keep the block count low
     if (dt == KASF_F32) hipLaunchKernelGGL(k_gate_bwd<float>, dim3(grid), dim3(256), 0, s, (const float*)g, (const float*)xa, (const float*)xg, (const float*)xb, W, alpha, (float*)ga, (float*)gg, (float*)gb, dW, db, M, adaptive);
     else hipLaunchKernelGGL(k_gate_bwd<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)g, (const bf16*)xa, (const bf16*)xg, (const bf16*)xb, W, alpha, (bf16*)ga, (bf16*)gg, (bf16*)gb, dW, db, M, adaptive);
 }
@@ -554,7 +554,7 @@ void kasf_launch_head_fwd(int dt, hipStream_t s, const void* rep, const float* W
     else hipLaunchKernelGGL(k_head_fwd<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)rep, W, b, out, M);
 }
 void kasf_launch_head_bwd(int dt, hipStream_t s, const float* dy, const void* rep, const float* W, void* dpre, float* dW, float* db, int64_t M) {
-    const unsigned grid = ew_grid(M * 16, 1024);
+    const unsigned grid = ew_grid(M * 16, 256);
     if (dt == KASF_F32) hipLaunchKernelGGL(k_head_bwd<float>, dim3(grid), dim3(256), 0, s, dy, (const float*)rep, W, (float*)dpre, dW, db, M);
     else hipLaunchKernelGGL(k_head_bwd<bf16>, dim3(grid), dim3(256), 0, s, dy, (const bf16*)rep, W, (bf16*)dpre, dW, db, M);
 }

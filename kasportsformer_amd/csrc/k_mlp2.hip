@@ -1,0 +1,363 @@
+// MLP backward, second generation (bf16 mode): hidden-quarter ownership with register-resident weights.
+//
+// Problem with the first generation (k_mlp_bwd + two k_wgrad launches): the 512-wide H and dZ had to round-trip
+// through HBM (480 MB per block at B=256) and every 128x128 weight block was re-streamed from L2 per 64 tokens,
+// with a workgroup barrier per block: the kernel spent >50 % of its wave-cycles waiting.
+//
+// Here a workgroup (8 waves) owns ONE QUARTER of the hidden units (128 of 512) and a long range of tokens:
+//   * its slices of W1, (ls2.W2)^T and W1^T live in VGPRs for the whole kernel (3 x 16 registers per wave):
+//     wave w owns hidden units 16w..16w+15 of the quarter for Z / dH and channels 16w..16w+15 for dA;
+//   * per 64-token tile:  Z_q = W1_q LN(x)^T,  dH_q = (ls2.W2)_q^T g^T,  H_q = GELU(Z_q),  dZ_q = dH_q GELU'(Z_q)
+//     go registers -> LDS (bf16) once;  dA_q = W1_q^T dZ_q is stored as a bf16 partial (summed over the four
+//     quarters by k_lnbwd_sum4, which also does the LayerNorm backward + residual);
+//   * the weight gradients  dW1_q += dZ_q^T LN(x)  and  dW2_q += g^T H_q  accumulate in registers over the whole
+//     token range (2 x 32 registers per lane) from transposed LDS fragments (ds_read_b64_tr_b16), and leave the
+//     kernel once as per-range partial tiles for the deterministic k_wgrad_reduce.
+// HBM traffic per token drops from ~5.5 KB (dgrad + two wgrads) to ~3.3 KB, nothing streams from L2 in the loop,
+// and there are two barriers per 64 tokens.
+#include "common.h"
+#include "kernels.h"
+#include "tile_ops.h"
+
+namespace {
+
+constexpr int Q_BM = 32;          // tokens per tile (64 overflows the 256-register budget of a 2-waves-per-SIMD wave)
+constexpr int Q_MT = Q_BM / 16;   // 16-token tiles per tile
+constexpr int Q_NW = 8;           // waves per workgroup of k_mlp_bwd_q (see the kernel comment)
+
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+
+// B-operand fragment (rows = tokens) of k-step ks from a swizzled [rows][128] tile
+__device__ __forceinline__ bf16x8 tok_frag(const bf16* s, int row, int ks) {
+    const int g = (threadIdx.x & 63) >> 4;
+    return *reinterpret_cast<const bf16x8*>(s + Tile<bf16>::chunk_off(row, 4 * ks + g));
+}
+
+// NW waves per workgroup: 8 (2 per SIMD, 256 registers each) or 4 "fat" waves (1 per SIMD, 512 registers: room for the
+// compiler to batch LDS operand reads ahead of the MFMAs).  A wave owns HW = 128/NW hidden units (Z, dH), HW channels
+// (dA) and a 32 x (1024/NW) block of each 128 x 128 weight-gradient quarter.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void k_mlp_bwd_q(const bf16* __restrict__ X, const bf16* __restrict__ G, const float* __restrict__ ln_g,
+                                                       const float* __restrict__ ln_b, const bf16* __restrict__ W1, const float* __restrict__ b1,
+                                                       const bf16* __restrict__ W2ts, const bf16* __restrict__ W1t, bf16* __restrict__ dApart,
+                                                       float* __restrict__ dW1part, float* __restrict__ dW2part, float* __restrict__ db1,
+                                                       int64_t M, int tiles_per_range) {
+    constexpr int NTHR = NW * 64, NTW = 8 / NW;           // 16-row tiles of hidden units / channels per wave
+    constexpr int CT = 32 / NW;                           // 16-column tiles of the weight-gradient block per wave
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* sA = reinterpret_cast<bf16*>(smem);            // [2][BM][128] LN(x), double buffered
+    bf16* sG = sA + 2 * Q_BM * 128;                      // [3][BM][128] upstream gradient: in use / landed / in flight
+    bf16* sH = sG + 3 * Q_BM * 128;                      // [BM][128]    H of this quarter
+    bf16* sD = sH + Q_BM * 128;                          // [BM][128]    dZ of this quarter
+    bf16* sXr = sD + Q_BM * 128;                         // [2][BM][128] raw x rows (LDS-direct landing zone), two tiles ahead
+    const int q = blockIdx.x & 3, range = blockIdx.x >> 2;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+    const int64_t tile0 = (int64_t)range * tiles_per_range;
+    const int64_t ntiles_total = (M + Q_BM - 1) / Q_BM;
+    int64_t ntiles = ntiles_total - tile0;
+    if (ntiles > tiles_per_range) ntiles = tiles_per_range;
+    const int h0 = 16 * NTW * w;                          // first hidden unit / channel of this wave inside the quarter
+
+    // ---- register-resident weight slices ----
+    bf16x8 w1f[NTW][4], w2f[NTW][4], wtf[NTW][4];
+    f32x4 bias4[NTW];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            w1f[nt][ks] = *reinterpret_cast<const bf16x8*>(W1 + (int64_t)(q * 128 + h0 + 16 * nt + i) * 128 + 32 * ks + 8 * g);
+            w2f[nt][ks] = *reinterpret_cast<const bf16x8*>(W2ts + (int64_t)(q * 128 + h0 + 16 * nt + i) * 128 + 32 * ks + 8 * g);
+            wtf[nt][ks] = *reinterpret_cast<const bf16x8*>(W1t + (int64_t)(h0 + 16 * nt + i) * 512 + q * 128 + 32 * ks + 8 * g);
+        }
+        bias4[nt] = *reinterpret_cast<const f32x4*>(b1 + q * 128 + h0 + 16 * nt + 4 * g);
+    }
+    const int tr0 = NW == 4 ? 32 * w : 32 * (w >> 1), tc0 = NW == 4 ? 0 : 64 * (w & 1);
+    f32x4 accW1[2][CT], accW2[2][CT];
+    zero_acc(accW1);
+    zero_acc(accW2);
+    f32x4 db1acc[NTW];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) db1acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int sub = threadIdx.x & 15;
+    // phase 1 (right after B2): request g by LDS-direct loads and x into registers; phase 2 (after the GEMMs): LayerNorm -> LDS
+    // Tile t's g and raw x are requested TWO tiles ahead (HBM latency is longer than one tile's work); every request is
+    // exactly LPI LDS-direct loads per wave, so "all but the youngest LPI" == "everything requested before the last issue".
+    constexpr int LPI = 2 * (Q_BM / 4 / NW);
+    auto stage_issue = [&](int64_t t) {
+        if (t < ntiles) {
+            const int64_t row0 = (tile0 + t) * Q_BM;
+            const int nvalid = (int)((M - row0) < Q_BM ? (M - row0) : Q_BM);
+            stage_tile_async<bf16, Q_BM, NTHR>(sG + (int)(t % 3) * Q_BM * 128, G + row0 * 128, 128, nvalid);
+            stage_tile_async<bf16, Q_BM, NTHR>(sXr + (int)(t & 1) * Q_BM * 128, X + row0 * 128, 128, nvalid);
+        } else {                                         // keep the per-issue load count constant (harmless re-read of the last tile)
+            stage_tile_async<bf16, Q_BM, NTHR>(sG + (int)(t % 3) * Q_BM * 128, G, 128, 1);
+            stage_tile_async<bf16, Q_BM, NTHR>(sXr + (int)(t & 1) * Q_BM * 128, X, 128, 1);
+        }
+    };
+    auto stage_finish = [&](int64_t t, int buf) {
+        const int64_t row0 = (tile0 + t) * Q_BM;
+        // gamma / beta as unconditional vector loads (L1 hits).  A per-element "cond ? f(load) : 0" makes hipcc branch
+        // around every scalar load with a full vmcnt(0) each: 32 dependent round trips per tile.
+        float gmv[8], btv[8];
+        {
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(ln_g + sub * 8), g1 = *reinterpret_cast<const f32x4*>(ln_g + sub * 8 + 4);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(ln_b + sub * 8), b1v = *reinterpret_cast<const f32x4*>(ln_b + sub * 8 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { gmv[e] = g0[e]; gmv[4 + e] = g1[e]; btv[e] = b0[e]; btv[4 + e] = b1v[e]; }
+        }
+        // wave w normalises exactly the rows its own LDS-direct loads delivered (rows [w*BM/NW, (w+1)*BM/NW)), so its own
+        // counted vmcnt is all the synchronisation this needs (the caller has waited for everything but the youngest issue)
+        constexpr int RPW = Q_BM / NW;
+        const bf16* xr = sXr + (int)(t & 1) * Q_BM * 128;
+        static_assert(RPW % 4 == 0, "each wave normalises whole groups of 4 rows");
+#pragma unroll
+        for (int b = 0; b < RPW / 4; ++b) {
+            const int r = w * RPW + 4 * b + (lane >> 4);
+            float v[8];
+            tile_load8(xr, r, sub * 8, v);
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += v[e];
+            const float mean = reduce16(s) * (1.0f / 128.0f);
+            float qv = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { v[e] -= mean; qv += v[e] * v[e]; }
+            const float rstd = rsqrtf(reduce16(qv) * (1.0f / 128.0f) + KASF_LN_EPS);
+            const float keep = row0 + r < M ? 1.0f : 0.0f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (v[e] * rstd * gmv[e] + btv[e]) * keep;
+            tile_store8(sA + buf * Q_BM * 128, r, sub * 8, v);
+        }
+    };
+    stage_issue(0);
+    stage_issue(1);
+    wait_async_le<LPI>();                                // tile 0 landed, tile 1 may still be in flight
+    if (ntiles > 0) stage_finish(0, 0);
+    for (int64_t t = 0; t < ntiles; ++t) {
+        const int buf = (int)(t & 1);
+        const bf16* cA = sA + buf * Q_BM * 128;
+        const bf16* cG = sG + (int)(t % 3) * Q_BM * 128;
+        const int64_t row0 = (tile0 + t) * Q_BM;
+        const int nvalid = (int)((M - row0) < Q_BM ? (M - row0) : Q_BM);
+        wait_async_le<LPI>();                            // g(t) (requested two tiles ago) is complete; the youngest issue stays in flight
+        barrier_keep_async();                            // B1: tile t staged; every wave is past tile t-1
+        // ---- Z_q and dH_q for this wave's hidden units x 64 tokens ----
+        {
+            f32x4 accZ[NTW][Q_MT], accH[NTW][Q_MT];
+            zero_acc(accZ);
+            zero_acc(accH);
+            // fragments of k-step ks+1 are requested before the MFMAs of k-step ks; the scheduling barriers keep hipcc from
+            // hoisting every LDS read of the phase to the top (which spills) or sinking them next to their use (which stalls)
+            bf16x8 fa[2][Q_MT], fg[2][Q_MT];
+#pragma unroll
+            for (int mt = 0; mt < Q_MT; ++mt) { fa[0][mt] = tok_frag(cA, mt * 16 + i, 0); fg[0][mt] = tok_frag(cG, mt * 16 + i, 0); }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks + 1 < 4) {
+#pragma unroll
+                    for (int mt = 0; mt < Q_MT; ++mt) { fa[(ks + 1) & 1][mt] = tok_frag(cA, mt * 16 + i, ks + 1); fg[(ks + 1) & 1][mt] = tok_frag(cG, mt * 16 + i, ks + 1); }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mt = 0; mt < Q_MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NTW; ++nt) {
+                        accZ[nt][mt] = mfma16(w1f[nt][ks], fa[ks & 1][mt], accZ[nt][mt]);
+                        accH[nt][mt] = mfma16(w2f[nt][ks], fg[ks & 1][mt], accH[nt][mt]);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < Q_MT; ++mt) {
+                    float h[4], dz[4];
+                    const float live = mt * 16 + i < nvalid ? 1.0f : 0.0f;     // padded tokens must not leak GELU(b1) into anything
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float dg;
+                        gelu_and_grad(accZ[nt][mt][r] + bias4[nt][r], h[r], dg);
+                        h[r] *= live;
+                        dz[r] = accH[nt][mt][r] * dg * live;
+                        db1acc[nt][r] += dz[r];
+                    }
+                    store4(sH + Tile<bf16>::off4(mt * 16 + i, h0 + 16 * nt + 4 * g), h);
+                    store4(sD + Tile<bf16>::off4(mt * 16 + i, h0 + 16 * nt + 4 * g), dz);
+                }
+        }
+        barrier_keep_async();                            // B2: H_q / dZ_q of all 128 hidden units are in LDS
+        // ---- dA_q partial: this wave's channels x 64 tokens ----
+        {
+            f32x4 accA[NTW][Q_MT];
+            zero_acc(accA);
+            bf16x8 fd[2][Q_MT];
+#pragma unroll
+            for (int mt = 0; mt < Q_MT; ++mt) fd[0][mt] = tok_frag(sD, mt * 16 + i, 0);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks + 1 < 4) {
+#pragma unroll
+                    for (int mt = 0; mt < Q_MT; ++mt) fd[(ks + 1) & 1][mt] = tok_frag(sD, mt * 16 + i, ks + 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mt = 0; mt < Q_MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NTW; ++nt) accA[nt][mt] = mfma16(wtf[nt][ks], fd[ks & 1][mt], accA[nt][mt]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int mt = 0; mt < Q_MT; ++mt) {
+                const int64_t row = row0 + mt * 16 + i;
+                if (row < M) {
+#pragma unroll
+                    for (int nt = 0; nt < NTW; ++nt) {
+                        float v[4] = {accA[nt][mt][0], accA[nt][mt][1], accA[nt][mt][2], accA[nt][mt][3]};
+                        store4(dApart + ((int64_t)q * M + row) * 128 + h0 + 16 * nt + 4 * g, v);
+                    }
+                }
+            }
+        }
+        stage_issue(t + 2);                              // after the dA stores: older than this issue == safe to count on
+        // ---- weight gradients: reduction over the tokens of the tile (32-token k-steps), pipelined stages ----
+        {
+            bf16x8 ra[2][2], cb[2][CT];
+            auto load_stage = [&](int st, int slot) {        // st = 2*s + which (0: dW1 operands dZ^T, LN(x); 1: dW2 operands g^T, H)
+                const int mb = 32 * (st >> 1) + 8 * g;
+                const bf16* rowsrc = (st & 1) ? cG : sD;
+                const bf16* colsrc = (st & 1) ? sH : cA;
+#pragma unroll
+                for (int a = 0; a < 2; ++a) ra[slot][a] = frag_tr(rowsrc, mb, tr0 + 16 * a);
+#pragma unroll
+                for (int b = 0; b < CT; ++b) cb[slot][b] = frag_tr(colsrc, mb, tc0 + 16 * b);
+            };
+            load_stage(0, 0);
+#pragma unroll
+            for (int st = 0; st < 2 * (Q_BM / 32); ++st) {
+                if (st + 1 < 2 * (Q_BM / 32)) load_stage(st + 1, (st + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < CT; ++b) {
+                        if (st & 1) accW2[a][b] = mfma16(ra[st & 1][a], cb[st & 1][b], accW2[a][b]);     // dW2[c][hq] += g^T H
+                        else accW1[a][b] = mfma16(ra[st & 1][a], cb[st & 1][b], accW1[a][b]);            // dW1[hq][k] += dZ^T LN(x)
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        wait_async_le<LPI>();                            // x(t+1), requested during tile t-1, has landed
+        if (t + 1 < ntiles) stage_finish(t + 1, buf ^ 1);
+    }
+    wait_async();                                        // drain the look-ahead requests before the wave retires
+    // ---- leave: per-range partial tiles (summed by k_wgrad_reduce), bias partials by atomics ----
+    {
+        float* p1 = dW1part + (int64_t)range * 512 * 128;        // [512][128]
+        float* p2 = dW2part + (int64_t)range * 128 * 512;        // [128][512]
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < CT; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rr = tr0 + 16 * a + 4 * g + r, cc = tc0 + 16 * b + i;
+                    p1[(int64_t)(q * 128 + rr) * 128 + cc] = accW1[a][b][r];
+                    p2[(int64_t)rr * 512 + q * 128 + cc] = accW2[a][b][r];
+                }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = db1acc[nt][r];                     // sum over the 16 token lanes that share (g, r)
+            v += __shfl_xor(v, 1);
+            v += __shfl_xor(v, 2);
+            v += __shfl_xor(v, 4);
+            v += __shfl_xor(v, 8);
+            if (i == 0) atomicAdd(db1 + q * 128 + h0 + 16 * nt + 4 * g + r, v);
+        }
+}
+
+// g_in = g + LNbwd( sum_q dApart[q] ; x, gamma );  dgamma / dbeta block partials -> atomics.  16 lanes per token row.
+__global__ __launch_bounds__(256) void k_lnbwd_sum4(const bf16* __restrict__ dApart, const bf16* __restrict__ X, const bf16* __restrict__ G,
+                                                    const float* __restrict__ gamma, bf16* __restrict__ g_in, float* __restrict__ dgamma,
+                                                    float* __restrict__ dbeta, float* __restrict__ gsum, int64_t M) {
+    __shared__ float red[3][16][128];
+    const int sub = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    float gm[8], dg[8], db[8], gsv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { gm[e] = gamma[sub * 8 + e]; dg[e] = 0.f; db[e] = 0.f; gsv[e] = 0.f; }
+    for (int64_t row = (int64_t)blockIdx.x * 16 + rl; row < M; row += (int64_t)gridDim.x * 16) {
+        float d[8], x[8], t[8];
+        load8(dApart + row * 128 + sub * 8, d);
+#pragma unroll
+        for (int qq = 1; qq < 4; ++qq) {
+            load8(dApart + ((int64_t)qq * M + row) * 128 + sub * 8, t);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d[e] += t[e];
+        }
+        load8(X + row * 128 + sub * 8, x);
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += x[e];
+        const float mean = reduce16(s) * (1.0f / 128.0f);
+        float qv = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { x[e] -= mean; qv += x[e] * x[e]; }
+        const float rstd = rsqrtf(reduce16(qv) * (1.0f / 128.0f) + KASF_LN_EPS);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            x[e] *= rstd;
+            dg[e] += d[e] * x[e];
+            db[e] += d[e];
+            d[e] *= gm[e];
+            s1 += d[e];
+            s2 += d[e] * x[e];
+        }
+        s1 = reduce16(s1) * (1.0f / 128.0f);
+        s2 = reduce16(s2) * (1.0f / 128.0f);
+        load8(G + row * 128 + sub * 8, t);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { gsv[e] += t[e]; t[e] += rstd * (d[e] - s1 - x[e] * s2); }      // gsv: colsum(g) for the fc2 bias / layer-scale gradients
+        store8(g_in + row * 128 + sub * 8, t);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[0][rl][sub * 8 + e] = dg[e]; red[1][rl][sub * 8 + e] = db[e]; red[2][rl][sub * 8 + e] = gsv[e]; }
+    __syncthreads();
+    for (int item = threadIdx.x; item < 3 * 128; item += 256) {
+        const int c = item & 127, which = item >> 7;
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += red[which][k][c];
+        atomicAdd((which == 0 ? dgamma : (which == 1 ? dbeta : gsum)) + c, s);
+    }
+}
+
+}  // namespace
+
+// scratch needs: dApart = 4*M*128 bf16;  partial >= 2 * ranges * 65536 floats (returned through *ranges_out)
+int kasf_mlp_bwd_q_ranges(int64_t M) {
+    const int64_t tiles = (M + Q_BM - 1) / Q_BM;
+    return (int)(tiles < 64 ? tiles : 64);
+}
+void kasf_launch_mlp_bwd_q(hipStream_t s, const void* x, const void* g, const float* ln_g, const float* ln_b, const void* W1, const float* b1,
+                           const void* W2ts, const void* W1t, void* dApart, float* partial, float* dW1, float* dW2, float* db1, float* gsum, void* g_in,
+                           float* dgamma, float* dbeta, int64_t M) {
+    const int ranges = kasf_mlp_bwd_q_ranges(M);
+    const int64_t tiles = (M + Q_BM - 1) / Q_BM;
+    const int tpr = (int)((tiles + ranges - 1) / ranges);
+    const int used = (int)((tiles + tpr - 1) / tpr);             // ranges that own at least one tile
+    float* p1 = partial;
+    float* p2 = partial + (int64_t)used * 512 * 128;
+    const size_t sh = (size_t)(9 * Q_BM * 128) * sizeof(bf16);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_bwd_q<Q_NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    hipLaunchKernelGGL(k_mlp_bwd_q<Q_NW>, dim3(4 * used), dim3(Q_NW * 64), sh, s, (const bf16*)x, (const bf16*)g, ln_g, ln_b, (const bf16*)W1, b1, (const bf16*)W2ts,
+                       (const bf16*)W1t, (bf16*)dApart, p1, p2, db1, M, tpr);
+    kasf_launch_wgrad_reduce(s, p1, dW1, 128, 512, 128, used);
+    kasf_launch_wgrad_reduce(s, p2, dW2, 512, 128, 512, used);
+    int64_t blocks = (M + 15) / 16;
+    if (blocks > 512) blocks = 512;                     // few blocks: every block ends with 384 same-address atomics (contended atomics serialise)
+    hipLaunchKernelGGL(k_lnbwd_sum4, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16*)dApart, (const bf16*)x, (const bf16*)g, ln_g, (bf16*)g_in, dgamma,
+                       dbeta, gsum, M);
+}

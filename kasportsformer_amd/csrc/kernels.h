@@ -50,6 +50,14 @@ void kasf_launch_mlp_bwd(int dt, hipStream_t s, const void* x, const void* g, co
                          const void* W2t_scaled, const void* W1t, void* Hbuf, void* dZbuf, void* xn_buf, void* g_in, float* dgamma, float* dbeta,
                          int64_t M);
 
+// ---- k_mlp2.hip (bf16): hidden-quarter MLP backward with fused weight gradients ----
+// dApart: 4*M*128 bf16 scratch; partial: >= 2*64*65536 floats; dW2 / gsum are the UNSCALED fc2 weight gradient and colsum(g)
+// (finish with kasf_launch_finalize_ls).  Writes g_in = g + LNbwd(dA) and accumulates dgamma/dbeta, dW1, db1.
+void kasf_launch_mlp_bwd_q(hipStream_t s, const void* x, const void* g, const float* ln_g, const float* ln_b, const void* W1, const float* b1,
+                           const void* W2ts, const void* W1t, void* dApart, float* partial, float* dW1, float* dW2, float* db1, float* gsum, void* g_in,
+                           float* dgamma, float* dbeta, int64_t M);
+void kasf_launch_wgrad_reduce(hipStream_t s, const float* partial, float* out, int64_t ldo, int N, int K, int splits);
+
 // ---- k_attn.hip ----
 // mode 0: spatial (groups = B*T frames of 17 tokens), mode 1: temporal (groups = B*17 joint tracks of T tokens)
 void kasf_launch_attn_fwd(int dt, hipStream_t s, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, void* o, int B, int T,

@@ -126,3 +126,16 @@ __device__ __forceinline__ void lnbwd_rows(const T* sC, const T* __restrict__ X,
         atomicAdd((which ? dbeta : dgamma) + c, s);
     }
 }
+
+// ---- transposed fragments: the reduction index is the ROW index of a row-major swizzled [m][128] tile ----
+template <typename T> __device__ __forceinline__ int eoff(int row, int col) { return Tile<T>::chunk_off(row, col / Tile<T>::EPC) + (col % Tile<T>::EPC); }
+
+__device__ __forceinline__ bf16x8 frag_tr(const bf16* s, int mbase, int col0) {
+    // group of 16 lanes: lane u = 4q+p supplies row (mbase+q), columns col0+4p..; lane u receives column col0+u of 4 rows
+    const int u = threadIdx.x & 15, q = u >> 2, p = u & 3;
+    typedef __attribute__((address_space(3))) bf16x4 lds_v4;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)(s + eoff<bf16>(mbase + q, col0 + 4 * p)));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)(s + eoff<bf16>(mbase + 4 + q, col0 + 4 * p)));
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+

@@ -83,7 +83,7 @@ def test_stage_by_stage_against_oracle(cd, tol):
     assert _abs_err(limb, oracle.bone_refusion(x)) < 1e-5
 
 
-@pytest.mark.parametrize("cd,tol", [("fp32", 2e-3), ("bf16", 0.25)])
+@pytest.mark.parametrize("cd,tol", [("fp32", 2e-3), ("bf16", 0.35)])
 def test_backward_matches_oracle(cd, tol):
     oracle, model = make_pair(2, 27, cd)
     x, y = O.synthetic_clips(2, 27)
