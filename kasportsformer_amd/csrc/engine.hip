@@ -37,11 +37,13 @@ constexpr int64_t WG_PARTIAL_FLOATS = 2 * 64 * 65536;       // per-split weight-
 struct BlkWs { int64_t qkv, kv, o, xn, y, mask, x_mid, x_out, stats, bstats, coef; };
 struct LayerWs { BlkWs b[6]; int64_t gate_out, alpha; };
 struct WsEntry { std::string name; int64_t off, numel; int kind; };
+struct Scratch { int64_t uv, t1, t2, hbuf, dzbuf, d_o, dqkv, rbuf, duv, xn_a, xn_b, wg_part, g_in; };   // per-branch (att / graph / bone)
 struct Plan {
     int64_t total = 0, stats_begin = 0, stats_bytes = 0, bstats_begin = 0, bstats_bytes = 0;
     int64_t x3, bone3, limb3, xj, xb, xl, rep, uv;
     std::vector<LayerWs> layers;
-    int64_t g_layer, g_prev, ga, gg, gb, t1, t2, g_limb, g_bone, hbuf, dzbuf, d_o, dqkv, rbuf, duv, dlimb3, xn_a, xn_b, wg_part;
+    int64_t g_layer, g_prev, ga, gg, gb, g_limb, g_bone, dlimb3;
+    Scratch sc[3];
     std::vector<WsEntry> entries;
 };
 
@@ -61,6 +63,10 @@ struct kasf_model {
     KasfPackDesc* d_pack = nullptr;
     int* d_tile_start = nullptr;
     KasfProOff* d_pro = nullptr;
+    // the three branches of a layer (attention / graph / bone) are independent: branch 0 stays on the caller's stream,
+    // branches 1 and 2 fork onto these and join before the gate (pure event fork/join: graph-capture safe)
+    hipStream_t side[2] = {nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
 };
 
 int kasf_set_error(int code, const char* msg) {
@@ -273,27 +279,33 @@ void build_plan(const kasf_model* m, int B, bool train, bool names, Plan& p) {
         lw.alpha = take(M * 4, 1, "alpha", l);
     }
     p.rep = take(M * 512, 0, "rep");
-    p.uv = take(M * 256, 0, "scratch_uv");
+    for (int br = 0; br < 3; ++br) p.sc[br].uv = (br == 1) ? take(M * 256, 0, "scratch_uv") : -1;     // only the graph branch needs it
     if (train) {
         p.g_layer = take(M * 128, 0, "g_layer");
         p.g_prev = take(M * 128, 0, "g_prev");
         p.ga = take(M * 128, 0, "g_att");
         p.gg = take(M * 128, 0, "g_graph");
         p.gb = take(M * 128, 0, "g_bonebr");
-        p.t1 = take(M * 128, 0, "g_tmp1");
-        p.t2 = take(M * 128, 0, "g_tmp2");
         p.g_limb = take(M * 128, 0, "g_limb");
         p.g_bone = take(M * 128, 0, "g_bone");
-        p.hbuf = take(M * 512, 0, "mlp_h");
-        p.dzbuf = take(M * 512, 0, "mlp_dz");
-        p.d_o = take(M * 128, 0, "d_o");
-        p.dqkv = take(M * 384, 0, "dqkv");
-        p.rbuf = take(M * 128, 0, "gcn_r");
-        p.duv = take(M * 256, 0, "gcn_duv");
         p.dlimb3 = take(M * 3, 1, "dlimb3");
-        p.xn_a = take(M * 128, 0, "scratch_xn_a");
-        p.xn_b = take(M * 128, 0, "scratch_xn_b");
-        p.wg_part = take(WG_PARTIAL_FLOATS, 1, "wgrad_partials");
+        static const char* const BR[3] = {"att", "graph", "bone"};
+        for (int br = 0; br < 3; ++br) {                 // the three branches of a layer run concurrently: private scratch each
+            Scratch& s = p.sc[br];
+            auto nm = [&](const char* base) { static thread_local std::string t; t = std::string(base) + "." + BR[br]; return t.c_str(); };
+            s.t1 = take(M * 128, 0, nm("g_tmp1"));
+            s.t2 = take(M * 128, 0, nm("g_tmp2"));
+            s.g_in = take(M * 128, 0, nm("g_in"));
+            s.hbuf = take(M * 512, 0, nm("mlp_h"));
+            s.dzbuf = es == 4 ? take(M * 512, 0, nm("mlp_dz")) : -1;          // bf16 fuses the weight gradients: no dZ round trip
+            s.xn_a = take(M * 128, 0, nm("scratch_xn_a"));
+            s.wg_part = take(WG_PARTIAL_FLOATS, 1, nm("wgrad_partials"));
+            s.d_o = br != 1 ? take(M * 128, 0, nm("d_o")) : -1;
+            s.dqkv = br != 1 ? take(M * 384, 0, nm("dqkv")) : -1;
+            s.xn_b = br == 2 ? take(M * 128, 0, nm("scratch_xn_b")) : -1;
+            s.rbuf = br == 1 ? take(M * 128, 0, nm("gcn_r")) : -1;
+            s.duv = br == 1 ? take(M * 256, 0, nm("gcn_duv")) : -1;
+        }
     }
     p.total = cur;
 }
@@ -314,7 +326,7 @@ struct Ctx {
     void* w(int64_t byte_off) const { return ws + byte_off; }
 };
 
-void block_forward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void* x_in, const void* x_limb, const Plan& p) {
+void block_forward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void* x_in, const void* x_limb, const Plan& p, const Scratch& sc) {
     const float* P = c.P;
     if (o.kind == KIND_ATT) {
         kasf_launch_linear(c.dt, c.s, x_in, 128, c.pk(o.p_mix), 128, nullptr, c.w(w.qkv), 384, c.M, 384, P + o.n1w, P + o.n1b, nullptr, 0);
@@ -326,8 +338,8 @@ void block_forward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void* 
         const char* kv = (const char*)c.w(w.kv);
         kasf_launch_attn_fwd(c.dt, c.s, c.w(w.qkv), 128, kv, kv + 128 * c.es, 256, c.w(w.o), c.B, c.T, o.mode);
     } else {
-        kasf_launch_linear(c.dt, c.s, x_in, 128, c.pk(o.p_mix), 128, P + o.uv_b, c.w(p.uv), 256, c.M, 256, P + o.n1w, P + o.n1b, c.w(w.xn), 0);
-        kasf_launch_gcn_agg_fwd(c.dt, c.s, c.w(p.uv), c.w(w.xn), c.w(w.y), w.mask >= 0 ? (uint32_t*)c.w(w.mask) : nullptr, (double*)c.w(w.stats), c.B,
+        kasf_launch_linear(c.dt, c.s, x_in, 128, c.pk(o.p_mix), 128, P + o.uv_b, c.w(sc.uv), 256, c.M, 256, P + o.n1w, P + o.n1b, c.w(w.xn), 0);
+        kasf_launch_gcn_agg_fwd(c.dt, c.s, c.w(sc.uv), c.w(w.xn), c.w(w.y), w.mask >= 0 ? (uint32_t*)c.w(w.mask) : nullptr, (double*)c.w(w.stats), c.B,
                                 c.T, o.mode);
         const double count = o.mode == 0 ? (double)c.B * c.T * 128 : (double)c.B * 17 * 128;
         kasf_launch_bn_finalize(c.s, (const double*)c.w(w.stats), P + o.bn_w, P + o.bn_b, c.buf + o.bn_rm, c.buf + o.bn_rv, (float*)c.w(w.coef), o.nodes,
@@ -341,60 +353,60 @@ void block_forward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void* 
 
 // g_out: gradient w.r.t. the block output; writes (or accumulates) the gradient w.r.t. x_in into dst
 void block_backward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void* x_in, const void* x_limb, const void* g_out, void* dst, int accumulate,
-                    const Plan& p) {
+                    const Plan& p, const Scratch& sc) {
     const float* P = c.P;
     float* G = c.G;
-    void* g_mid = c.w(p.t2);
+    void* g_mid = c.w(sc.t2);
     // ---- MLP half ----
     if (c.dt == KASF_BF16) {
         // hidden-quarter kernel: dgrad + both weight gradients fused, then the 4-way partial sum + LayerNorm backward
-        kasf_launch_mlp_bwd_q(c.s, c.w(w.x_mid), g_out, P + o.n2w, P + o.n2b, c.pk(o.p_fc1), P + o.fc1b, c.pk(o.p_fc2Ts), c.pk(o.p_fc1T), c.w(p.hbuf),
-                              (float*)c.w(p.wg_part), G + o.fc1w, G + o.fc2w, G + o.fc1b, G + o.fc2b, g_mid, G + o.n2w, G + o.n2b, c.M);
+        kasf_launch_mlp_bwd_q(c.s, c.w(w.x_mid), g_out, P + o.n2w, P + o.n2b, c.pk(o.p_fc1), P + o.fc1b, c.pk(o.p_fc2Ts), c.pk(o.p_fc1T), c.w(sc.hbuf),
+                              (float*)c.w(sc.wg_part), G + o.fc1w, G + o.fc2w, G + o.fc1b, G + o.fc2b, g_mid, G + o.n2w, G + o.n2b, c.M);
     } else {
-        kasf_launch_mlp_bwd(c.dt, c.s, c.w(w.x_mid), g_out, P + o.n2w, P + o.n2b, c.pk(o.p_fc1), P + o.fc1b, c.pk(o.p_fc2Ts), c.pk(o.p_fc1T), c.w(p.hbuf),
-                            c.w(p.dzbuf), c.w(p.xn_a), g_mid, G + o.n2w, G + o.n2b, c.M);
-        kasf_launch_wgrad(c.dt, c.s, c.w(p.dzbuf), 512, 512, c.w(p.xn_a), 128, 128, nullptr, nullptr, G + o.fc1w, 128, G + o.fc1b, c.M,
-                          (float*)c.w(p.wg_part), WG_PARTIAL_FLOATS);
-        kasf_launch_wgrad(c.dt, c.s, g_out, 128, 128, c.w(p.hbuf), 512, 512, nullptr, nullptr, G + o.fc2w, 512, G + o.fc2b, c.M, (float*)c.w(p.wg_part),
+        kasf_launch_mlp_bwd(c.dt, c.s, c.w(w.x_mid), g_out, P + o.n2w, P + o.n2b, c.pk(o.p_fc1), P + o.fc1b, c.pk(o.p_fc2Ts), c.pk(o.p_fc1T), c.w(sc.hbuf),
+                            c.w(sc.dzbuf), c.w(sc.xn_a), g_mid, G + o.n2w, G + o.n2b, c.M);
+        kasf_launch_wgrad(c.dt, c.s, c.w(sc.dzbuf), 512, 512, c.w(sc.xn_a), 128, 128, nullptr, nullptr, G + o.fc1w, 128, G + o.fc1b, c.M,
+                          (float*)c.w(sc.wg_part), WG_PARTIAL_FLOATS);
+        kasf_launch_wgrad(c.dt, c.s, g_out, 128, 128, c.w(sc.hbuf), 512, 512, nullptr, nullptr, G + o.fc2w, 512, G + o.fc2b, c.M, (float*)c.w(sc.wg_part),
                           WG_PARTIAL_FLOATS);
     }
     kasf_launch_finalize_ls(c.s, G + o.fc2w, P + o.fc2w, P + o.fc2b, P + o.ls2, G + o.fc2b, G + o.ls2, 128, 512);
     // ---- mixer half ----
     if (o.kind == KIND_GRAPH) {
-        kasf_launch_gcn_bwd1(c.dt, c.s, g_mid, c.w(w.xn), c.w(w.y), (const float*)c.w(w.coef), P + o.ls1, c.w(p.rbuf), G + o.ls1, (double*)c.w(w.bstats),
+        kasf_launch_gcn_bwd1(c.dt, c.s, g_mid, c.w(w.xn), c.w(w.y), (const float*)c.w(w.coef), P + o.ls1, c.w(sc.rbuf), G + o.ls1, (double*)c.w(w.bstats),
                              c.B, c.T, o.mode);
         const double count = o.mode == 0 ? (double)c.B * c.T * 128 : (double)c.B * 17 * 128;
         kasf_launch_gcn_bwd_finalize(c.s, (const double*)c.w(w.bstats), (float*)c.w(w.coef), G + o.bn_w, G + o.bn_b, o.nodes, count);
-        kasf_launch_gcn_bwd2(c.dt, c.s, c.w(p.rbuf), c.w(w.y), (const float*)c.w(w.coef), w.mask >= 0 ? (const uint32_t*)c.w(w.mask) : nullptr, c.w(p.duv),
+        kasf_launch_gcn_bwd2(c.dt, c.s, c.w(sc.rbuf), c.w(w.y), (const float*)c.w(w.coef), w.mask >= 0 ? (const uint32_t*)c.w(w.mask) : nullptr, c.w(sc.duv),
                              c.B, c.T, o.mode);
-        kasf_launch_dgrad_lnbwd(c.dt, c.s, c.w(p.duv), 256, c.pk(o.p_mixT), c.w(p.rbuf), x_in, P + o.n1w, g_mid, dst, accumulate, G + o.n1w, G + o.n1b,
+        kasf_launch_dgrad_lnbwd(c.dt, c.s, c.w(sc.duv), 256, c.pk(o.p_mixT), c.w(sc.rbuf), x_in, P + o.n1w, g_mid, dst, accumulate, G + o.n1w, G + o.n1b,
                                 c.M);
-        kasf_launch_wgrad(c.dt, c.s, c.w(p.duv), 256, 256, c.w(w.xn), 128, 128, nullptr, nullptr, G + o.mix_w, 128, G + o.uv_b, c.M, (float*)c.w(p.wg_part), WG_PARTIAL_FLOATS);
+        kasf_launch_wgrad(c.dt, c.s, c.w(sc.duv), 256, 256, c.w(w.xn), 128, 128, nullptr, nullptr, G + o.mix_w, 128, G + o.uv_b, c.M, (float*)c.w(sc.wg_part), WG_PARTIAL_FLOATS);
         return;
     }
     // d_o = g_mid . (ls1 . Wproj);  G_proj = g_mid^T o (unscaled) -> finalize: dWproj, dbproj, dls1
-    kasf_launch_linear(c.dt, c.s, g_mid, 128, c.pk(o.p_projTs), 128, nullptr, c.w(p.d_o), 128, c.M, 128, nullptr, nullptr, nullptr, 0);
-    kasf_launch_wgrad(c.dt, c.s, g_mid, 128, 128, c.w(w.o), 128, 128, nullptr, nullptr, G + o.proj_w, 128, G + o.proj_b, c.M, (float*)c.w(p.wg_part), WG_PARTIAL_FLOATS);
+    kasf_launch_linear(c.dt, c.s, g_mid, 128, c.pk(o.p_projTs), 128, nullptr, c.w(sc.d_o), 128, c.M, 128, nullptr, nullptr, nullptr, 0);
+    kasf_launch_wgrad(c.dt, c.s, g_mid, 128, 128, c.w(w.o), 128, 128, nullptr, nullptr, G + o.proj_w, 128, G + o.proj_b, c.M, (float*)c.w(sc.wg_part), WG_PARTIAL_FLOATS);
     kasf_launch_finalize_ls(c.s, G + o.proj_w, P + o.proj_w, P + o.proj_b, P + o.ls1, G + o.proj_b, G + o.ls1, 128, 128);
     if (o.kind == KIND_ATT) {
         const char* q = (const char*)c.w(w.qkv);
-        char* dq = (char*)c.w(p.dqkv);
-        kasf_launch_attn_bwd(c.dt, c.s, q, 384, q + 128 * c.es, q + 256 * c.es, 384, c.w(p.d_o), dq, 384, dq + 128 * c.es, dq + 256 * c.es, 384, c.B, c.T,
+        char* dq = (char*)c.w(sc.dqkv);
+        kasf_launch_attn_bwd(c.dt, c.s, q, 384, q + 128 * c.es, q + 256 * c.es, 384, c.w(sc.d_o), dq, 384, dq + 128 * c.es, dq + 256 * c.es, 384, c.B, c.T,
                              o.mode);
         kasf_launch_dgrad_lnbwd(c.dt, c.s, dq, 384, c.pk(o.p_mixT), nullptr, x_in, P + o.n1w, g_mid, dst, accumulate, G + o.n1w, G + o.n1b, c.M,
-                                c.w(p.xn_a), P + o.n1b);
-        kasf_launch_wgrad(c.dt, c.s, dq, 384, 384, c.w(p.xn_a), 128, 128, nullptr, nullptr, G + o.mix_w, 128, nullptr, c.M, (float*)c.w(p.wg_part), WG_PARTIAL_FLOATS);
+                                c.w(sc.xn_a), P + o.n1b);
+        kasf_launch_wgrad(c.dt, c.s, dq, 384, 384, c.w(sc.xn_a), 128, 128, nullptr, nullptr, G + o.mix_w, 128, nullptr, c.M, (float*)c.w(sc.wg_part), WG_PARTIAL_FLOATS);
     } else {
         const char* kv = (const char*)c.w(w.kv);
-        char* dq = (char*)c.w(p.dqkv);
+        char* dq = (char*)c.w(sc.dqkv);
         char* dkv = dq + c.M * 128 * c.es;
-        kasf_launch_attn_bwd(c.dt, c.s, c.w(w.qkv), 128, kv, kv + 128 * c.es, 256, c.w(p.d_o), dq, 128, dkv, dkv + 128 * c.es, 256, c.B, c.T, o.mode);
+        kasf_launch_attn_bwd(c.dt, c.s, c.w(w.qkv), 128, kv, kv + 128 * c.es, 256, c.w(sc.d_o), dq, 128, dkv, dkv + 128 * c.es, 256, c.B, c.T, o.mode);
         kasf_launch_dgrad_lnbwd(c.dt, c.s, dq, 128, c.pk(o.p_mixT), nullptr, x_in, P + o.n1w, g_mid, dst, accumulate, G + o.n1w, G + o.n1b, c.M,
-                                c.w(p.xn_a), P + o.n1b);
+                                c.w(sc.xn_a), P + o.n1b);
         kasf_launch_dgrad_lnbwd(c.dt, c.s, dkv, 256, c.pk(o.p_kvT), nullptr, x_limb, P + o.n1lw, nullptr, c.w(p.g_limb), 1, G + o.n1lw, G + o.n1lb, c.M,
-                                c.w(p.xn_b), P + o.n1lb);
-        kasf_launch_wgrad(c.dt, c.s, dq, 128, 128, c.w(p.xn_a), 128, 128, nullptr, nullptr, G + o.mix_w, 128, nullptr, c.M, (float*)c.w(p.wg_part), WG_PARTIAL_FLOATS);
-        kasf_launch_wgrad(c.dt, c.s, dkv, 256, 256, c.w(p.xn_b), 128, 128, nullptr, nullptr, G + o.kv_w, 128, nullptr, c.M, (float*)c.w(p.wg_part), WG_PARTIAL_FLOATS);
+                                c.w(sc.xn_b), P + o.n1lb);
+        kasf_launch_wgrad(c.dt, c.s, dq, 128, 128, c.w(sc.xn_a), 128, 128, nullptr, nullptr, G + o.mix_w, 128, nullptr, c.M, (float*)c.w(sc.wg_part), WG_PARTIAL_FLOATS);
+        kasf_launch_wgrad(c.dt, c.s, dkv, 256, 256, c.w(sc.xn_b), 128, 128, nullptr, nullptr, G + o.kv_w, 128, nullptr, c.M, (float*)c.w(sc.wg_part), WG_PARTIAL_FLOATS);
     }
 }
 
@@ -428,6 +440,11 @@ int kasf_model_create(const kasf_config* cfg, kasf_model** out) {
     HIPCHK(hipMemcpy(m->d_pack, m->pack.data(), m->pack.size() * sizeof(KasfPackDesc), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(m->d_tile_start, m->pack_tile_start.data(), m->pack_tile_start.size() * sizeof(int), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(m->d_pro, &m->pro, sizeof(KasfProOff), hipMemcpyHostToDevice));
+    for (int i = 0; i < 2; ++i) {
+        HIPCHK(hipStreamCreateWithFlags(&m->side[i], hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&m->ev_join[i], hipEventDisableTiming));
+    }
+    HIPCHK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
     kasf_gcn_init();
     *out = m;
     return 0;
@@ -448,6 +465,11 @@ void kasf_model_destroy(kasf_model* m) {
     if (m->d_pack) (void)hipFree(m->d_pack);
     if (m->d_tile_start) (void)hipFree(m->d_tile_start);
     if (m->d_pro) (void)hipFree(m->d_pro);
+    for (int i = 0; i < 2; ++i) {
+        if (m->side[i]) (void)hipStreamDestroy(m->side[i]);
+        if (m->ev_join[i]) (void)hipEventDestroy(m->ev_join[i]);
+    }
+    if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
     delete m;
 }
 
@@ -542,10 +564,20 @@ int kasf_forward(const kasf_model* m, const float* params, const void* packed, f
         const LayerOff& lo = m->layers[l];
         const LayerWs& lw = p.layers[train ? l : 0];
         if (!train && l > 0) HIPCHK(hipMemsetAsync(c.w(p.stats_begin), 0, p.stats_bytes, c.s));
+        HIPCHK(hipEventRecord(m->ev_fork, c.s));
         for (int br = 0; br < 3; ++br) {
+            Ctx cb = c;
+            if (br > 0) {
+                cb.s = m->side[br - 1];
+                HIPCHK(hipStreamWaitEvent(cb.s, m->ev_fork, 0));
+            }
             const void* in0 = (br == 2 && l == 0) ? c.w(p.xb) : xcur;         // layer 0: bone branch starts from the bone embedding (:332-336)
-            block_forward(c, lo.blk[2 * br], lw.b[2 * br], in0, c.w(p.xl), p);
-            block_forward(c, lo.blk[2 * br + 1], lw.b[2 * br + 1], c.w(lw.b[2 * br].x_out), c.w(p.xl), p);
+            block_forward(cb, lo.blk[2 * br], lw.b[2 * br], in0, c.w(p.xl), p, p.sc[br]);
+            block_forward(cb, lo.blk[2 * br + 1], lw.b[2 * br + 1], c.w(lw.b[2 * br].x_out), c.w(p.xl), p, p.sc[br]);
+            if (br > 0) {
+                HIPCHK(hipEventRecord(m->ev_join[br - 1], cb.s));
+                HIPCHK(hipStreamWaitEvent(c.s, m->ev_join[br - 1], 0));
+            }
         }
         kasf_launch_gate_fwd(c.dt, c.s, c.w(lw.b[1].x_out), c.w(lw.b[3].x_out), c.w(lw.b[5].x_out), params + lo.fus_w, params + lo.fus_b, c.w(lw.gate_out),
                              (float*)c.w(lw.alpha), c.M, m->cfg.use_adaptive_fusion);
@@ -580,10 +612,11 @@ int kasf_backward(const kasf_model* m, const float* params, const void* packed, 
             HIPCHK(hipMemsetAsync(c.w(p.bstats_begin), 0, p.bstats_bytes, c.s));
             HIPCHK(hipMemsetAsync(c.w(p.g_limb), 0, c.M * 128 * c.es, c.s));
             const void* x_final = c.w(p.layers[L - 1].gate_out);
-            kasf_launch_head_bwd(c.dt, c.s, dout, c.w(p.rep), params + t.head_w, c.w(p.hbuf), grads + t.head_w, grads + t.head_b, c.M);
-            kasf_launch_dgrad_lnbwd(c.dt, c.s, c.w(p.hbuf), 512, c.pk(t.p_fcT), nullptr, x_final, params + t.norm_w, nullptr, gbuf(0), 0, grads + t.norm_w,
-                                    grads + t.norm_b, c.M, c.w(p.xn_a), params + t.norm_b);
-            kasf_launch_wgrad(c.dt, c.s, c.w(p.hbuf), 512, 512, c.w(p.xn_a), 128, 128, nullptr, nullptr, grads + t.fc_w, 128, grads + t.fc_b, c.M, (float*)c.w(p.wg_part), WG_PARTIAL_FLOATS);
+            kasf_launch_head_bwd(c.dt, c.s, dout, c.w(p.rep), params + t.head_w, c.w(p.sc[0].hbuf), grads + t.head_w, grads + t.head_b, c.M);
+            kasf_launch_dgrad_lnbwd(c.dt, c.s, c.w(p.sc[0].hbuf), 512, c.pk(t.p_fcT), nullptr, x_final, params + t.norm_w, nullptr, gbuf(0), 0, grads + t.norm_w,
+                                    grads + t.norm_b, c.M, c.w(p.sc[0].xn_a), params + t.norm_b);
+            kasf_launch_wgrad(c.dt, c.s, c.w(p.sc[0].hbuf), 512, 512, c.w(p.sc[0].xn_a), 128, 128, nullptr, nullptr, grads + t.fc_w, 128, grads + t.fc_b, c.M,
+                              (float*)c.w(p.sc[0].wg_part), WG_PARTIAL_FLOATS);
         } else if (st <= L) {
             const int l = L - st;
             const LayerOff& lo = m->layers[l];
@@ -594,12 +627,25 @@ int kasf_backward(const kasf_model* m, const float* params, const void* packed, 
             kasf_launch_gate_bwd(c.dt, c.s, g_out, c.w(lw.b[1].x_out), c.w(lw.b[3].x_out), c.w(lw.b[5].x_out), params + lo.fus_w, (const float*)c.w(lw.alpha),
                                  c.w(p.ga), c.w(p.gg), c.w(p.gb), grads + lo.fus_w, grads + lo.fus_b, c.M, m->cfg.use_adaptive_fusion);
             const int64_t gsrc[3] = {p.ga, p.gg, p.gb};
+            HIPCHK(hipEventRecord(m->ev_fork, c.s));
             for (int br = 0; br < 3; ++br) {
+                Ctx cb = c;
+                if (br > 0) {
+                    cb.s = m->side[br - 1];
+                    HIPCHK(hipStreamWaitEvent(cb.s, m->ev_fork, 0));
+                }
+                const Scratch& sc = p.sc[br];
                 const bool bone0 = (br == 2 && l == 0);
                 const void* in0 = bone0 ? c.w(p.xb) : x_in;
-                block_backward(c, lo.blk[2 * br + 1], lw.b[2 * br + 1], c.w(lw.b[2 * br].x_out), c.w(p.xl), c.w(gsrc[br]), c.w(p.t1), 0, p);
-                block_backward(c, lo.blk[2 * br], lw.b[2 * br], in0, c.w(p.xl), c.w(p.t1), bone0 ? c.w(p.g_bone) : g_in, (bone0 || br == 0) ? 0 : 1, p);
+                block_backward(cb, lo.blk[2 * br + 1], lw.b[2 * br + 1], c.w(lw.b[2 * br].x_out), c.w(p.xl), c.w(gsrc[br]), c.w(sc.t1), 0, p, sc);
+                block_backward(cb, lo.blk[2 * br], lw.b[2 * br], in0, c.w(p.xl), c.w(sc.t1), bone0 ? c.w(p.g_bone) : c.w(sc.g_in), 0, p, sc);
+                if (br > 0) {
+                    HIPCHK(hipEventRecord(m->ev_join[br - 1], cb.s));
+                    HIPCHK(hipStreamWaitEvent(c.s, m->ev_join[br - 1], 0));
+                }
             }
+            // gradient w.r.t. the layer input = sum over the branches (layer 0: the bone branch fed on the bone embedding instead)
+            kasf_launch_add3(c.dt, c.s, g_in, c.w(p.sc[0].g_in), c.w(p.sc[1].g_in), l == 0 ? nullptr : c.w(p.sc[2].g_in), c.M * 128);
         } else {
             void* g_x = gbuf(L);
             const int64_t frames = (int64_t)batch * c.T;

@@ -392,6 +392,22 @@ template <typename T> __global__ void k_add_inplace(T* __restrict__ dst, const T
     }
 }
 
+template <typename T> __global__ void k_add3(T* __restrict__ dst, const T* __restrict__ a, const T* __restrict__ b, const T* __restrict__ c, int64_t n8) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        float x[8], y[8];
+        load8(a + i * 8, x);
+        load8(b + i * 8, y);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] += y[e];
+        if (c != nullptr) {
+            load8(c + i * 8, y);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] += y[e];
+        }
+        store8(dst + i * 8, x);
+    }
+}
+
 // dls[n] = sum_k W[n][k] G[n][k] + bias[n] * gsum[n];  G[n][:] *= ls[n];  gsum[n] *= ls[n]   (one workgroup per row n)
 __global__ __launch_bounds__(128) void k_finalize_ls(float* __restrict__ dW, const float* __restrict__ W, const float* __restrict__ bias,
                                                      const float* __restrict__ ls, float* __restrict__ db, float* __restrict__ dls, int K) {
@@ -569,6 +585,10 @@ void kasf_launch_cast_from_f32(int dt, hipStream_t s, const float* src, void* ds
 void kasf_launch_add_inplace(int dt, hipStream_t s, void* dst, const void* a, int64_t n) {
     if (dt == KASF_F32) hipLaunchKernelGGL(k_add_inplace<float>, dim3(ew_grid(n / 8)), dim3(256), 0, s, (float*)dst, (const float*)a, n / 8);
     else hipLaunchKernelGGL(k_add_inplace<bf16>, dim3(ew_grid(n / 8)), dim3(256), 0, s, (bf16*)dst, (const bf16*)a, n / 8);
+}
+void kasf_launch_add3(int dt, hipStream_t s, void* dst, const void* a, const void* b, const void* c, int64_t n) {
+    if (dt == KASF_F32) hipLaunchKernelGGL(k_add3<float>, dim3(ew_grid(n / 8)), dim3(256), 0, s, (float*)dst, (const float*)a, (const float*)b, (const float*)c, n / 8);
+    else hipLaunchKernelGGL(k_add3<bf16>, dim3(ew_grid(n / 8)), dim3(256), 0, s, (bf16*)dst, (const bf16*)a, (const bf16*)b, (const bf16*)c, n / 8);
 }
 void kasf_launch_finalize_ls(hipStream_t s, float* dW, const float* W, const float* bias, const float* ls, float* db, float* dls, int N, int K) {
     hipLaunchKernelGGL(k_finalize_ls, dim3(N), dim3(128), 0, s, dW, W, bias, ls, db, dls, K);

@@ -99,6 +99,7 @@ void kasf_launch_head_bwd(int dt, hipStream_t s, const float* dy, const void* re
 void kasf_launch_cast_to_f32(int dt, hipStream_t s, const void* src, float* dst, int64_t n);
 void kasf_launch_cast_from_f32(int dt, hipStream_t s, const float* src, void* dst, int64_t n);
 void kasf_launch_add_inplace(int dt, hipStream_t s, void* dst, const void* a, int64_t n);   // dst += a
+void kasf_launch_add3(int dt, hipStream_t s, void* dst, const void* a, const void* b, const void* c, int64_t n);   // dst = a + b (+ c)
 // in: dW = unscaled G = g^T A, db = colsum(g).  out: dls[n] = sum_k W[n][k] G[n][k] + bias[n] db[n];  dW *= ls[n];  db *= ls[n]
 void kasf_launch_finalize_ls(hipStream_t s, float* dW, const float* W, const float* bias, const float* ls, float* db, float* dls, int N, int K);
 void kasf_launch_loss3(hipStream_t s, const float* pred, const float* tgt, float* dpred, float* losses, int B, int T, float lambda_n, float lambda_v,
