@@ -74,7 +74,7 @@ __global__ __launch_bounds__(NTHR) void k_mlp_fwd(const T* __restrict__ X, const
         f32x4 acc1[4][MT];
         zero_acc(acc1);
         mma_k128<4, MT>(w1, wn0, sA, wm0, acc1);
-        acc_to_tile<T>(sH, acc1, wn0, wm0, [&](float v, int n) { return gelu_f(v + b1[hc * 128 + n]); });
+        acc_to_tile<T>(sH, acc1, wn0, wm0, [&](float v, int n) { return gelu_f<T>(v + b1[hc * 128 + n]); });
         ring.close(2 * hc);
         const T* w2 = ring.open(2 * hc + 1);            // barrier: sH complete, GEMM1 done with its tile
         mma_k128<4, MT>(w2, wn0, sH, wm0, acc2);
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(NTHR) void k_mlp_bwd(const T* __restrict__ X, const
                     for (int r = 0; r < 4; ++r) {
                         const float z = accZ[nt][mt][r] + b1[hc * 128 + n + r];
                         float dg;
-                        gelu_and_grad(z, h[r], dg);
+                        gelu_and_grad<T>(z, h[r], dg);
                         dz[r] = accH[nt][mt][r] * dg;
                     }
                     store4(sHs + Tile<T>::off4(m, n), h);
@@ -214,7 +214,7 @@ void mlp_bwd_T(hipStream_t s, const void* x, const void* g, const float* ln_g, c
 void kasf_launch_mlp_fwd(int dt, hipStream_t s, const void* x, const float* ln_g, const float* ln_b, const void* W1, const float* b1, const void* W2,
                          const float* b2, const float* ls2, void* out, int64_t M) {
     if (dt == KASF_F32) mlp_fwd_T<float>(s, x, ln_g, ln_b, W1, b1, W2, b2, ls2, out, M);
-    else mlp_fwd_T<bf16>(s, x, ln_g, ln_b, W1, b1, W2, b2, ls2, out, M);
+    else kasf_launch_mlp_fwd_r(s, x, ln_g, ln_b, W1, b1, W2, b2, ls2, out, M);      // first generation: mlp_fwd_T<bf16>
 }
 void kasf_launch_mlp_bwd(int dt, hipStream_t s, const void* x, const void* g, const float* ln_g, const float* ln_b, const void* W1, const float* b1,
                          const void* W2ts, const void* W1t, void* Hbuf, void* dZbuf, void* xn_buf, void* g_in, float* dgamma, float* dbeta,

@@ -176,7 +176,7 @@ __global__ __launch_bounds__(NW * 64) void k_mlp_bwd_q(const bf16* __restrict__ 
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float dg;
-                        gelu_and_grad(accZ[nt][mt][r] + bias4[nt][r], h[r], dg);
+                        gelu_and_grad<bf16>(accZ[nt][mt][r] + bias4[nt][r], h[r], dg);
                         h[r] *= live;
                         dz[r] = accH[nt][mt][r] * dg * live;
                         db1acc[nt][r] += dz[r];
@@ -334,6 +334,147 @@ __global__ __launch_bounds__(256) void k_lnbwd_sum4(const bf16* __restrict__ dAp
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// MLP forward, second generation (bf16): persistent workgroups, ALL weights resident in registers.
+//   wave w keeps W1 rows [64w, 64w+64) (GEMM1: its 64 hidden units) and W2 rows [16w, 16w+16) (GEMM2: its 16 output
+//   channels over all 512 hidden units): 2 x 64 VGPRs.  Per 32-token tile: LN(x) -> sA, GEMM1 + GELU -> sH (bf16,
+//   [32][512] as four swizzled [32][128] tiles), barrier, GEMM2 over the whole hidden axis, epilogue x + ls2 (y + b2)
+//   with x taken from the raw tile that is still in LDS.  Raw x tiles arrive by LDS-direct loads two tiles ahead.
+//   Nothing is streamed from L2 inside the loop and there are two barriers per tile.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int F_BM = 32, F_NW = 8, F_THR = F_NW * 64;
+
+__global__ __launch_bounds__(F_THR) void k_mlp_fwd_r(const bf16* __restrict__ X, const float* __restrict__ ln_g, const float* __restrict__ ln_b,
+                                                     const bf16* __restrict__ W1, const float* __restrict__ b1, const bf16* __restrict__ W2,
+                                                     const float* __restrict__ b2, const float* __restrict__ ls2, bf16* __restrict__ out, int64_t M) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* sA = reinterpret_cast<bf16*>(smem);            // [2][32][128]  LN(x)
+    bf16* sH = sA + 2 * F_BM * 128;                      // [4][32][128]  GELU output, hidden chunk major
+    bf16* sXr = sH + 4 * F_BM * 128;                     // [3][32][128]  raw x: in use / landed / in flight
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4, sub = lane & 15;
+    const int64_t ntiles_total = (M + F_BM - 1) / F_BM;
+    const int64_t per = (ntiles_total + gridDim.x - 1) / gridDim.x;
+    const int64_t tile0 = (int64_t)blockIdx.x * per;
+    int64_t ntiles = ntiles_total - tile0;
+    if (ntiles > per) ntiles = per;
+    if (ntiles <= 0) return;
+
+    bf16x8 w1f[4][4], w2f[16];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) w1f[nt][ks] = *reinterpret_cast<const bf16x8*>(W1 + (int64_t)(64 * w + 16 * nt + i) * 128 + 32 * ks + 8 * g);
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) w2f[ks] = *reinterpret_cast<const bf16x8*>(W2 + (int64_t)(16 * w + i) * 512 + 32 * ks + 8 * g);
+    f32x4 b1v[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) b1v[nt] = *reinterpret_cast<const f32x4*>(b1 + 64 * w + 16 * nt + 4 * g);
+    const f32x4 b2v = *reinterpret_cast<const f32x4*>(b2 + 16 * w + 4 * g), lsv = *reinterpret_cast<const f32x4*>(ls2 + 16 * w + 4 * g);
+
+    auto issue = [&](int64_t t) {                        // exactly one LDS-direct load per wave per call
+        const int64_t tt = t < ntiles ? t : ntiles - 1;
+        const int64_t row0 = (tile0 + tt) * F_BM;
+        const int nvalid = (int)((M - row0) < F_BM ? (M - row0) : F_BM);
+        stage_tile_async<bf16, F_BM, F_THR>(sXr + (int)(t % 3) * F_BM * 128, X + row0 * 128, 128, nvalid);
+    };
+    auto layernorm = [&](int64_t t) {                    // wave w normalises the 4 rows its own load delivered
+        float gmv[8], btv[8];
+        {
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(ln_g + sub * 8), g1 = *reinterpret_cast<const f32x4*>(ln_g + sub * 8 + 4);
+            const f32x4 c0 = *reinterpret_cast<const f32x4*>(ln_b + sub * 8), c1 = *reinterpret_cast<const f32x4*>(ln_b + sub * 8 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { gmv[e] = g0[e]; gmv[4 + e] = g1[e]; btv[e] = c0[e]; btv[4 + e] = c1[e]; }
+        }
+        const int r = 4 * w + (lane >> 4);
+        float v[8];
+        tile_load8(sXr + (int)(t % 3) * F_BM * 128, r, sub * 8, v);
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[e];
+        const float mean = reduce16(s) * (1.0f / 128.0f);
+        float qv = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { v[e] -= mean; qv += v[e] * v[e]; }
+        const float rstd = rsqrtf(reduce16(qv) * (1.0f / 128.0f) + KASF_LN_EPS);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] * rstd * gmv[e] + btv[e];
+        tile_store8(sA + (int)(t & 1) * F_BM * 128, r, sub * 8, v);
+    };
+    issue(0);
+    issue(1);
+    wait_async_le<1>();
+    layernorm(0);
+    for (int64_t t = 0; t < ntiles; ++t) {
+        const bf16* cA = sA + (int)(t & 1) * F_BM * 128;
+        const bf16* cX = sXr + (int)(t % 3) * F_BM * 128;
+        const int64_t row0 = (tile0 + t) * F_BM;
+        barrier_keep_async();                            // B1: LN(x_t) complete; everyone is past tile t-1
+        {   // ---- GEMM1: this wave's 64 hidden units x 32 tokens, then GELU -> sH ----
+            f32x4 acc1[4][2];
+            zero_acc(acc1);
+            bf16x8 fa[2][2];
+            fa[0][0] = tok_frag(cA, i, 0);
+            fa[0][1] = tok_frag(cA, 16 + i, 0);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks + 1 < 4) { fa[(ks + 1) & 1][0] = tok_frag(cA, i, ks + 1); fa[(ks + 1) & 1][1] = tok_frag(cA, 16 + i, ks + 1); }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) acc1[nt][mt] = mfma16(w1f[nt][ks], fa[ks & 1][mt], acc1[nt][mt]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            bf16* hT = sH + (w >> 1) * F_BM * 128;       // hidden chunk of this wave
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    float h[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h[r] = gelu_f<bf16>(acc1[nt][mt][r] + b1v[nt][r]);
+                    store4(hT + Tile<bf16>::off4(mt * 16 + i, 64 * (w & 1) + 16 * nt + 4 * g), h);
+                }
+        }
+        barrier_keep_async();                            // B2: the whole [32][512] hidden tile is in LDS
+        issue(t + 2);
+        {   // ---- GEMM2: this wave's 16 output channels x 32 tokens over all 512 hidden units ----
+            f32x4 acc2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            bf16x8 fh[2][2];
+            fh[0][0] = tok_frag(sH, i, 0);
+            fh[0][1] = tok_frag(sH, 16 + i, 0);
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                if (ks + 1 < 16) {
+                    const bf16* hT = sH + ((ks + 1) >> 2) * F_BM * 128;
+                    fh[(ks + 1) & 1][0] = tok_frag(hT, i, (ks + 1) & 3);
+                    fh[(ks + 1) & 1][1] = tok_frag(hT, 16 + i, (ks + 1) & 3);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                acc2[0] = mfma16(w2f[ks], fh[ks & 1][0], acc2[0]);
+                acc2[1] = mfma16(w2f[ks], fh[ks & 1][1], acc2[1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // x(t+1) has landed when only the youngest request (t+2) is still outstanding; this tile's output stores are
+            // issued AFTER this wait so that they never count as "youngest" (they get the whole next tile to drain)
+            wait_async_le<1>();
+            if (t + 1 < ntiles) layernorm(t + 1);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int64_t row = row0 + mt * 16 + i;
+                if (row < M) {
+                    float x[4], y[4];
+                    load4(cX + Tile<bf16>::off4(mt * 16 + i, 16 * w + 4 * g), x);      // residual from the raw tile still in LDS
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) y[r] = x[r] + lsv[r] * (acc2[mt][r] + b2v[r]);
+                    store4(out + row * 128 + 16 * w + 4 * g, y);
+                }
+            }
+        }
+    }
+    wait_async();
+}
+
 }  // namespace
 
 // scratch needs: dApart = 4*M*128 bf16;  partial >= 2 * ranges * 65536 floats (returned through *ranges_out)
@@ -360,4 +501,13 @@ void kasf_launch_mlp_bwd_q(hipStream_t s, const void* x, const void* g, const fl
     if (blocks > 512) blocks = 512;                     // few blocks: every block ends with 384 same-address atomics (contended atomics serialise)
     hipLaunchKernelGGL(k_lnbwd_sum4, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16*)dApart, (const bf16*)x, (const bf16*)g, ln_g, (bf16*)g_in, dgamma,
                        dbeta, gsum, M);
+}
+
+void kasf_launch_mlp_fwd_r(hipStream_t s, const void* x, const float* ln_g, const float* ln_b, const void* W1, const float* b1, const void* W2,
+                           const float* b2, const float* ls2, void* out, int64_t M) {
+    const int64_t tiles = (M + F_BM - 1) / F_BM;
+    const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
+    const size_t sh = (size_t)(9 * F_BM * 128) * sizeof(bf16);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_fwd_r), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    hipLaunchKernelGGL(k_mlp_fwd_r, dim3(grid), dim3(F_THR), sh, s, (const bf16*)x, ln_g, ln_b, (const bf16*)W1, b1, (const bf16*)W2, b2, ls2, (bf16*)out, M);
 }

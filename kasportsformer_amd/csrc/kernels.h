@@ -56,6 +56,9 @@ void kasf_launch_mlp_bwd(int dt, hipStream_t s, const void* x, const void* g, co
 void kasf_launch_mlp_bwd_q(hipStream_t s, const void* x, const void* g, const float* ln_g, const float* ln_b, const void* W1, const float* b1,
                            const void* W2ts, const void* W1t, void* dApart, float* partial, float* dW1, float* dW2, float* db1, float* gsum, void* g_in,
                            float* dgamma, float* dbeta, int64_t M);
+// bf16 forward with all weights resident in registers (persistent workgroups)
+void kasf_launch_mlp_fwd_r(hipStream_t s, const void* x, const float* ln_g, const float* ln_b, const void* W1, const float* b1, const void* W2,
+                           const float* b2, const float* ls2, void* out, int64_t M);
 void kasf_launch_wgrad_reduce(hipStream_t s, const float* partial, float* out, int64_t ldo, int N, int K, int splits);
 
 // ---- k_attn.hip ----
