@@ -64,18 +64,38 @@ def kernel_rooflines(M):
     st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
     p = lambda t: C.c_void_p(t.data_ptr())
     fwd = lambda: lib.kasf_op_mlp_fwd(1, p(x), p(gam), p(bet), p(w1), p(b1), p(w2), p(b2), p(ls), p(out), M, st())
-    bwd = lambda: lib.kasf_op_mlp_bwd(1, p(x), p(gout), p(gam), p(bet), p(w1), p(b1), p(w2ts), p(w1t), p(H), p(dZ), p(gin), p(dg), p(db), M, st())
+    dap = torch.empty(4 * M * 128, device=dev, dtype=bf)
+    part2 = torch.empty(2 * 64 * 65536, device=dev)
+    # the engine's bf16 backward: data gradient + both weight gradients + LayerNorm backward in k_mlp_bwd_q / k_lnbwd_sum4 / k_wgrad_reduce
+    bwd = lambda: lib.kasf_op_mlp_bwd_fused(p(x), p(gout), p(gam), p(bet), p(w1), p(b1), p(w2ts), p(w1t), p(dap), p(part2), p(dW1), p(dW2), p(db1),
+                                            p(gs), p(gin), p(dg), p(db), M, st())
     wg1 = lambda: lib.kasf_op_wgrad(1, p(dZ), 512, p(x), 128, None, None, p(dW1), p(db1), M, p(part), part.numel(), st())   # engine path: X = LN(x) emitted by k_mlp_bwd
     wg2 = lambda: lib.kasf_op_wgrad(1, p(gout), 128, p(H), 512, None, None, p(dW2), p(gs), M, p(part), part.numel(), st())
     res = {}
-    for name, fn, flop in (("k_mlp_fwd", fwd, MLP_FLOP_PER_TOKEN_FWD * M), ("k_mlp_bwd", bwd, MLP_FLOP_PER_TOKEN_FWD * M),
-                           ("k_wgrad_fc1", wg1, MLP_FLOP_PER_TOKEN_FWD // 2 * M), ("k_wgrad_fc2", wg2, MLP_FLOP_PER_TOKEN_FWD // 2 * M)):
+    # algorithmic FLOP: forward 2 GEMMs; fused backward = dgrad (2 GEMMs) + wgrad (2 GEMMs) = 2x forward (the Z recompute is not counted)
+    for name, fn, flop in (("k_mlp_fwd_r", fwd, MLP_FLOP_PER_TOKEN_FWD * M), ("k_mlp_bwd_q(+lnbwd_sum4+reduce)", bwd, 2 * MLP_FLOP_PER_TOKEN_FWD * M),
+                           ("k_wgrad_ring[512x128]", wg1, MLP_FLOP_PER_TOKEN_FWD // 2 * M), ("k_wgrad_ring[128x512]", wg2, MLP_FLOP_PER_TOKEN_FWD // 2 * M)):
         t = time_kernel(fn)
         res[name] = {"seconds": t, "achieved_tflops": flop / t / 1e12, "algorithmic_flop": flop}
     return res
 
 
-def cpu_baseline(batch=8, steps=2):
+TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_traffic.json")
+TRAFFIC_PARTS = {"k_mlp_fwd_r": {"k_mlp_fwd_r": 1}, "k_mlp_bwd_q(+lnbwd_sum4+reduce)": {"k_mlp_bwd_q": 1, "k_lnbwd_sum4": 1, "k_wgrad_reduce": 2}}
+
+
+def pmc_traffic(entry, M):
+    """HBM bytes per launch of a micro-benchmark entry, from the committed rocprofv3 --pmc summary (tools/pmc_traffic.py; the
+    counters cannot be read from inside the process).  Only valid for the token count the summary was collected at."""
+    if entry not in TRAFFIC_PARTS or M != BATCH_PER_GPU * T * 17 or not os.path.exists(TRAFFIC_FILE):
+        return None
+    ks = json.load(open(TRAFFIC_FILE))["kernels"]
+    if any(k not in ks for k in TRAFFIC_PARTS[entry]):
+        return None
+    return sum(ks[k]["hbm_bytes"] * n for k, n in TRAFFIC_PARTS[entry].items())
+
+
+def cpu_baseline(batch=8, steps=8):
     """Bounded sample of the SAME workload on the host cores: the CPU oracle (PyTorch fp32 restatement,
     verified equal to the reference on the golden fixtures) doing forward + 3-term loss + backward + AdamW."""
     from oracle import kasf_oracle as O
@@ -196,7 +216,8 @@ def main():
             log("kernel rooflines done")
             dom = max(ks, key=lambda k: ks[k]["seconds"])
             out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ks[dom]["achieved_tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ks[dom]["achieved_tflops"] / PEAK_BF16_TFLOPS, "traffic": None,
+                               "frac": ks[dom]["achieved_tflops"] / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(dom, args.batch * T * 17),
+                               "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/r1_pmc_traffic.json)",
                                "launch_ms": ks[dom]["seconds"] * 1e3, "algorithmic_flop_per_launch": ks[dom]["algorithmic_flop"]}
             out["kernels"] = {k: {"ms": v["seconds"] * 1e3, "tflops": v["achieved_tflops"]} for k, v in ks.items()}
         if not args.no_cpu_baseline and world == 1:

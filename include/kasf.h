@@ -103,6 +103,13 @@ int kasf_op_mlp_fwd(int32_t dtype, const void* x, const float* ln_g, const float
                     const float* ls2, void* out, int64_t M, void* stream);
 int kasf_op_mlp_bwd(int32_t dtype, const void* x, const void* g, const float* ln_g, const float* ln_b, const void* w1, const float* b1,
                     const void* w2t_scaled, const void* w1t, void* hbuf, void* dzbuf, void* g_in, float* dgamma, float* dbeta, int64_t M, void* stream);
+/* bf16 only: fused MLP backward (hidden-quarter ownership, weights in registers): data gradient AND both weight gradients.
+ * g_in = g + LNbwd(dA); dw1 [512,128] += dZ^T LN(x); db1 [512] += colsum(dZ); dw2_unscaled [128,512] += g^T H;
+ * gsum [128] += colsum(g); dgamma/dbeta += LayerNorm parameter gradients.  dapart: 4*M*128 elements of scratch (bf16);
+ * partial: >= 2*64*65536 floats of scratch. */
+int kasf_op_mlp_bwd_fused(const void* x, const void* g, const float* ln_g, const float* ln_b, const void* w1, const float* b1, const void* w2t_scaled,
+                          const void* w1t, void* dapart, float* partial, float* dw1, float* dw2_unscaled, float* db1, float* gsum, void* g_in,
+                          float* dgamma, float* dbeta, int64_t M, void* stream);
 /* dW[N,K] += G^T LN?(X), dbias[N] += colsum(G): G [M,N], X [M,K].  partial: optional fp32 scratch of partial_floats
  * elements (>= 256*128*128 covers every shape of this model): per-split tiles are stored and summed by a second
  * kernel (bitwise reproducible); NULL -> fp32 atomics on dw. */

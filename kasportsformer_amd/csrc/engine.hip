@@ -706,6 +706,15 @@ int kasf_op_mlp_bwd(int32_t dtype, const void* x, const void* g, const float* ln
     HIPCHK(hipGetLastError());
     return 0;
 }
+int kasf_op_mlp_bwd_fused(const void* x, const void* g, const float* ln_g, const float* ln_b, const void* w1, const float* b1, const void* w2t_scaled,
+                          const void* w1t, void* dapart, float* partial, float* dw1, float* dw2_unscaled, float* db1, float* gsum, void* g_in,
+                          float* dgamma, float* dbeta, int64_t M, void* stream) {
+    if (!x || !g || !dapart || !partial || !dw1 || !dw2_unscaled || !db1 || !gsum || !g_in) return kasf_set_error(2, "null pointer argument");
+    kasf_launch_mlp_bwd_q((hipStream_t)stream, x, g, ln_g, ln_b, w1, b1, w2t_scaled, w1t, dapart, partial, dw1, dw2_unscaled, db1, gsum, g_in, dgamma,
+                          dbeta, M);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
 int kasf_op_wgrad(int32_t dtype, const void* g, int32_t N, const void* x, int32_t K, const float* ln_g, const float* ln_b, float* dw, float* dbias,
                   int64_t M, float* partial, int64_t partial_floats, void* stream) {
     OP_DT_CHECK(dtype);

@@ -50,7 +50,14 @@ __global__ __launch_bounds__(NW * 64) void k_mlp_bwd_q(const bf16* __restrict__ 
     bf16* sH = sG + 3 * Q_BM * 128;                      // [BM][128]    H of this quarter
     bf16* sD = sH + Q_BM * 128;                          // [BM][128]    dZ of this quarter
     bf16* sXr = sD + Q_BM * 128;                         // [2][BM][128] raw x rows (LDS-direct landing zone), two tiles ahead
-    const int q = blockIdx.x & 3, range = blockIdx.x >> 2;
+    // XCD-aware mapping: workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), so the four hidden quarters of one token range
+    // sit at blockIdx b, b+8, b+16, b+24: same XCD, same L2 -> x and g cross the fabric once, not four times.
+    int q, range;
+    {
+        const int used = gridDim.x >> 2, full = used & ~7, b = blockIdx.x;
+        if (b < 4 * full) { q = (b >> 3) & 3; range = (b & 7) + 8 * (b >> 5); }
+        else { q = (b - 4 * full) & 3; range = full + ((b - 4 * full) >> 2); }
+    }
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
     const int64_t tile0 = (int64_t)range * tiles_per_range;
     const int64_t ntiles_total = (M + Q_BM - 1) / Q_BM;

@@ -83,10 +83,11 @@ def test_stage_by_stage_against_oracle(cd, tol):
     assert _abs_err(limb, oracle.bone_refusion(x)) < 1e-5
 
 
+@pytest.mark.parametrize("L,T,B", [(2, 27, 2), (1, 81, 2), (1, 9, 3)])
 @pytest.mark.parametrize("cd,tol", [("fp32", 2e-3), ("bf16", 0.35)])
-def test_backward_matches_oracle(cd, tol):
-    oracle, model = make_pair(2, 27, cd)
-    x, y = O.synthetic_clips(2, 27)
+def test_backward_matches_oracle(cd, tol, L, T, B):
+    oracle, model = make_pair(L, T, cd)
+    x, y = O.synthetic_clips(B, T)
     oracle.train()
     loss_ref, _ = O.loss_total(oracle(x), y)
     loss_ref.backward()
@@ -107,17 +108,17 @@ def test_backward_matches_oracle(cd, tol):
         if r is None:
             continue
         g = p.grad.detach().double().cpu()
-        if cd == "fp32":
-            worst[n] = rel_err(g, r)
+        if cd == "fp32":   # floor: gradients that are sums of cancelling terms (constant-confidence limb MLPs) carry fp32 summation-order noise on both sides
+            worst[n] = float((g - r.double()).abs().max() / max(float(r.abs().max()), 1e-3 * gmax))
         else:   # bf16: tiny gradients (16-element limb-refusion tensors fed through a bf16-accumulated g_limb) sit at the bf16 noise floor -> floor the scale
             worst[n] = float((g - r.double()).abs().max() / max(float(r.abs().max()), 0.05 * gmax))
         dots[0] += float((g * r.double()).sum()); dots[1] += float((g * g).sum()); dots[2] += float((r.double() ** 2).sum())
     assert not none_mismatch, none_mismatch
-    assert sum(1 for p in model.parameters() if p.grad is None) == 16      # 8 dead norm1_limb tensors per layer
+    assert sum(1 for p in model.parameters() if p.grad is None) == 8 * L   # 8 dead norm1_limb tensors per layer
     cosine = dots[0] / (dots[1] ** 0.5 * dots[2] ** 0.5)
     assert cosine > (0.999999 if cd == "fp32" else 0.995), cosine
-    bad = sorted(((v, k) for k, v in worst.items() if not v < tol), reverse=True)
-    assert not bad, f"{len(bad)} gradients above {tol}; worst: {bad[:12]}"
+    bad = sorted(((v, k, float(ref_grads[k].grad.abs().max()) / gmax) for k, v in worst.items() if not v < tol), reverse=True)
+    assert not bad, f"{len(bad)} gradients above {tol}; worst (err, name, |g|max/gmax): {bad[:12]}"
 
 
 def test_fp32_backward_matches_reference_golden():

@@ -143,6 +143,39 @@ def test_mlp_backward_and_wgrad(lib, cd):
     assert rel_err(_back(gsum), gr.sum(0)) < tol
 
 
+@pytest.mark.parametrize("M", [459, 3000])
+def test_mlp_backward_fused_bf16(lib, M):
+    """k_mlp_bwd_q + k_lnbwd_sum4 + k_wgrad_reduce (the bf16 engine path) against autograd."""
+    from kasportsformer_amd import _lib
+    cd = "bf16"
+    p = _mlp_params(seed=30)
+    x, gout = _rand(M, 128, seed=31), _rand(M, 128, seed=32)
+    xd, gd, w1 = _dev(x, cd), _dev(gout, cd), _dev(p["W1"], cd)
+    w2ts = _dev((p["ls"][:, None] * p["W2"]).T.contiguous(), cd)
+    w1t = _dev(p["W1"].T.contiguous(), cd)
+    dap = torch.empty(4 * M * 128, device="cuda", dtype=torch.bfloat16)
+    part = torch.empty(2 * 64 * 65536, device="cuda")
+    gin = torch.empty_like(xd)
+    z = lambda *s: torch.zeros(*s, device="cuda")
+    dW1, dW2, db1, gsum, dg, db = z(512, 128), z(128, 512), z(512), z(128), z(128), z(128)
+    _lib.check(lib.kasf_op_mlp_bwd_fused(ptr(xd), ptr(gd), ptr(_f32(p["g"])), ptr(_f32(p["b"])), ptr(w1), ptr(_f32(p["b1"])), ptr(w2ts), ptr(w1t),
+                                         ptr(dap), ptr(part), ptr(dW1), ptr(dW2), ptr(db1), ptr(gsum), ptr(gin), ptr(dg), ptr(db), M, stream()))
+    torch.cuda.synchronize()
+    xr = _back(xd).requires_grad_(True)
+    pr = {k: (v.clone().requires_grad_(True) if k in ("b1", "W2", "g", "b") else v) for k, v in p.items()}
+    pr["W1"] = _back(w1).requires_grad_(True)
+    gr = _back(gd)
+    h = F.gelu(_ln(xr, pr["g"], pr["b"]) @ pr["W1"].T + pr["b1"])
+    out = xr + p["ls"] * (h @ pr["W2"].T + p["b2"])
+    out.backward(gr)
+    tol = TOL[cd]
+    assert rel_err(_back(gin), xr.grad) < tol
+    assert rel_err(_back(dg), pr["g"].grad) < tol and rel_err(_back(db), pr["b"].grad) < tol
+    assert rel_err(_back(dW1), pr["W1"].grad) < tol and rel_err(_back(db1), pr["b1"].grad) < tol
+    assert rel_err(p["ls"][:, None] * _back(dW2), pr["W2"].grad) < tol
+    assert rel_err(_back(gsum), gr.sum(0)) < tol
+
+
 @pytest.mark.parametrize("cd", ["fp32", "bf16"])
 @pytest.mark.parametrize("Kd", [128, 384, 512])
 def test_dgrad_lnbwd(lib, cd, Kd):

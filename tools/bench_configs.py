@@ -1,0 +1,66 @@
+"""Throughput of the other SURVEY §8(d) configurations (bench.py reports configs[1] only).
+
+    python tools/bench_configs.py train81        # config 4: T=81, B=128, bf16 training step
+    python tools/bench_configs.py eval           # config 5: forward only, T=27, B/GPU sweep, with and without flip-TTA
+One JSON line per measurement.
+"""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import kasportsformer_amd as K
+from oracle import kasf_oracle as O     # synthetic clip recipe only
+
+FWD_GFLOP = {27: 27.44, 81: 85.28}      # SURVEY §8(d), per clip
+
+
+def timed(fn, steps, warmup):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def train(T, B, steps=5, warmup=2):
+    torch.manual_seed(114514)
+    model = K.KASportsFormer(n_layers=26, num_heads=8, n_frames=T, compute_dtype="bf16").cuda().train()
+    model.attach_param_grads = False
+    opt = K.FusedAdamW(model, lr=5e-4, weight_decay=0.01)
+    x, y = (t.cuda() for t in O.synthetic_clips(B, T, seed=1234))
+
+    def step():
+        opt.zero_grad()
+        loss, _ = K.loss3(model(x), y)
+        loss.backward()
+        opt.step()
+    dt = timed(step, steps, warmup)
+    print(json.dumps({"config": f"train T={T} B={B} bf16", "clips_per_s": B / dt, "ms_per_step": dt * 1e3,
+                      "mfma_frac": B / dt * 3 * FWD_GFLOP[T] * 1e9 / 2.5e15}), flush=True)
+
+
+def evaluate(T=27, batches=(32, 64, 128, 256, 512), steps=10, warmup=3):
+    torch.manual_seed(114514)
+    model = K.KASportsFormer(n_layers=26, num_heads=8, n_frames=T, compute_dtype="bf16").cuda().eval()
+    for B in batches:
+        x, _ = O.synthetic_clips(B, T, seed=1234)
+        x = x.cuda()
+        with torch.no_grad():
+            dt = timed(lambda: model(x), steps, warmup)
+            row = {"config": f"eval T={T} B={B} bf16", "clips_per_s": B / dt, "ms_per_batch": dt * 1e3, "mfma_frac": B / dt * FWD_GFLOP[T] * 1e9 / 2.5e15}
+            if hasattr(K, "predict_flip_tta"):
+                dt2 = timed(lambda: K.predict_flip_tta(model, x), steps, warmup)
+                row["clips_per_s_flip_tta"] = B / dt2
+        print(json.dumps(row), flush=True)
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "eval"
+    if what == "train81":
+        train(81, 128)
+    elif what == "train27":
+        train(27, 256)
+    else:
+        evaluate()
