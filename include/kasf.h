@@ -17,6 +17,9 @@
  *   kasf_backward          <- torch.autograd of the above         train_and_evaluate_sp.py:241  (loss.backward())
  *   kasf_loss3             <- mpjpe + 0.5 n_mpjpe + 20 velocity   utils/loss_calc.py:6-27, train_and_evaluate_sp.py:212-222
  *   kasf_adamw_step        <- optim.AdamW(...).step()             train_and_evaluate_sp.py:270-272,243
+ *   kasf_joint_flip        <- joint_flip                            utils/utilities.py:128-135
+ *   kasf_tta_merge         <- flip-TTA average + root zeroing        train_and_evaluate_sp.py:46-55
+ *   kasf_eval_metrics      <- de-normalise + MPJPE/JPE/accel/P-MPJPE train_and_evaluate_sp.py:57-93, utils/error_calc.py:5-48
  *   kasf_op_*              <- the individual nn.Modules under model/modules/ (unit-test entry points)
  */
 #ifndef KASF_H_
@@ -88,6 +91,19 @@ int kasf_loss3(const float* pred, const float* target, float* dpred, float* loss
 /* torch.optim.AdamW step over n contiguous fp32 elements (n multiple of 4); step_index starts at 1 */
 int kasf_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2, float eps,
                     float weight_decay, int32_t step_index, float grad_scale, void* stream);
+
+/* ---- evaluation side: fp32 [rows = B*T][17][3] poses ---- */
+/* dst = joint_flip(src): x negated, left joints [1,2,3,14,15,16] swapped with right [4,5,6,11,12,13]; src != dst */
+int kasf_joint_flip(const float* src, float* dst, int64_t rows, void* stream);
+/* out = (pred + joint_flip(pred_of_flipped)) / 2 with the root joint zeroed; pred_of_flipped == NULL: root zeroing only */
+int kasf_tta_merge(const float* pred, const float* pred_of_flipped, float* out, int64_t rows, void* stream);
+/* The reference's per-clip evaluation loop in one launch.  pred [B,T,17,3] (normalised model output, root zeroed here again),
+ * label_scaled [B,T,17,3] (mm), factor [B,T], res [B,2] = (w,h) as floats, action [B] ids in [0,n_actions) (or NULL with action_sums NULL).
+ * Per-frame outputs: mpjpe [B,T], p_mpjpe [B,T], accel [B,T-2], jpe [B,T,17].  action_sums [n_actions][KASF_EVAL_COLS] fp64 is
+ * ACCUMULATED into: columns = sum mpjpe, sum p_mpjpe, sum accel, sum jpe[17], #frames, #accel frames. */
+#define KASF_EVAL_COLS 22
+int kasf_eval_metrics(const float* pred, const float* label_scaled, const float* factor, const float* res, const int32_t* action, int32_t batch,
+                      int32_t n_frames, int32_t n_actions, float* mpjpe, float* p_mpjpe, float* accel, float* jpe, double* action_sums, void* stream);
 
 /* debugging / tests: locate a named activation inside the workspace (see kasf_ws_name()) */
 int32_t kasf_ws_entries(const kasf_model* m, int32_t batch, int32_t flags);

@@ -5,10 +5,14 @@ Public surface mirrors the reference's interface for this path:
   loss3, mpjpe_loss / ...               utils/loss_calc.py:6-27 (+ the train-step combination)
   FusedAdamW                            optim.AdamW as used in train_and_evaluate_sp.py:270-272
   DataParallel                          nn.DataParallel replacement: one process per GPU, RCCL all-reduce
+  joint_flip, predict_flip_tta,         utils/utilities.py:128-135, train_and_evaluate_sp.py:27-149, utils/error_calc.py:5-48
+  clip_metrics, Evaluator, evaluate_one_epoch
 """
 from .model import KASportsFormer, load_model
 from .functional import loss3
 from .optim import FusedAdamW
 from .parallel import DataParallel
+from .evaluate import joint_flip, predict_flip_tta, clip_metrics, Evaluator, evaluate_one_epoch
 
-__all__ = ["KASportsFormer", "load_model", "loss3", "FusedAdamW", "DataParallel"]
+__all__ = ["KASportsFormer", "load_model", "loss3", "FusedAdamW", "DataParallel", "joint_flip", "predict_flip_tta", "clip_metrics", "Evaluator",
+           "evaluate_one_epoch"]

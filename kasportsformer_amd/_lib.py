@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libkasf_hip.so")
 
 DTYPE_F32, DTYPE_BF16 = 0, 1
 FLAG_TRAIN, FLAG_RETURN_REP = 1, 2
+EVAL_COLS = 22
 
 
 class KasfConfig(C.Structure):
@@ -49,6 +50,9 @@ SIGNATURES = {
     "kasf_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "kasf_loss3": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _f32, _f32, _vp]),
     "kasf_adamw_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _vp]),
+    "kasf_joint_flip": (_i32, [_vp, _vp, _i64, _vp]),
+    "kasf_tta_merge": (_i32, [_vp, _vp, _vp, _i64, _vp]),
+    "kasf_eval_metrics": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "kasf_ws_entries": (_i32, [_vp, _i32, _i32]),
     "kasf_ws_entry": (_i32, [_vp, _i32, _i32, _i32, C.c_char_p, _i32, _pi64, _pi64, _pi32]),
     "kasf_op_linear": (_i32, [_i32, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _vp]),

@@ -681,6 +681,28 @@ int kasf_adamw_step(float* params, const float* grads, float* exp_avg, float* ex
     return 0;
 }
 
+int kasf_joint_flip(const float* src, float* dst, int64_t rows, void* stream) {
+    if (!src || !dst || src == dst) return kasf_set_error(2, "joint_flip: null or aliased pointers");
+    kasf_launch_joint_flip((hipStream_t)stream, src, dst, rows);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int kasf_tta_merge(const float* pred, const float* pred_of_flipped, float* out, int64_t rows, void* stream) {
+    if (!pred || !out) return kasf_set_error(2, "null pointer argument");
+    kasf_launch_tta_merge((hipStream_t)stream, pred, pred_of_flipped, out, rows);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int kasf_eval_metrics(const float* pred, const float* label_scaled, const float* factor, const float* res, const int32_t* action, int32_t batch,
+                      int32_t n_frames, int32_t n_actions, float* mpjpe, float* p_mpjpe, float* accel, float* jpe, double* action_sums, void* stream) {
+    if (!pred || !label_scaled || !factor || !res || !mpjpe || !p_mpjpe || !accel || !jpe) return kasf_set_error(2, "null pointer argument");
+    if (n_frames < 3 || n_frames > 128) return kasf_set_error(2, "eval_metrics: n_frames must be in [3,128]");
+    if ((action == nullptr) != (action_sums == nullptr)) return kasf_set_error(2, "eval_metrics: action and action_sums go together");
+    kasf_launch_eval_metrics((hipStream_t)stream, pred, label_scaled, factor, res, action, batch, n_frames, n_actions, mpjpe, p_mpjpe, accel, jpe, action_sums);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 #define OP_DT_CHECK(dt) \
     if ((dt) != KASF_F32 && (dt) != KASF_BF16) return kasf_set_error(3, "bad dtype")
 

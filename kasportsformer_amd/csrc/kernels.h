@@ -109,3 +109,9 @@ void kasf_launch_loss3(hipStream_t s, const float* pred, const float* tgt, float
                        float grad_scale);
 void kasf_launch_adamw(hipStream_t s, float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float wd,
                        float bc1, float bc2, float grad_scale);
+
+// ---- k_eval.hip ----
+void kasf_launch_joint_flip(hipStream_t s, const float* src, float* dst, int64_t rows);
+void kasf_launch_tta_merge(hipStream_t s, const float* p, const float* pf, float* out, int64_t rows);
+void kasf_launch_eval_metrics(hipStream_t s, const float* pred, const float* label, const float* factor, const float* res, const int* action, int B, int T,
+                              int n_actions, float* mpjpe, float* pmpjpe, float* acc, float* jpe, double* action_sums);

@@ -450,3 +450,72 @@ def synthetic_clips(B, T, seed=1234, res=(1312, 1216), det_conf=False):
     y = torch.randn(B, T, 17, 3, generator=g) * 0.25
     y = y - y[:, :, :1]
     return x.contiguous(), y.contiguous()
+
+
+ACTIONS = ("soccer", "tennis", "jump", "throw_baseball", "volley")     # 5 SportsPose activity names (data_action values)
+
+
+def synthetic_test_extras(y, seed=4321, res_choices=((1312, 1216), (1216, 1936))):
+    """Test-split extras of a clip (SURVEY §8(d) recipe; clip_generate_sp.py:52-79 fields): per-frame ``factor`` ~U(0.8,1.2),
+    ``res`` (w,h), an action name, and ``label_scaled`` (mm) consistent with ``y``: de-normalised, scaled, plus noise so errors are non-zero."""
+    g = torch.Generator().manual_seed(seed)
+    B, T = y.shape[:2]
+    factor = torch.rand(B, T, generator=g) * 0.4 + 0.8
+    pick = torch.randint(0, len(res_choices), (B,), generator=g)
+    res = torch.tensor([res_choices[int(i)] for i in pick], dtype=torch.int64)
+    actions = [ACTIONS[int(i)] for i in torch.randint(0, len(ACTIONS), (B,), generator=g)]
+    w = res[:, 0].float()[:, None, None, None]
+    label_scaled = y * w / 2 * factor[:, :, None, None] + torch.randn(B, T, 17, 3, generator=g) * 20.0
+    label_scaled = label_scaled - label_scaled[:, :, :1]
+    return label_scaled.contiguous(), factor.contiguous(), res, actions
+
+
+def predict_flip_tta(model, x, flip=True):
+    """train_and_evaluate_sp.py:46-55."""
+    if flip:
+        pred = (model(x) + joint_flip(model(joint_flip(x)))) / 2
+    else:
+        pred = model(x)
+    pred = pred.clone()
+    pred[:, :, 0, :] = 0
+    return pred
+
+
+def clip_metrics(pred_clip: np.ndarray, label_scaled: np.ndarray, factor: np.ndarray, res):
+    """De-normalisation and per-frame metrics of ONE clip (train_and_evaluate_sp.py:59-76).  pred_clip float32 [T,17,3], root already zeroed."""
+    res_w, res_h = res
+    pd = pred_clip.copy()
+    pd[:, :, :2] = (pd[:, :, :2] + np.array([1, res_h / res_w])) * res_w / 2
+    pd[:, :, 2:] = pd[:, :, 2:] * res_w / 2
+    pd *= factor[:, None, None]
+    pd = pd - pd[:, 0:1, :]
+    gt = label_scaled - label_scaled[:, 0:1, :]
+    return mpjpe(pd, gt), jpe(pd, gt), acc_error(pd, gt), p_mpjpe(pd, gt)
+
+
+def evaluate_batches(batches, num_joints=17):
+    """Restatement of the aggregation of evaluate_one_epoch_new (train_and_evaluate_sp.py:27-149).
+
+    ``batches`` yields (pred [B,T,17,3] float32 numpy with the root zeroed, label_scaled, factor, actions(list of str), res [B,2]).
+    Returns the reference's evaluate_result_dict; actions are listed in first-seen order (the reference iterates a Python ``set``)."""
+    per_act, per_act_p, per_act_a = {}, {}, {}
+    per_joint = [dict() for _ in range(num_joints)]
+    order = []
+    for pred, label_scaled, factor, actions, res in batches:
+        for i in range(pred.shape[0]):
+            m, j, a, p = clip_metrics(np.asarray(pred[i], dtype=np.float32), np.asarray(label_scaled[i], dtype=np.float32), np.asarray(factor[i]),
+                                      (int(res[i][0]), int(res[i][1])))
+            act = actions[i]
+            if act not in per_act:
+                order.append(act)
+            per_act.setdefault(act, []).extend(m)
+            per_act_p.setdefault(act, []).extend(p)
+            per_act_a.setdefault(act, []).extend(a)
+            for k in range(num_joints):
+                per_joint[k].setdefault(act, []).extend(j[:, k])
+    m_act = [np.mean(per_act[a]) for a in order]
+    p_act = [np.mean(per_act_p[a]) for a in order]
+    a_act = [np.mean(per_act_a[a]) for a in order]
+    joints = np.array([np.mean(np.array([np.mean(per_joint[k][a]) for a in order])) for k in range(num_joints)])
+    return {"mpjpe": np.mean(np.array(m_act)), "p_mpjpe": np.mean(np.array(p_act)), "acceleration_error": np.mean(np.array(a_act)),
+            "activity_name_sequence": order, "mpjpe_activity": m_act, "mpjpe_joint": joints}

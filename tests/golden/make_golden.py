@@ -111,9 +111,51 @@ def model_fixture(Ref, LC, path, n_layers, B, T, stages):
     print("wrote", path, "%.2f MB" % (os.path.getsize(path) / 1e6))
 
 
+def eval_fixture(Ref, EC):
+    left, right = [1, 2, 3, 14, 15, 16], [4, 5, 6, 11, 12, 13]
+    # 4. evaluation procedure (SURVEY §8(d) config 1 at 2 layers): REFERENCE model + REFERENCE metric functions; the loop around them
+    #    (train_and_evaluate_sp.py:27-149) cannot be imported (wandb, easydict) and is the restatement in oracle.evaluate_batches.
+    torch.manual_seed(0)
+    ref = Ref(n_layers=2, dim_in=3, dim_feat=128, dim_rep=512, dim_out=3, mlp_ratio=4, num_heads=8, n_frames=27)
+    sd = O.name_seeded_fill(ref.state_dict())
+    ref.load_state_dict(sd)
+    ref.eval()
+    x, y = O.synthetic_clips(4, 27, seed=99)
+    label_scaled, factor, res, actions = O.synthetic_test_extras(y, seed=98)
+
+    def flip(t):
+        t = t.clone()
+        t[..., 0] *= -1
+        t[..., left + right, :] = t[..., right + left, :]
+        return t
+    with torch.no_grad():
+        p0 = ref(x.clone())
+        p1 = flip(ref(flip(x)))
+        pred_tta, pred_plain = (p0 + p1) / 2, p0.clone()
+    pred_tta[:, :, 0, :] = 0
+    pred_plain[:, :, 0, :] = 0
+    saved = (O.mpjpe, O.jpe, O.acc_error, O.p_mpjpe)
+    O.mpjpe, O.jpe, O.acc_error, O.p_mpjpe = EC.mpjpe_calc, EC.jpe_calc, EC.acc_error_calc, EC.p_mpjpe_calc
+    ev = {}
+    for tag, pr in (("tta", pred_tta), ("plain", pred_plain)):
+        r = O.evaluate_batches([(pr.numpy(), label_scaled.numpy(), factor.numpy(), actions, res.numpy())])
+        ev.update({f"{tag}_mpjpe": np.float64(r["mpjpe"]), f"{tag}_p_mpjpe": np.float64(r["p_mpjpe"]), f"{tag}_acc": np.float64(r["acceleration_error"]),
+                   f"{tag}_mpjpe_joint": np.asarray(r["mpjpe_joint"], np.float64), f"{tag}_mpjpe_activity": np.asarray(r["mpjpe_activity"], np.float64)})
+        ev["activity_name_sequence"] = np.array(r["activity_name_sequence"])
+    per = [O.clip_metrics(pred_tta[i].numpy(), label_scaled[i].numpy(), factor[i].numpy(), (int(res[i][0]), int(res[i][1]))) for i in range(4)]
+    O.mpjpe, O.jpe, O.acc_error, O.p_mpjpe = saved
+    ev.update(x=x.numpy(), label_scaled=label_scaled.numpy(), factor=factor.numpy(), res=res.numpy(), actions=np.array(actions),
+              pred_tta=pred_tta.numpy(), pred_plain=pred_plain.numpy(), clip_mpjpe=np.stack([q[0] for q in per]), clip_jpe=np.stack([q[1] for q in per]),
+              clip_acc=np.stack([q[2] for q in per]), clip_pmpjpe=np.stack([q[3] for q in per]))
+    np.savez_compressed(os.path.join(HERE, "eval_L2_T27_B4.npz"), **ev)
+    print("wrote eval_L2_T27_B4.npz:", {k: float(v) for k, v in ev.items() if np.ndim(v) == 0})
+
+
 def main():
     Ref, bone_decomposer, LC, EC = import_reference()
     torch.set_num_threads(8)
+    if sys.argv[1:] == ["eval"]:                             # only the evaluation fixture
+        return eval_fixture(Ref, EC)
 
     # 1. state_dict manifest of the full 26-layer model (names/shapes/dtypes only)
     full = Ref(n_layers=26, dim_in=3, dim_feat=128, dim_rep=512, dim_out=3, mlp_ratio=4, num_heads=8, n_frames=27)
@@ -159,6 +201,7 @@ def main():
     fx.update(flip_in=xf.numpy(), flip_out=fl.numpy())
     np.savez_compressed(os.path.join(HERE, "functional.npz"), **fx)
     print("wrote functional.npz")
+    eval_fixture(Ref, EC)
 
 
 if __name__ == "__main__":

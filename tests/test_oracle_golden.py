@@ -108,3 +108,29 @@ def test_functional_pins(golden_dir):
     assert np.array_equal(O.joint_flip(torch.from_numpy(fx["flip_in"])).numpy(), fx["flip_out"])
     f = torch.from_numpy(fx["flip_in"])
     assert torch.equal(O.joint_flip(O.joint_flip(f)), f)
+
+
+def test_evaluation_procedure_matches_reference_fixture(golden_dir):
+    """Reference model + reference metric functions (fixture) vs oracle model + oracle metrics + restated evaluation loop
+    (train_and_evaluate_sp.py:27-149); SURVEY §8(d) config 1 at 2 layers."""
+    fx = _load(golden_dir, "eval_L2_T27_B4.npz")
+    m = O.KASportsFormerOracle(n_layers=2, num_heads=8, n_frames=27)
+    m.load_state_dict(O.name_seeded_fill(m.state_dict()), strict=True)
+    m.eval()
+    x, y = O.synthetic_clips(4, 27, seed=99)
+    label_scaled, factor, res, actions = O.synthetic_test_extras(y, seed=98)
+    assert np.array_equal(x.numpy(), fx["x"]) and np.array_equal(label_scaled.numpy(), fx["label_scaled"])
+    assert actions == list(fx["actions"]) and np.array_equal(res.numpy(), fx["res"])
+    with torch.no_grad():
+        for tag, flip in (("tta", True), ("plain", False)):
+            pred = O.predict_flip_tta(m, x, flip=flip)
+            assert np.abs(pred.numpy() - fx[f"pred_{tag}"]).max() < TOL
+            r = O.evaluate_batches([(fx[f"pred_{tag}"], fx["label_scaled"], fx["factor"], actions, fx["res"])])
+            assert r["activity_name_sequence"] == list(fx["activity_name_sequence"])
+            for key, name in (("mpjpe", "mpjpe"), ("p_mpjpe", "p_mpjpe"), ("acceleration_error", "acc")):
+                assert abs(float(r[key]) - float(fx[f"{tag}_{name}"])) < 1e-5 * float(fx[f"{tag}_{name}"])
+            assert np.allclose(r["mpjpe_joint"], fx[f"{tag}_mpjpe_joint"], rtol=1e-5)
+            assert np.allclose(r["mpjpe_activity"], fx[f"{tag}_mpjpe_activity"], rtol=1e-5)
+    per = [O.clip_metrics(fx["pred_tta"][i], fx["label_scaled"][i], fx["factor"][i], tuple(int(v) for v in fx["res"][i])) for i in range(4)]
+    for k, name in enumerate(("clip_mpjpe", "clip_jpe", "clip_acc", "clip_pmpjpe")):
+        assert np.allclose(np.stack([q[k] for q in per]), fx[name], rtol=1e-5, atol=1e-4)
