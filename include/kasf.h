@@ -17,6 +17,7 @@
  *   kasf_backward          <- torch.autograd of the above         train_and_evaluate_sp.py:241  (loss.backward())
  *   kasf_loss3             <- mpjpe + 0.5 n_mpjpe + 20 velocity   utils/loss_calc.py:6-27, train_and_evaluate_sp.py:212-222
  *   kasf_adamw_step        <- optim.AdamW(...).step()             train_and_evaluate_sp.py:270-272,243
+ *   kasf_gather_clips      <- Dataset.__getitem__ + DataLoader collate data/reader/sp_dataset.py:45-92
  *   kasf_joint_flip        <- joint_flip                            utils/utilities.py:128-135
  *   kasf_tta_merge         <- flip-TTA average + root zeroing        train_and_evaluate_sp.py:46-55
  *   kasf_eval_metrics      <- de-normalise + MPJPE/JPE/accel/P-MPJPE train_and_evaluate_sp.py:57-93, utils/error_calc.py:5-48
@@ -91,6 +92,12 @@ int kasf_loss3(const float* pred, const float* target, float* dpred, float* loss
 /* torch.optim.AdamW step over n contiguous fp32 elements (n multiple of 4); step_index starts at 1 */
 int kasf_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2, float eps,
                     float weight_decay, int32_t step_index, float grad_scale, void* stream);
+
+/* ---- batch assembly from a clip set resident in device memory: x_all/y_all [n_clips,T,17,3] fp32 (y_all may be NULL) ----
+ * x_out[b] = x_all[index[b]] (same for y), left/right flipped (flip_data, sp_dataset.py:36-40) where flip[b] != 0 (flip may be NULL).
+ * An index outside [0,n_clips) yields a zero clip. */
+int kasf_gather_clips(const float* x_all, const float* y_all, const int64_t* index, const uint8_t* flip, int64_t n_clips, int32_t batch,
+                      int32_t n_frames, float* x_out, float* y_out, void* stream);
 
 /* ---- evaluation side: fp32 [rows = B*T][17][3] poses ---- */
 /* dst = joint_flip(src): x negated, left joints [1,2,3,14,15,16] swapped with right [4,5,6,11,12,13]; src != dst */

@@ -7,12 +7,15 @@ Public surface mirrors the reference's interface for this path:
   DataParallel                          nn.DataParallel replacement: one process per GPU, RCCL all-reduce
   joint_flip, predict_flip_tta,         utils/utilities.py:128-135, train_and_evaluate_sp.py:27-149, utils/error_calc.py:5-48
   clip_metrics, Evaluator, evaluate_one_epoch
+  pack_clip_directory, PackedClips,     data/preprocessor/clip_generate_sp.py:28-79 (file format), data/reader/sp_dataset.py:45-92
+  DeviceClipLoader
 """
 from .model import KASportsFormer, load_model
 from .functional import loss3
 from .optim import FusedAdamW
 from .parallel import DataParallel
+from .data import PackedClips, DeviceClipLoader, pack_clip_directory, read_clip_file, shard_indices
 from .evaluate import joint_flip, predict_flip_tta, clip_metrics, Evaluator, evaluate_one_epoch
 
 __all__ = ["KASportsFormer", "load_model", "loss3", "FusedAdamW", "DataParallel", "joint_flip", "predict_flip_tta", "clip_metrics", "Evaluator",
-           "evaluate_one_epoch"]
+           "evaluate_one_epoch", "PackedClips", "DeviceClipLoader", "pack_clip_directory", "read_clip_file", "shard_indices"]

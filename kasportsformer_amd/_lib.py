@@ -50,6 +50,7 @@ SIGNATURES = {
     "kasf_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "kasf_loss3": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _f32, _f32, _vp]),
     "kasf_adamw_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _vp]),
+    "kasf_gather_clips": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
     "kasf_joint_flip": (_i32, [_vp, _vp, _i64, _vp]),
     "kasf_tta_merge": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "kasf_eval_metrics": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -681,6 +681,14 @@ int kasf_adamw_step(float* params, const float* grads, float* exp_avg, float* ex
     return 0;
 }
 
+int kasf_gather_clips(const float* x_all, const float* y_all, const int64_t* index, const uint8_t* flip, int64_t n_clips, int32_t batch,
+                      int32_t n_frames, float* x_out, float* y_out, void* stream) {
+    if (!x_all || !index || !x_out || (y_all && !y_out)) return kasf_set_error(2, "null pointer argument");
+    if (n_clips < 1 || n_frames < 1) return kasf_set_error(2, "gather_clips: empty clip set");
+    kasf_launch_gather_clips((hipStream_t)stream, x_all, y_all, index, flip, n_clips, batch, n_frames, x_out, y_out);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
 int kasf_joint_flip(const float* src, float* dst, int64_t rows, void* stream) {
     if (!src || !dst || src == dst) return kasf_set_error(2, "joint_flip: null or aliased pointers");
     kasf_launch_joint_flip((hipStream_t)stream, src, dst, rows);

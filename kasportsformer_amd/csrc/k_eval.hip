@@ -31,6 +31,28 @@ __global__ __launch_bounds__(256) void k_tta_merge(const float* __restrict__ p, 
     }
 }
 
+// Batch assembly from the HBM-resident clip set (data/reader/sp_dataset.py:45-92): out[b] = clips[index[b]], left/right flipped when flip[b].
+// Two arrays share the plan (train: inputs + labels; test: inputs + scaled labels).  Out-of-range indices produce zeros, never a fault.
+__global__ __launch_bounds__(256) void k_gather_clips(const float* __restrict__ xa, const float* __restrict__ ya, const int64_t* __restrict__ index,
+                                                       const unsigned char* __restrict__ flip, int64_t n_clips, int64_t clip_floats, int64_t n,
+                                                       float* __restrict__ xo, float* __restrict__ yo) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t b = i / clip_floats, r = i - b * clip_floats, row = r / 51;
+        const int q = (int)(r - row * 51), j = q / 3, c = q - 3 * j;
+        const int64_t src = index[b];
+        const bool f = flip && flip[b];
+        float vx = 0.0f, vy = 0.0f;
+        if (src >= 0 && src < n_clips) {
+            const int64_t o = src * clip_floats + row * 51 + 3 * (f ? c_flip_src[j] : j) + c;
+            vx = xa[o];
+            if (ya) vy = ya[o];
+            if (f && c == 0) { vx = -vx; vy = -vy; }
+        }
+        xo[i] = vx;
+        if (ya) yo[i] = vy;
+    }
+}
+
 // cyclic Jacobi on a symmetric 3x3 (fp64): A -> eigenvalues on the diagonal, V columns = eigenvectors
 __device__ inline void jacobi3(double A[3][3], double V[3][3]) {
 #pragma unroll
@@ -234,6 +256,12 @@ void kasf_launch_joint_flip(hipStream_t s, const float* src, float* dst, int64_t
 void kasf_launch_tta_merge(hipStream_t s, const float* p, const float* pf, float* out, int64_t rows) {
     if (rows <= 0) return;
     hipLaunchKernelGGL(k_tta_merge, dim3(grid_for(rows * 51)), dim3(256), 0, s, p, pf, out, rows * 51);
+}
+void kasf_launch_gather_clips(hipStream_t s, const float* xa, const float* ya, const int64_t* index, const unsigned char* flip, int64_t n_clips, int B,
+                              int T, float* xo, float* yo) {
+    if (B <= 0) return;
+    const int64_t cf = (int64_t)T * 51;
+    hipLaunchKernelGGL(k_gather_clips, dim3(grid_for(B * cf)), dim3(256), 0, s, xa, ya, index, flip, n_clips, cf, B * cf, xo, yo);
 }
 void kasf_launch_eval_metrics(hipStream_t s, const float* pred, const float* label, const float* factor, const float* res, const int* action, int B, int T,
                               int n_actions, float* mpjpe, float* pmpjpe, float* acc, float* jpe, double* action_sums) {

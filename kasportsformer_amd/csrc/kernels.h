@@ -115,3 +115,5 @@ void kasf_launch_joint_flip(hipStream_t s, const float* src, float* dst, int64_t
 void kasf_launch_tta_merge(hipStream_t s, const float* p, const float* pf, float* out, int64_t rows);
 void kasf_launch_eval_metrics(hipStream_t s, const float* pred, const float* label, const float* factor, const float* res, const int* action, int B, int T,
                               int n_actions, float* mpjpe, float* pmpjpe, float* acc, float* jpe, double* action_sums);
+void kasf_launch_gather_clips(hipStream_t s, const float* xa, const float* ya, const int64_t* index, const unsigned char* flip, int64_t n_clips, int B,
+                              int T, float* xo, float* yo);

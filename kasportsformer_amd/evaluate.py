@@ -101,11 +101,20 @@ class Evaluator:
 
     MAX_ACTIONS = 64
 
-    def __init__(self, num_joints: int = 17, device="cuda"):
+    def __init__(self, num_joints: int = 17, device="cuda", action_names=None):
+        """``action_names``: fixed id table (e.g. ``PackedClips.action_names``) -- required when several ranks evaluate shards and
+        ``reduce()`` sums their tables; without it ids are handed out in first-seen order."""
         if num_joints != 17:
             raise NotImplementedError("17-joint skeleton only")
         self.sums = torch.zeros(self.MAX_ACTIONS, _lib.EVAL_COLS, dtype=torch.float64, device=device)
-        self.action_ids = {}                   # name -> id, first-seen order
+        self.action_ids = {a: i for i, a in enumerate(action_names or ())}     # name -> id
+        if len(self.action_ids) > self.MAX_ACTIONS:
+            raise RuntimeError("too many distinct actions")
+
+    def reduce(self, group=None):
+        """Sums the per-action tables of all ranks (one 11 KB all-reduce per evaluation)."""
+        import torch.distributed as dist
+        dist.all_reduce(self.sums, group=group)
 
     def update(self, predicted_result, joint_label_scaled, joint_factor, joint_action, joint_res):
         """Same five per-batch values the reference's loop handles (``predicted_result`` = output of ``predict_flip_tta``)."""
@@ -115,11 +124,14 @@ class Evaluator:
                     raise RuntimeError("too many distinct actions")
                 self.action_ids[a] = len(self.action_ids)
         ids = torch.tensor([self.action_ids[a] for a in joint_action], dtype=torch.int32)
-        return clip_metrics(predicted_result, joint_label_scaled, joint_factor, torch.as_tensor(np.asarray(joint_res)), ids, self.sums)
+        res = joint_res if torch.is_tensor(joint_res) else torch.as_tensor(np.asarray(joint_res))
+        return clip_metrics(predicted_result, joint_label_scaled, joint_factor, res, ids, self.sums)
 
     def result(self):
         names = list(self.action_ids)
         s = self.sums[:len(names)].cpu().numpy()            # the only device->host copy of the evaluation
+        seen = s[:, 20] > 0
+        names, s = [n for n, k in zip(names, seen) if k], s[seen]
         m_act = s[:, 0] / s[:, 20]
         p_act = s[:, 1] / s[:, 20]
         a_act = s[:, 2] / s[:, 21]
@@ -128,14 +140,16 @@ class Evaluator:
                 "activity_name_sequence": names, "mpjpe_activity": [float(v) for v in m_act], "mpjpe_joint": j_act.mean(axis=0)}
 
 
-def evaluate_one_epoch(model, test_loader, flip: bool = True, device="cuda"):
+def evaluate_one_epoch(model, test_loader, flip: bool = True, device="cuda", action_names=None, distributed: bool = False):
     """evaluate_one_epoch_new (train_and_evaluate_sp.py:27-149) / evaluate_one_epoch (train_and_evaluate_wp.py:25-135): ``test_loader``
     yields (joint_input, joint_label_scaled, joint_factor, joint_action, joint_res) like the reference's test DataLoader."""
     was_training = model.training
     model.eval()
-    ev = Evaluator(device=device)
+    ev = Evaluator(device=device, action_names=action_names)
     for joint_input, joint_label_scaled, joint_factor, joint_action, joint_res in test_loader:
         pred = predict_flip_tta(model, joint_input.to(device), flip)
         ev.update(pred, joint_label_scaled, joint_factor, list(joint_action), joint_res)
     model.train(was_training)
+    if distributed:
+        ev.reduce()
     return ev.result()

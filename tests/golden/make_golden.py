@@ -151,9 +151,64 @@ def eval_fixture(Ref, EC):
     print("wrote eval_L2_T27_B4.npz:", {k: float(v) for k, v in ev.items() if np.ndim(v) == 0})
 
 
+def clips_fixture():
+    """Clip files written by the REFERENCE writers (data/preprocessor/clip_generate_{sp,wp}.py:28-79) and read back by the REFERENCE
+    datasets (data/reader/{sp,wp}_dataset.py:45-92).  The .pkl files are data (dicts of numpy arrays); what the datasets return is
+    stored next to them as the expected result of the product loader."""
+    import importlib
+    import random
+    import shutil
+    import io
+    import contextlib
+    sys.path.insert(0, "/root/reference/data")
+    T = 9
+    out_root = os.path.join(HERE, "clips")
+    shutil.rmtree(out_root, ignore_errors=True)
+    exp = {}
+    for tag, gen_name, ds_mod, ds_cls, set_name in (("sp", "preprocessor.clip_generate_sp", "reader.sp_dataset", "SportsPose3DDataset", f"SPgt-{T}"),
+                                                    ("wp", "preprocessor.clip_generate_wp", "reader.wp_dataset", "WorldPose3DDataset", f"WPdete-{T}")):
+        gen = importlib.import_module(gen_name)
+        ds = getattr(importlib.import_module(ds_mod), ds_cls)
+        n_train, n_test = 5, 4
+        x, y = O.synthetic_clips(n_train + n_test, T, seed=31 if tag == "sp" else 32, res=(1312, 1216) if tag == "sp" else (1920, 1080),
+                                 det_conf=(tag == "wp"))
+        y_abs = y + torch.randn(n_train + n_test, T, 1, 3, generator=torch.Generator().manual_seed(5)) * 0.1   # labels before root-relative
+        label_scaled, factor, res, actions = O.synthetic_test_extras(y[n_train:], seed=33, res_choices=((1312, 1216), (1216, 1936)) if tag == "sp" else ((1920, 1080),))
+        root = os.path.join(out_root, set_name)
+        with contextlib.redirect_stderr(io.StringIO()):
+            gen.save_clips_train(root_path=root, input_set=x[:n_train].numpy(), label_set=y_abs[:n_train].numpy())
+            kw = dict(root_path=root, input_set=x[n_train:].numpy(), label_set=y_abs[n_train:].numpy(), label_scaled_set=label_scaled.numpy().astype(np.float64),
+                      action_set=[[a] * T for a in actions], factor_set=factor.numpy().astype(np.float64), hw_set=res.numpy().astype(np.float64))
+            if tag == "sp":
+                kw["envtag_set"] = [["indoors" if i % 2 else "outdoors"] * T for i in range(n_test)]
+            gen.save_clips_test(**kw)
+        args = types.SimpleNamespace(model_name="KASportsFormer", input_channel_number=3, data_root=out_root, flip=False, clip_set_name=set_name)
+        tr = ds(args, "train")
+        exp[f"{tag}_train_x"] = np.stack([tr[i][0].numpy() for i in range(len(tr))])
+        exp[f"{tag}_train_y"] = np.stack([tr[i][1].numpy() for i in range(len(tr))])
+        args.flip = True
+        keep = random.random
+        random.random = lambda: 0.9                                  # "> 0.5": every clip flipped
+        trf = ds(args, "train")
+        exp[f"{tag}_train_x_flip"] = np.stack([trf[i][0].numpy() for i in range(len(trf))])
+        exp[f"{tag}_train_y_flip"] = np.stack([trf[i][1].numpy() for i in range(len(trf))])
+        random.random = keep
+        te = ds(args, "test")
+        items = [te[i] for i in range(len(te))]
+        exp[f"{tag}_test_x"] = np.stack([it[0].numpy() for it in items])
+        exp[f"{tag}_test_label_scaled"] = np.stack([np.asarray(it[1]) for it in items])
+        exp[f"{tag}_test_factor"] = np.stack([np.asarray(it[2]) for it in items])
+        exp[f"{tag}_test_action"] = np.array([it[3] for it in items])
+        exp[f"{tag}_test_res"] = np.stack([np.asarray(it[4]) for it in items])
+    np.savez_compressed(os.path.join(HERE, "clips_expected.npz"), **exp)
+    print("wrote clips/ and clips_expected.npz:", {k: v.shape for k, v in exp.items()})
+
+
 def main():
     Ref, bone_decomposer, LC, EC = import_reference()
     torch.set_num_threads(8)
+    if sys.argv[1:] == ["clips"]:                            # only the clip-file fixture
+        return clips_fixture()
     if sys.argv[1:] == ["eval"]:                             # only the evaluation fixture
         return eval_fixture(Ref, EC)
 
@@ -202,6 +257,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "functional.npz"), **fx)
     print("wrote functional.npz")
     eval_fixture(Ref, EC)
+    clips_fixture()
 
 
 if __name__ == "__main__":
