@@ -1,0 +1,88 @@
+"""Checkpoint interchange with the reference's scripts (utils/utilities.py:110-118, train_and_evaluate_sp.py:285-301): host logic."""
+import os
+
+import pytest
+import torch
+
+import kasportsformer_amd as K
+from oracle import kasf_oracle as O
+
+
+def _pair():
+    oracle = O.KASportsFormerOracle(n_layers=1, num_heads=8, n_frames=9)
+    sd = O.name_seeded_fill(oracle.state_dict())
+    oracle.load_state_dict(sd)
+    model = K.KASportsFormer(n_layers=1, num_heads=8, n_frames=9, compute_dtype="fp32")
+    model.load_state_dict(sd)
+    return oracle, model
+
+
+def test_fused_adamw_state_loads_into_torch_adamw_and_back(tmp_path):
+    oracle, model = _pair()
+    opt = K.FusedAdamW(model, lr=3e-4, weight_decay=0.02)
+    g = torch.Generator().manual_seed(0)
+    opt.exp_avg.copy_(torch.randn(opt.exp_avg.shape, generator=g))
+    opt.exp_avg_sq.copy_(torch.rand(opt.exp_avg_sq.shape, generator=g))
+    mask = torch.zeros_like(opt.exp_avg)                     # the live region is padded to the update kernel's vector width
+    for _, off, numel, _ in model._live:
+        mask[off:off + numel] = 1
+    opt.exp_avg.mul_(mask)
+    opt.exp_avg_sq.mul_(mask)
+    opt.step_index = 7
+    path = tmp_path / "ck.pth"
+    K.checkpoint_save(str(path), epoch=4, lr=3e-4, optimizer=opt, model=model, min_mpjpe=51.5, wandb_id="abc123")
+    ck = torch.load(str(path), map_location="cpu", weights_only=True)
+    assert set(ck) == {"epoch", "learning_rate", "optimizer", "model", "min_mpjpe", "wandb_id"} and ck["epoch"] == 5
+    assert all(k.startswith("module.") for k in ck["model"]) and len(ck["model"]) == len(oracle.state_dict())
+    # the reference side: DataParallel-style keys load strict=True, and a real torch AdamW accepts the optimiser entry
+    oracle.load_state_dict(K.strip_module_prefix(ck["model"]), strict=True)
+    topt = torch.optim.AdamW(filter(lambda p: p.requires_grad, oracle.parameters()), lr=1.0, weight_decay=0.5)
+    topt.load_state_dict(ck["optimizer"])
+    assert topt.param_groups[0]["lr"] == 3e-4 and topt.param_groups[0]["weight_decay"] == 0.02
+    names = [n for n, _ in oracle.named_parameters()]
+    dead = {i for i, n in enumerate(names) if "norm1_limb" in n and ".bone_" not in n}
+    assert len(dead) == 8
+    assert set(ck["optimizer"]["state"]) == set(range(len(names))) - dead             # torch keeps no state for grad-None parameters
+    # ... and back: torch's state_dict -> a fresh FusedAdamW
+    _, model2 = _pair()
+    opt2 = K.FusedAdamW(model2)
+    info = K.checkpoint_load(str(path), model2, opt2, resume=True)
+    assert info == {"epoch": 5, "lr": 3e-4, "min_mpjpe": 51.5, "wandb_run_id": "abc123"}
+    assert opt2.step_index == 7 and torch.equal(opt2.exp_avg, opt.exp_avg) and torch.equal(opt2.exp_avg_sq, opt.exp_avg_sq)
+    assert opt2.param_groups[0]["lr"] == 3e-4 and opt2.param_groups[0]["weight_decay"] == 0.02
+    for (n, a), (_, b) in zip(model.state_dict().items(), model2.state_dict().items()):
+        assert torch.equal(a, b), n
+
+
+def test_reference_written_checkpoint_resumes_here(tmp_path):
+    """A file as the reference writes it: DataParallel prefix, torch AdamW state after real steps, reference key names."""
+    oracle, model = _pair()
+    topt = torch.optim.AdamW(filter(lambda p: p.requires_grad, oracle.parameters()), lr=5e-4, weight_decay=0.01)
+    x, y = O.synthetic_clips(2, 9)
+    for _ in range(2):
+        topt.zero_grad()
+        O.loss_total(oracle(x), y)[0].backward()
+        topt.step()
+    path = tmp_path / "ref_latest.pth"
+    torch.save({"epoch": 12, "learning_rate": 4.05e-4, "optimizer": topt.state_dict(), "model": {"module." + k: v for k, v in oracle.state_dict().items()},
+                "min_mpjpe": 33.25, "wandb_id": "run9"}, str(path))
+    opt = K.FusedAdamW(model)
+    info = K.checkpoint_load(str(path), model, opt, resume=True)
+    assert info["epoch"] == 12 and info["lr"] == 4.05e-4 and info["min_mpjpe"] == 33.25 and info["wandb_run_id"] == "run9"
+    assert opt.step_index == 2
+    for n, p in model.named_parameters():
+        assert torch.equal(p.detach(), dict(oracle.named_parameters())[n].detach()), n
+    st = topt.state_dict()["state"]
+    for i, (p, off, numel, shape) in enumerate(model._live[:50]):
+        slot = [id(q) for q in model.parameters()].index(id(p))
+        assert torch.equal(opt.exp_avg[off:off + numel].view(shape), st[slot]["exp_avg"])
+    # evaluation-style load (no resume) leaves the optimiser alone
+    opt3 = K.FusedAdamW(model)
+    assert K.checkpoint_load(str(path), model)["epoch"] == 0 and opt3.step_index == 0
+    with pytest.raises(Exception, match="checkpoint path is wrong"):
+        K.checkpoint_load(str(tmp_path / "missing.pth"), model)
+    bad = torch.load(str(path), weights_only=True)
+    bad["model"].pop("module.head.bias")
+    torch.save(bad, str(tmp_path / "bad.pth"))
+    with pytest.raises(RuntimeError):
+        K.checkpoint_load(str(tmp_path / "bad.pth"), model)                           # strict=True like the reference
