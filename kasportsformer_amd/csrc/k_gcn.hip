@@ -57,83 +57,105 @@ __global__ __launch_bounds__(256) void k_gcn_agg_spatial(const T* __restrict__ u
     if (threadIdx.x < KASF_J * 2) atomicAdd(stats + threadIdx.x, (double)sStat[threadIdx.x]);
 }
 
-// ------------------------------------------------------------------ temporal aggregate: one workgroup per (b, joint) track
+// ------------------------------------------------------------------ temporal aggregate: persistent workgroups, one (b, joint) track at a time
+// S = xn xn^T runs on the matrix cores (bf16: v_mfma_f32_16x16x32_bf16 on the stored bf16 rows, exact products, fp32 accumulate;
+// fp32 mode: the exact v_mfma_f32_16x16x4_f32 chain).  Both operands are the SAME rows in the same k order, so S is bitwise symmetric.
+// BatchNorm sums are kept in LDS across all tracks of the workgroup and leave it as ONE fp64 atomic per frame at the end.
+template <int L> constexpr int agg_lp() { return (L + 15) / 16 * 16; }
 template <typename T, int L>
 __global__ __launch_bounds__(256) void k_gcn_agg_temporal(const T* __restrict__ uv, const T* __restrict__ xn, T* __restrict__ y,
-                                                          uint32_t* __restrict__ mask, double* __restrict__ stats, int Tn, int kth) {
+                                                          uint32_t* __restrict__ mask, double* __restrict__ stats, int Tn, int kth, int n_tracks) {
+    constexpr int LP = agg_lp<L>(), NTL = LP / 16, EPC = Tile<T>::EPC, CPR = Tile<T>::CPR;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* sX = reinterpret_cast<float*>(smem);         // [L][SX_LD]  LN(x) rows of the track
-    float* sV = sX + L * SX_LD;                         // [L][SX_LD]  V rows
-    float* sS = sV + L * SX_LD;                         // [L][L+1]    similarity
-    float* sDinv = sS + L * (L + 1);                    // [L]
-    float* sStat = sDinv + L;                           // [L][2]
+    T* sX = reinterpret_cast<T*>(smem);                 // [LP][128] swizzled tile, LN(x) rows of the track (rows >= L stay zero)
+    T* sV = sX + LP * 128;                              // [L][128]  V rows
+    float* sS = reinterpret_cast<float*>(sV + L * 128); // [L][LP+1] similarity
+    float* sDinv = sS + L * (LP + 1);                   // [L]
+    float* sStat = sDinv + L;                           // [L][2]    running BatchNorm sums of this workgroup
     uint32_t* sMask = reinterpret_cast<uint32_t*>(sStat + 2 * L);   // [L][MASK_W]
-    const int G = blockIdx.x, b = G / KASF_J, j = G % KASF_J;
-    auto tok = [&](int r) { return ((int64_t)b * Tn + r) * KASF_J + j; };
-    for (int idx = threadIdx.x; idx < L * 16; idx += 256) {
-        const int r = idx >> 4, sub = idx & 15;
-        float a[8], v[8];
-        load8(xn + tok(r) * 128 + sub * 8, a);
-        load8(uv + tok(r) * 256 + 128 + sub * 8, v);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { sX[r * SX_LD + sub * 8 + e] = a[e]; sV[r * SX_LD + sub * 8 + e] = v[e]; }
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
+    for (int idx = threadIdx.x; idx < (LP - L) * CPR; idx += 256) {
+        const int r = L + idx / CPR, ch = idx % CPR;
+        float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if constexpr (EPC == 8) tile_store8(sX, r, ch * 8, z);
+        else { float z4[4] = {0.f, 0.f, 0.f, 0.f}; store4(sX + Tile<float>::chunk_off(r, ch), z4); }
     }
     if (threadIdx.x < 2 * L) sStat[threadIdx.x] = 0.f;
-    __syncthreads();
-    // similarity: every (r,c) with the same k order => bitwise symmetric
-    for (int idx = threadIdx.x; idx < L * L; idx += 256) {
-        const int r = idx / L, c = idx % L;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-#pragma unroll 8
-        for (int k = 0; k < 128; k += 4) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(sX + r * SX_LD + k), bb = *reinterpret_cast<const f32x4*>(sX + c * SX_LD + k);
-            s0 += a[0] * bb[0]; s1 += a[1] * bb[1]; s2 += a[2] * bb[2]; s3 += a[3] * bb[3];
+    for (int G = blockIdx.x; G < n_tracks; G += gridDim.x) {
+        const int b = G / KASF_J, j = G % KASF_J;
+        auto tok = [&](int r) { return ((int64_t)b * Tn + r) * KASF_J + j; };
+        __syncthreads();                                // previous track fully consumed (and the zero fill / sStat init visible)
+        for (int idx = threadIdx.x; idx < L * CPR; idx += 256) {     // raw 16-byte copies: no conversion on the way in
+            const int r = idx / CPR, ch = idx % CPR;
+            *reinterpret_cast<f32x4*>(sX + Tile<T>::chunk_off(r, ch)) = *reinterpret_cast<const f32x4*>(xn + tok(r) * 128 + ch * EPC);
+            *reinterpret_cast<f32x4*>(sV + r * 128 + ch * EPC) = *reinterpret_cast<const f32x4*>(uv + tok(r) * 256 + 128 + ch * EPC);
         }
-        sS[r * (L + 1) + c] = (s0 + s1) + (s2 + s3);
-    }
-    __syncthreads();
-    // k-th largest per row -> adjacency bits and degree
-    for (int r = threadIdx.x; r < L; r += 256) {
-        float top[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-        for (int c = 0; c < L; ++c) {
-            float v = sS[r * (L + 1) + c];
+        __syncthreads();
+        for (int t = w; t < NTL * NTL; t += 4) {        // 16x16 tiles of S over the 4 waves
+            const int tn = t / NTL, tm = t % NTL;
+            f32x4 acc[1][1];
+            zero_acc(acc);
+            mma_k128<1, 1>(sX, tn * 16, sX, tm * 16, acc);
+            const int r = tm * 16 + li;                 // acc[r4] = S[row r][col tn*16 + 4*lg + r4]
+            if (r < L) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (v > top[e]) { const float t = top[e]; top[e] = v; v = t; }
+                for (int q = 0; q < 4; ++q) {
+                    const int c = tn * 16 + 4 * lg + q;
+                    if (c < L) sS[r * (LP + 1) + c] = acc[0][0][q];
+                }
             }
         }
-        const float thr = kth <= 1 ? top[0] : (kth == 2 ? top[1] : (kth == 3 ? top[2] : top[3]));
-        uint32_t w[MASK_W] = {0u, 0u, 0u};
-        int deg = 0;
-        for (int c = 0; c < L; ++c) {
-            if (sS[r * (L + 1) + c] >= thr) { w[c >> 5] |= 1u << (c & 31); ++deg; }
-        }
+        __syncthreads();
+        // k-th largest per row -> adjacency bits and degree (graph.py:104-112: ties kept)
+        for (int r = threadIdx.x; r < L; r += 256) {
+            float top[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            for (int c = 0; c < L; ++c) {
+                float v = sS[r * (LP + 1) + c];
 #pragma unroll
-        for (int e = 0; e < MASK_W; ++e) { sMask[r * MASK_W + e] = w[e]; mask[((int64_t)G * L + r) * MASK_W + e] = w[e]; }
-        sDinv[r] = 1.0f / sqrtf((float)deg);
-    }
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < L * 16; idx += 256) {
-        const int r = idx >> 4, sub = idx & 15;
-        float acc[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-        for (int c = 0; c < L; ++c) {
-            if ((sMask[r * MASK_W + (c >> 5)] >> (c & 31)) & 1u) {
-                const float w = sDinv[r] * sDinv[c];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] += w * sV[c * SX_LD + sub * 8 + e];
+                for (int e = 0; e < 4; ++e) {
+                    if (v > top[e]) { const float t = top[e]; top[e] = v; v = t; }
+                }
             }
-        }
-        float u[8];
-        load8(uv + tok(r) * 256 + sub * 8, u);
-        float s1 = 0.f, s2 = 0.f;
+            const float thr = kth <= 1 ? top[0] : (kth == 2 ? top[1] : (kth == 3 ? top[2] : top[3]));
+            uint32_t wd[MASK_W] = {0u, 0u, 0u};
+            int deg = 0;
+            for (int c = 0; c < L; ++c) {
+                if (sS[r * (LP + 1) + c] >= thr) { wd[c >> 5] |= 1u << (c & 31); ++deg; }
+            }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { acc[e] += u[e]; const float q = to_f(from_f<T>(acc[e])); s1 += q; s2 += q * q; }
-        store8(y + tok(r) * 128 + sub * 8, acc);
-        s1 = reduce16(s1);
-        s2 = reduce16(s2);
-        if (sub == 0) { atomicAdd(&sStat[r * 2], s1); atomicAdd(&sStat[r * 2 + 1], s2); }
+            for (int e = 0; e < MASK_W; ++e) { sMask[r * MASK_W + e] = wd[e]; mask[((int64_t)G * L + r) * MASK_W + e] = wd[e]; }
+            sDinv[r] = 1.0f / sqrtf((float)deg);
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < L * 16; idx += 256) {
+            const int r = idx >> 4, sub = idx & 15;
+            float acc[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+            const float dr = sDinv[r];
+#pragma unroll
+            for (int wi = 0; wi < (L + 31) / 32; ++wi) {
+                uint32_t bits = sMask[r * MASK_W + wi];
+                while (bits) {                           // visit set bits only (>= 4 neighbours per row, rarely more)
+                    const int c = wi * 32 + __builtin_ctz(bits);
+                    bits &= bits - 1;
+                    const float wgt = dr * sDinv[c];
+                    float v[8];
+                    load8(sV + c * 128 + sub * 8, v);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e] += wgt * v[e];
+                }
+            }
+            float u[8];
+            load8(uv + tok(r) * 256 + sub * 8, u);
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { acc[e] += u[e]; const float q = to_f(from_f<T>(acc[e])); s1 += q; s2 += q * q; }
+            store8(y + tok(r) * 128 + sub * 8, acc);
+            s1 = reduce16(s1);
+            s2 = reduce16(s2);
+            if (sub == 0) { atomicAdd(&sStat[r * 2], s1); atomicAdd(&sStat[r * 2 + 1], s2); }
+        }
     }
     __syncthreads();
     if (threadIdx.x < 2 * L) atomicAdd(stats + threadIdx.x, (double)sStat[threadIdx.x]);
@@ -330,13 +352,18 @@ inline unsigned ew_grid(int64_t M) {
 template <typename K> void set_smem(K k, size_t bytes) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
-template <int L> constexpr size_t agg_smem() { return (2 * L * SX_LD + L * (L + 1) + L + 2 * L) * sizeof(float) + L * MASK_W * sizeof(uint32_t); }
+template <typename T, int L> constexpr size_t agg_smem() {
+    return (size_t)(agg_lp<L>() + L) * 128 * sizeof(T) + (L * (agg_lp<L>() + 1) + L + 2 * L) * sizeof(float) + L * MASK_W * sizeof(uint32_t);
+}
 template <int L> constexpr size_t bwd2_smem() { return (L * SX_LD + L) * sizeof(float) + L * MASK_W * sizeof(uint32_t); }
 
 template <typename T, int L>
 void agg_temporal_TL(hipStream_t s, const void* uv, const void* xn, void* y, uint32_t* mask, double* stats, int B, int Tn) {
-    set_smem(k_gcn_agg_temporal<T, L>, agg_smem<L>());
-    hipLaunchKernelGGL((k_gcn_agg_temporal<T, L>), dim3(B * KASF_J), dim3(256), agg_smem<L>(), s, (const T*)uv, (const T*)xn, (T*)y, mask, stats, Tn, 4);
+    const size_t sh = agg_smem<T, L>();
+    set_smem(k_gcn_agg_temporal<T, L>, sh);
+    const int tracks = B * KASF_J, per = (tracks + 1023) / 1024;         // <= 1024 persistent workgroups, equal track counts
+    hipLaunchKernelGGL((k_gcn_agg_temporal<T, L>), dim3((tracks + per - 1) / per), dim3(256), sh, s, (const T*)uv, (const T*)xn, (T*)y, mask,
+                       stats, Tn, 4, tracks);
 }
 template <typename T, int L>
 void bwd2_temporal_TL(hipStream_t s, const void* r, const void* y, const float* coef, const uint32_t* mask, void* duv, int B, int Tn) {
@@ -348,7 +375,9 @@ template <typename T>
 void agg_fwd_T(hipStream_t s, const void* uv, const void* xn, void* y, uint32_t* mask, double* stats, int B, int Tn, int mode) {
     const int64_t M = (int64_t)B * Tn * KASF_J;
     if (mode == 0) {
-        hipLaunchKernelGGL(k_gcn_agg_spatial<T>, dim3(ew_grid(M)), dim3(256), 0, s, (const T*)uv, (T*)y, stats, M);
+        unsigned grid = ew_grid(M);
+        if (grid > 1024) grid = 1024;                    // every workgroup ends with 34 same-address fp64 atomics
+        hipLaunchKernelGGL(k_gcn_agg_spatial<T>, dim3(grid), dim3(256), 0, s, (const T*)uv, (T*)y, stats, M);
     } else if (Tn == 27) agg_temporal_TL<T, 27>(s, uv, xn, y, mask, stats, B, Tn);
     else if (Tn == 81) agg_temporal_TL<T, 81>(s, uv, xn, y, mask, stats, B, Tn);
     else if (Tn == 9) agg_temporal_TL<T, 9>(s, uv, xn, y, mask, stats, B, Tn);
