@@ -138,9 +138,11 @@ int kasf_op_mlp_bwd_fused(const void* x, const void* g, const float* ln_g, const
  * kernel (bitwise reproducible); NULL -> fp32 atomics on dw. */
 int kasf_op_wgrad(int32_t dtype, const void* g, int32_t N, const void* x, int32_t K, const float* ln_g, const float* ln_b, float* dw, float* dbias,
                   int64_t M, float* partial, int64_t partial_floats, void* stream);
-/* g_in = [resid] + LNbwd(dY Wt^T [+ add]): dY [M,Kd], Wt [128,Kd] */
+/* out = [resid] + [out, if accumulate] + LNbwd(dY Wt^T [+ dxn_add]): dY [M,Kd], Wt [128,Kd]; dgamma/dbeta are accumulated into;
+ * xn_out (optional, with beta) receives LN(x), the operand of the matching weight-gradient GEMM */
 int kasf_op_dgrad_lnbwd(int32_t dtype, const void* dy, int32_t Kd, const void* wt, const void* dxn_add, const void* x, const float* gamma,
-                        const void* resid, void* out, int32_t accumulate, float* dgamma, float* dbeta, int64_t M, void* stream);
+                        const void* resid, void* out, int32_t accumulate, float* dgamma, float* dbeta, int64_t M, void* xn_out, const float* beta,
+                        void* stream);
 /* attention core (selfattention.py:18-41): q [*,ldq], k/v [*,ldkv] token-major; mode 0 spatial, 1 temporal */
 int kasf_op_attention_fwd(int32_t dtype, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, void* o, int32_t batch, int32_t n_frames,
                           int32_t mode, void* stream);

@@ -61,7 +61,7 @@ SIGNATURES = {
     "kasf_op_mlp_bwd": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "kasf_op_mlp_bwd_fused": (_i32, [_vp] * 17 + [_i64, _vp]),
     "kasf_op_wgrad": (_i32, [_i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp]),
-    "kasf_op_dgrad_lnbwd": (_i32, [_i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i64, _vp]),
+    "kasf_op_dgrad_lnbwd": (_i32, [_i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i64, _vp, _vp, _vp]),
     "kasf_op_attention_fwd": (_i32, [_i32, _vp, _i64, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _vp]),
     "kasf_op_attention_bwd": (_i32, [_i32, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "kasf_op_cast": (_i32, [_i32, _vp, _vp, _i64, _i32, _vp]),

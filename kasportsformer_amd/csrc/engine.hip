@@ -755,10 +755,12 @@ int kasf_op_wgrad(int32_t dtype, const void* g, int32_t N, const void* x, int32_
     return 0;
 }
 int kasf_op_dgrad_lnbwd(int32_t dtype, const void* dy, int32_t Kd, const void* wt, const void* dxn_add, const void* x, const float* gamma,
-                        const void* resid, void* out, int32_t accumulate, float* dgamma, float* dbeta, int64_t M, void* stream) {
+                        const void* resid, void* out, int32_t accumulate, float* dgamma, float* dbeta, int64_t M, void* xn_out, const float* beta,
+                        void* stream) {
     OP_DT_CHECK(dtype);
     if (Kd % 128 != 0) return kasf_set_error(2, "Kd must be a multiple of 128");
-    kasf_launch_dgrad_lnbwd(dtype, (hipStream_t)stream, dy, Kd, wt, dxn_add, x, gamma, resid, out, accumulate, dgamma, dbeta, M);
+    if (xn_out != nullptr && beta == nullptr) return kasf_set_error(2, "xn_out needs beta");
+    kasf_launch_dgrad_lnbwd(dtype, (hipStream_t)stream, dy, Kd, wt, dxn_add, x, gamma, resid, out, accumulate, dgamma, dbeta, M, xn_out, beta);
     HIPCHK(hipGetLastError());
     return 0;
 }

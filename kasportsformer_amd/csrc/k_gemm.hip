@@ -525,6 +525,7 @@ static void dgrad_lnbwd_T(hipStream_t s, const void* dY, int Kd, const void* Wt,
 }
 void kasf_launch_dgrad_lnbwd(int dt, hipStream_t s, const void* dY, int Kd, const void* Wt, const void* dxn_add, const void* X, const float* gamma,
                              const void* resid, void* out, int accumulate, float* dgamma, float* dbeta, int64_t M, void* xn_out, const float* beta) {
+    if (dt == KASF_BF16 && kasf_launch_dgrad_r(s, dY, Kd, Wt, dxn_add, X, gamma, resid, out, accumulate, dgamma, dbeta, M, xn_out, beta)) return;
     DT_DISPATCH(dt, (dgrad_lnbwd_T<float>(s, dY, Kd, Wt, dxn_add, X, gamma, resid, out, accumulate, dgamma, dbeta, M, xn_out, beta)),
                 (dgrad_lnbwd_T<bf16>(s, dY, Kd, Wt, dxn_add, X, gamma, resid, out, accumulate, dgamma, dbeta, M, xn_out, beta)));
 }

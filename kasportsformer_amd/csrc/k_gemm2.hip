@@ -1,0 +1,195 @@
+// Second-generation row-GEMM kernels (bf16): persistent workgroups, weights resident in registers for the whole launch,
+// token tiles streamed through an LDS ring by LDS-direct loads issued two tiles ahead (counted vmcnt, raw barriers).
+// Per tile there is no L2 traffic besides the tokens themselves, so these kernels are bound by the HBM stream.
+//
+//   k_dgrad_r<KC,...>   out = [resid] + [out] + LNbwd( dY[M x 128KC] . Wt[128 x 128KC]^T [+ add] ; x, gamma ),
+//                       dgamma/dbeta reductions, optional LN(x) output for the matching weight-gradient GEMM
+//                       (the data gradient of every LN-fused linear of the mixers: qkv, q, kv, U|V)
+#include "common.h"
+#include "kernels.h"
+#include "tile_ops.h"
+
+namespace {
+
+constexpr int R_BM = 32, R_NW = 8, R_THR = R_NW * 64;
+constexpr int R_TILE = R_BM * 128;                      // elements of one [32][128] tile
+
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ bf16x8 tok_frag(const bf16* s, int row, int ks) {
+    const int g = (threadIdx.x & 63) >> 4;
+    return *reinterpret_cast<const bf16x8*>(s + Tile<bf16>::chunk_off(row, 4 * ks + g));
+}
+
+// Ring slot layout (tiles of [32][128] bf16, 8 KB each): dY chunk 0..KC-1 | x | resid? | add? | out(accumulate)?
+template <int KC, bool RESID, bool ADD, bool ACC, bool XN, int RING>
+__global__ __launch_bounds__(R_THR) void k_dgrad_r(const bf16* __restrict__ dY, const bf16* __restrict__ Wt, const bf16* __restrict__ dxn_add,
+                                                   const bf16* __restrict__ X, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                   const bf16* __restrict__ resid, bf16* __restrict__ out, float* __restrict__ dgamma,
+                                                   float* __restrict__ dbeta, bf16* __restrict__ xn_out, int64_t M) {
+    constexpr int Kd = 128 * KC;
+    constexpr int NSTREAM = KC + 1 + (RESID ? 1 : 0) + (ADD ? 1 : 0) + (ACC ? 1 : 0);     // LDS-direct loads per wave per tile
+    constexpr int SLOT = NSTREAM * R_TILE;
+    constexpr int O_X = KC * R_TILE, O_RES = O_X + R_TILE, O_ADD = O_RES + (RESID ? R_TILE : 0), O_ACC = O_ADD + (ADD ? R_TILE : 0);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* sRing = reinterpret_cast<bf16*>(smem);        // [RING][SLOT]
+    bf16* sD = sRing + RING * SLOT;                     // [32][128] dxn of the current tile
+    float* sRed = reinterpret_cast<float*>(smem);       // [2][32][128] end-of-kernel dgamma/dbeta partials: reuses the (then dead) ring
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4, sub = lane & 15, rl = threadIdx.x >> 4;
+    const int64_t ntiles_total = (M + R_BM - 1) / R_BM;
+    const int64_t per = (ntiles_total + gridDim.x - 1) / gridDim.x;
+    const int64_t tile0 = (int64_t)blockIdx.x * per;
+    int64_t ntiles = ntiles_total - tile0;
+    if (ntiles > per) ntiles = per;
+    if (ntiles <= 0) return;
+
+    bf16x8 wf[4 * KC];                                  // this wave's 16 output features over the whole reduction axis
+#pragma unroll
+    for (int ks = 0; ks < 4 * KC; ++ks) wf[ks] = *reinterpret_cast<const bf16x8*>(Wt + (int64_t)(16 * w + i) * Kd + 32 * ks + 8 * g);
+    float gm[8], bt[8], dg[8], db[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { gm[e] = gamma[sub * 8 + e]; bt[e] = XN ? beta[sub * 8 + e] : 0.f; dg[e] = 0.f; db[e] = 0.f; }
+
+    auto issue = [&](int64_t t) {                        // exactly NSTREAM LDS-direct loads per wave per call
+        const int64_t tt = t < ntiles ? t : ntiles - 1;
+        const int64_t row0 = (tile0 + tt) * R_BM;
+        const int nvalid = (int)((M - row0) < R_BM ? (M - row0) : R_BM);
+        bf16* slot = sRing + (int)(t % RING) * SLOT;
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) stage_tile_async<bf16, R_BM, R_THR>(slot + kc * R_TILE, dY + row0 * Kd + kc * 128, Kd, nvalid);
+        stage_tile_async<bf16, R_BM, R_THR>(slot + O_X, X + row0 * 128, 128, nvalid);
+        if (RESID) stage_tile_async<bf16, R_BM, R_THR>(slot + O_RES, resid + row0 * 128, 128, nvalid);
+        if (ADD) stage_tile_async<bf16, R_BM, R_THR>(slot + O_ADD, dxn_add + row0 * 128, 128, nvalid);
+        if (ACC) stage_tile_async<bf16, R_BM, R_THR>(slot + O_ACC, out + row0 * 128, 128, nvalid);
+    };
+    issue(0);
+    if (RING == 3) { issue(1); wait_async_le<NSTREAM>(); }   // tile 0 landed, tile 1 in flight
+    for (int64_t t = 0; t < ntiles; ++t) {
+        const bf16* slot = sRing + (int)(t % RING) * SLOT;
+        const int64_t row0 = (tile0 + t) * R_BM;
+        if (RING == 2) wait_async();
+        barrier_keep_async();                            // B1: tile t visible to every wave; everyone is past tile t-1
+        if (RING == 2) issue(t + 1);
+        {   // ---- GEMM: 16 features x 32 tokens per wave ----
+            f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            bf16x8 fb[2][2];
+            fb[0][0] = tok_frag(slot, i, 0);
+            fb[0][1] = tok_frag(slot, 16 + i, 0);
+#pragma unroll
+            for (int ks = 0; ks < 4 * KC; ++ks) {
+                if (ks + 1 < 4 * KC) {
+                    const bf16* nx = slot + ((ks + 1) >> 2) * R_TILE;
+                    fb[(ks + 1) & 1][0] = tok_frag(nx, i, (ks + 1) & 3);
+                    fb[(ks + 1) & 1][1] = tok_frag(nx, 16 + i, (ks + 1) & 3);
+                }
+                acc[0] = mfma16(wf[ks], fb[ks & 1][0], acc[0]);
+                acc[1] = mfma16(wf[ks], fb[ks & 1][1], acc[1]);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                float v[4] = {acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3]};
+                store4(sD + Tile<bf16>::off4(mt * 16 + i, 16 * w + 4 * g), v);
+            }
+        }
+        barrier_keep_async();                            // B2: the [32][128] dxn tile is complete
+        if (RING == 3) issue(t + 2);                     // slot (t+2)%3 held tile t-1, which everyone finished before B1
+        {   // ---- LayerNorm backward: one 16-lane group per token row ----
+            const int64_t row = row0 + rl;
+            float d[8], x[8], o[8];
+            tile_load8(sD, rl, sub * 8, d);
+            tile_load8(slot + O_X, rl, sub * 8, x);
+            if (ADD) {
+                float a[8];
+                tile_load8(slot + O_ADD, rl, sub * 8, a);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) d[e] += a[e];
+            }
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += x[e];
+            const float mean = reduce16(s) * (1.0f / 128.0f);
+            float q = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { x[e] -= mean; q += x[e] * x[e]; }
+            const float rstd = rsqrtf(reduce16(q) * (1.0f / 128.0f) + KASF_LN_EPS);
+            float xn[8];
+            float s1 = 0.f, s2 = 0.f;
+            const bool live = row < M;                   // rows past M are clamped copies of the last row: keep them out of the sums
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (XN) xn[e] = x[e] * rstd * gm[e] + bt[e];
+                x[e] *= rstd;
+                if (live) { dg[e] += d[e] * x[e]; db[e] += d[e]; }
+                d[e] *= gm[e];
+                s1 += d[e];
+                s2 += d[e] * x[e];
+            }
+            s1 = reduce16(s1) * (1.0f / 128.0f);
+            s2 = reduce16(s2) * (1.0f / 128.0f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = rstd * (d[e] - s1 - x[e] * s2);
+            if (RESID) {
+                float a[8];
+                tile_load8(slot + O_RES, rl, sub * 8, a);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] += a[e];
+            }
+            if (ACC) {
+                float a[8];
+                tile_load8(slot + O_ACC, rl, sub * 8, a);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] += a[e];
+            }
+            // tile t+1 has landed when only this wave's youngest NSTREAM requests (tile t+2) are outstanding.  Waiting BEFORE this
+            // tile's stores keeps them out of that count: they get the whole next tile to drain.
+            if (RING == 3) wait_async_le<NSTREAM>();
+            if (live) {
+                store8(out + row * 128 + sub * 8, o);
+                if (XN) store8(xn_out + row * 128 + sub * 8, xn);
+            }
+        }
+    }
+    wait_async();
+    __syncthreads();
+    // ---- dgamma / dbeta: 32 row groups -> one atomic per channel per workgroup ----
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sRed[rl * 128 + sub * 8 + e] = dg[e]; sRed[R_TILE + rl * 128 + sub * 8 + e] = db[e]; }
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        const int c = threadIdx.x & 127, which = threadIdx.x >> 7;
+        float s = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) s += sRed[which * R_TILE + k * 128 + c];
+        atomicAdd((which == 0 ? dgamma : dbeta) + c, s);
+    }
+}
+
+template <int KC, bool RESID, bool ADD, bool ACC, bool XN>
+void launch_dgrad_r(hipStream_t s, const void* dY, const void* Wt, const void* add, const void* X, const float* gamma, const float* beta, const void* resid,
+                    void* out, float* dgamma, float* dbeta, void* xn_out, int64_t M) {
+    constexpr int NSTREAM = KC + 1 + (RESID ? 1 : 0) + (ADD ? 1 : 0) + (ACC ? 1 : 0);
+    constexpr size_t fixed = (size_t)R_TILE * 2;                                        // sD (the end-of-kernel reduction reuses the ring: >= 32 KB)
+    constexpr bool ring3 = 3 * NSTREAM * R_TILE * 2 + fixed <= 160 * 1024;
+    constexpr int RING = ring3 ? 3 : 2;
+    const size_t sh = (size_t)RING * NSTREAM * R_TILE * 2 + fixed;
+    auto kern = k_dgrad_r<KC, RESID, ADD, ACC, XN, RING>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    const int64_t tiles = (M + R_BM - 1) / R_BM;
+    const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(R_THR), sh, s, (const bf16*)dY, (const bf16*)Wt, (const bf16*)add, (const bf16*)X, gamma, beta,
+                       (const bf16*)resid, (bf16*)out, dgamma, dbeta, (bf16*)xn_out, M);
+}
+
+}  // namespace
+
+// Returns false when the combination is not one of the instantiated ones (the caller then uses k_dgrad_lnbwd).
+bool kasf_launch_dgrad_r(hipStream_t s, const void* dY, int Kd, const void* Wt, const void* dxn_add, const void* X, const float* gamma, const void* resid,
+                         void* out, int accumulate, float* dgamma, float* dbeta, int64_t M, void* xn_out, const float* beta) {
+    const bool R = resid != nullptr, A = dxn_add != nullptr, C = accumulate != 0, XN = xn_out != nullptr;
+    if (M <= 0) return true;
+    if (Kd == 384 && R && !A && !C && XN) launch_dgrad_r<3, true, false, false, true>(s, dY, Wt, dxn_add, X, gamma, beta, resid, out, dgamma, dbeta, xn_out, M);
+    else if (Kd == 128 && R && !A && !C && XN) launch_dgrad_r<1, true, false, false, true>(s, dY, Wt, dxn_add, X, gamma, beta, resid, out, dgamma, dbeta, xn_out, M);
+    else if (Kd == 256 && !R && !A && C && XN) launch_dgrad_r<2, false, false, true, true>(s, dY, Wt, dxn_add, X, gamma, beta, resid, out, dgamma, dbeta, xn_out, M);
+    else if (Kd == 256 && R && A && !C && !XN) launch_dgrad_r<2, true, true, false, false>(s, dY, Wt, dxn_add, X, gamma, beta, resid, out, dgamma, dbeta, xn_out, M);
+    else return false;
+    return true;
+}

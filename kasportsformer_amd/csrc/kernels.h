@@ -117,3 +117,7 @@ void kasf_launch_eval_metrics(hipStream_t s, const float* pred, const float* lab
                               int n_actions, float* mpjpe, float* pmpjpe, float* acc, float* jpe, double* action_sums);
 void kasf_launch_gather_clips(hipStream_t s, const float* xa, const float* ya, const int64_t* index, const unsigned char* flip, int64_t n_clips, int B,
                               int T, float* xo, float* yo);
+
+// ---- k_gemm2.hip (bf16, persistent, register-resident weights) ----
+bool kasf_launch_dgrad_r(hipStream_t s, const void* dY, int Kd, const void* Wt, const void* dxn_add, const void* X, const float* gamma, const void* resid,
+                         void* out, int accumulate, float* dgamma, float* dbeta, int64_t M, void* xn_out, const float* beta);
