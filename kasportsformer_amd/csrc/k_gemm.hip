@@ -497,6 +497,7 @@ static void linear_T(hipStream_t s, const void* A, int64_t lda, const void* W, i
 }
 void kasf_launch_linear(int dt, hipStream_t s, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* C, int64_t ldc,
                         int64_t M, int N, const float* ln_g, const float* ln_b, void* xn_out, int act) {
+    if (dt == KASF_BF16 && act == 0 && lda == 128 && ldw == 128 && ldc == N && kasf_launch_linear_r(s, A, W, bias, C, M, N, ln_g, ln_b, xn_out)) return;
     DT_DISPATCH(dt, (linear_T<float>(s, A, lda, W, ldw, bias, C, ldc, M, N, ln_g, ln_b, xn_out, act)),
                 (linear_T<bf16>(s, A, lda, W, ldw, bias, C, ldc, M, N, ln_g, ln_b, xn_out, act)));
 }
@@ -511,6 +512,7 @@ static void linear_res_T(hipStream_t s, const void* A, const void* W, const floa
 }
 void kasf_launch_linear_res(int dt, hipStream_t s, const void* A, const void* W, const float* bias, const float* ls, const void* resid, void* C,
                             int64_t M) {
+    if (dt == KASF_BF16) { kasf_launch_linear_res_r(s, A, W, bias, ls, resid, C, M); return; }
     DT_DISPATCH(dt, (linear_res_T<float>(s, A, W, bias, ls, resid, C, M)), (linear_res_T<bf16>(s, A, W, bias, ls, resid, C, M)));
 }
 

@@ -5,6 +5,8 @@
 //   k_dgrad_r<KC,...>   out = [resid] + [out] + LNbwd( dY[M x 128KC] . Wt[128 x 128KC]^T [+ add] ; x, gamma ),
 //                       dgamma/dbeta reductions, optional LN(x) output for the matching weight-gradient GEMM
 //                       (the data gradient of every LN-fused linear of the mixers: qkv, q, kv, U|V)
+//   k_linear_r<NC,LN,RES>   C[M x 128NC] = LN?(A) . W^T + bias           (qkv / q / kv / U|V / d_o), optional LN(A) output
+//                           RES: C = resid + ls * (A . W^T + bias)        (attention proj + layer-scale + residual)
 #include "common.h"
 #include "kernels.h"
 #include "tile_ops.h"
@@ -179,6 +181,136 @@ void launch_dgrad_r(hipStream_t s, const void* dY, const void* Wt, const void* a
                        (const bf16*)resid, (bf16*)out, dgamma, dbeta, (bf16*)xn_out, M);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Forward linear.  Wave w owns output features [16 NC w, 16 NC (w+1)): NC weight tiles x 4 k-steps = 16 NC VGPRs.
+// Per 32-token tile: (LN: one 16-lane group per row normalises the raw tile into sA, one tile ahead) -> GEMM ->
+// accumulators to the swizzled output tile in LDS -> barrier -> full 16-byte-per-lane row stores.
+// ---------------------------------------------------------------------------------------------------------------
+template <int NC, bool LN, bool RES>
+__global__ __launch_bounds__(R_THR) void k_linear_r(const bf16* __restrict__ A, const bf16* __restrict__ W, const float* __restrict__ bias,
+                                                    const float* __restrict__ ln_g, const float* __restrict__ ln_b, bf16* __restrict__ xn_out,
+                                                    const float* __restrict__ ls, const bf16* __restrict__ resid, bf16* __restrict__ C, int64_t M) {
+    static_assert(!RES || NC == 1, "the residual form is 128 -> 128");
+    constexpr int N = 128 * NC, NSTREAM = 1 + (RES ? 1 : 0), SLOT = NSTREAM * R_TILE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* sRing = reinterpret_cast<bf16*>(smem);        // [3][SLOT]  raw A tile (| resid tile)
+    bf16* sA = sRing + 3 * SLOT;                        // [2][32][128] LN(A) (LN only)
+    bf16* sO = sA + (LN ? 2 * R_TILE : 0);              // [NC][32][128] output tile
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4, sub = lane & 15, rl = threadIdx.x >> 4;
+    const int64_t ntiles_total = (M + R_BM - 1) / R_BM;
+    const int64_t per = (ntiles_total + gridDim.x - 1) / gridDim.x;
+    const int64_t tile0 = (int64_t)blockIdx.x * per;
+    int64_t ntiles = ntiles_total - tile0;
+    if (ntiles > per) ntiles = per;
+    if (ntiles <= 0) return;
+
+    bf16x8 wf[NC][4];
+    f32x4 bv[NC], lsv = f32x4{1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+    for (int nt = 0; nt < NC; ++nt) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) wf[nt][ks] = *reinterpret_cast<const bf16x8*>(W + (int64_t)(16 * NC * w + 16 * nt + i) * 128 + 32 * ks + 8 * g);
+        bv[nt] = bias != nullptr ? *reinterpret_cast<const f32x4*>(bias + 16 * NC * w + 16 * nt + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (RES) lsv = *reinterpret_cast<const f32x4*>(ls + 16 * w + 4 * g);
+    float gm[8], bt[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { gm[e] = LN ? ln_g[sub * 8 + e] : 1.f; bt[e] = LN ? ln_b[sub * 8 + e] : 0.f; }
+
+    auto issue = [&](int64_t t) {
+        const int64_t tt = t < ntiles ? t : ntiles - 1;
+        const int64_t row0 = (tile0 + tt) * R_BM;
+        const int nvalid = (int)((M - row0) < R_BM ? (M - row0) : R_BM);
+        bf16* slot = sRing + (int)(t % 3) * SLOT;
+        stage_tile_async<bf16, R_BM, R_THR>(slot, A + row0 * 128, 128, nvalid);
+        if (RES) stage_tile_async<bf16, R_BM, R_THR>(slot + R_TILE, resid + row0 * 128, 128, nvalid);
+    };
+    auto layernorm = [&](int64_t t) {                    // row rl of tile t: raw slot -> sA[t & 1] (+ xn_out)
+        float v[8];
+        tile_load8(sRing + (int)(t % 3) * SLOT, rl, sub * 8, v);
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[e];
+        const float mean = reduce16(s) * (1.0f / 128.0f);
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { v[e] -= mean; q += v[e] * v[e]; }
+        const float rstd = rsqrtf(reduce16(q) * (1.0f / 128.0f) + KASF_LN_EPS);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] * rstd * gm[e] + bt[e];
+        tile_store8(sA + (int)(t & 1) * R_TILE, rl, sub * 8, v);
+        const int64_t row = (tile0 + t) * R_BM + rl;
+        if (xn_out != nullptr && row < M) store8(xn_out + row * 128 + sub * 8, v);
+    };
+    issue(0);
+    issue(1);
+    wait_async_le<NSTREAM>();
+    if (LN) layernorm(0);
+    for (int64_t t = 0; t < ntiles; ++t) {
+        const bf16* slot = sRing + (int)(t % 3) * SLOT;
+        const bf16* cA = LN ? sA + (int)(t & 1) * R_TILE : slot;
+        const int64_t row0 = (tile0 + t) * R_BM;
+        barrier_keep_async();                            // B1: operand tile t complete and visible; everyone is past the copy-out of tile t-1
+        {
+            f32x4 acc[NC][2];
+            zero_acc(acc);
+            bf16x8 fb[2][2];
+            fb[0][0] = tok_frag(cA, i, 0);
+            fb[0][1] = tok_frag(cA, 16 + i, 0);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks + 1 < 4) { fb[(ks + 1) & 1][0] = tok_frag(cA, i, ks + 1); fb[(ks + 1) & 1][1] = tok_frag(cA, 16 + i, ks + 1); }
+#pragma unroll
+                for (int nt = 0; nt < NC; ++nt) {
+                    acc[nt][0] = mfma16(wf[nt][ks], fb[ks & 1][0], acc[nt][0]);
+                    acc[nt][1] = mfma16(wf[nt][ks], fb[ks & 1][1], acc[nt][1]);
+                }
+            }
+#pragma unroll
+            for (int nt = 0; nt < NC; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const int col = 16 * NC * w + 16 * nt + 4 * g;          // feature index inside [0, 128 NC)
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = acc[nt][mt][r] + bv[nt][r];
+                    if (RES) {
+                        float x[4];
+                        load4(slot + R_TILE + Tile<bf16>::off4(mt * 16 + i, col), x);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = x[r] + lsv[r] * v[r];
+                    }
+                    store4(sO + (col >> 7) * R_TILE + Tile<bf16>::off4(mt * 16 + i, col & 127), v);
+                }
+        }
+        barrier_keep_async();                            // B2: output tile complete
+        issue(t + 2);                                    // slot (t+2)%3 held tile t-1: its last reader (epilogue of t-1) is behind B1
+        wait_async_le<NSTREAM>();                        // tile t+1 landed (only tile t+2 outstanding); this tile's stores come after
+        if (LN && t + 1 < ntiles) layernorm(t + 1);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {                   // 32 rows x 16 NC chunks of 16 bytes over 512 threads
+            const int chunk = c * R_THR + threadIdx.x, r = chunk / (16 * NC), cc = chunk % (16 * NC);
+            const int64_t row = row0 + r;
+            if (row < M)
+                *reinterpret_cast<f32x4*>(C + row * N + cc * 8) = *reinterpret_cast<const f32x4*>(sO + (cc >> 4) * R_TILE + Tile<bf16>::chunk_off(r, cc & 15));
+        }
+    }
+    wait_async();
+}
+
+template <int NC, bool LN, bool RES>
+void launch_linear_r(hipStream_t s, const void* A, const void* W, const float* bias, const float* ln_g, const float* ln_b, void* xn_out, const float* ls,
+                     const void* resid, void* C, int64_t M) {
+    const size_t sh = (size_t)(3 * (1 + (RES ? 1 : 0)) + (LN ? 2 : 0) + NC) * R_TILE * 2;
+    auto kern = k_linear_r<NC, LN, RES>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    const int64_t tiles = (M + R_BM - 1) / R_BM;
+    const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(R_THR), sh, s, (const bf16*)A, (const bf16*)W, bias, ln_g, ln_b, (bf16*)xn_out, ls, (const bf16*)resid,
+                       (bf16*)C, M);
+}
+
 }  // namespace
 
 // Returns false when the combination is not one of the instantiated ones (the caller then uses k_dgrad_lnbwd).
@@ -192,4 +324,22 @@ bool kasf_launch_dgrad_r(hipStream_t s, const void* dY, int Kd, const void* Wt, 
     else if (Kd == 256 && R && A && !C && !XN) launch_dgrad_r<2, true, true, false, false>(s, dY, Wt, dxn_add, X, gamma, beta, resid, out, dgamma, dbeta, xn_out, M);
     else return false;
     return true;
+}
+
+// y = LN?(a) W^T + bias, a [M,128] dense, W [N,128] dense, y [M,N] dense, N in {128, 256, 384}
+bool kasf_launch_linear_r(hipStream_t s, const void* A, const void* W, const float* bias, void* C, int64_t M, int N, const float* ln_g, const float* ln_b,
+                          void* xn_out) {
+    if (M <= 0) return true;
+    const bool ln = ln_g != nullptr;
+    if (N == 384 && ln) launch_linear_r<3, true, false>(s, A, W, bias, ln_g, ln_b, xn_out, nullptr, nullptr, C, M);
+    else if (N == 256 && ln) launch_linear_r<2, true, false>(s, A, W, bias, ln_g, ln_b, xn_out, nullptr, nullptr, C, M);
+    else if (N == 128 && ln) launch_linear_r<1, true, false>(s, A, W, bias, ln_g, ln_b, xn_out, nullptr, nullptr, C, M);
+    else if (N == 128 && !ln && xn_out == nullptr) launch_linear_r<1, false, false>(s, A, W, bias, nullptr, nullptr, nullptr, nullptr, nullptr, C, M);
+    else return false;
+    return true;
+}
+// x_mid = resid + ls * (o Wproj^T + b)
+void kasf_launch_linear_res_r(hipStream_t s, const void* A, const void* W, const float* bias, const float* ls, const void* resid, void* C, int64_t M) {
+    if (M <= 0) return;
+    launch_linear_r<1, false, true>(s, A, W, bias, nullptr, nullptr, nullptr, ls, resid, C, M);
 }

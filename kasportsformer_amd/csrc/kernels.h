@@ -121,3 +121,6 @@ void kasf_launch_gather_clips(hipStream_t s, const float* xa, const float* ya, c
 // ---- k_gemm2.hip (bf16, persistent, register-resident weights) ----
 bool kasf_launch_dgrad_r(hipStream_t s, const void* dY, int Kd, const void* Wt, const void* dxn_add, const void* X, const float* gamma, const void* resid,
                          void* out, int accumulate, float* dgamma, float* dbeta, int64_t M, void* xn_out, const float* beta);
+bool kasf_launch_linear_r(hipStream_t s, const void* A, const void* W, const float* bias, void* C, int64_t M, int N, const float* ln_g, const float* ln_b,
+                          void* xn_out);
+void kasf_launch_linear_res_r(hipStream_t s, const void* A, const void* W, const float* bias, const float* ls, const void* resid, void* C, int64_t M);
