@@ -624,8 +624,11 @@ int kasf_backward(const kasf_model* m, const float* params, const void* packed, 
             const void* x_in = l == 0 ? c.w(p.xj) : c.w(p.layers[l - 1].gate_out);
             void* g_out = gbuf(st - 1);
             void* g_in = gbuf(st);
-            kasf_launch_gate_bwd(c.dt, c.s, g_out, c.w(lw.b[1].x_out), c.w(lw.b[3].x_out), c.w(lw.b[5].x_out), params + lo.fus_w, (const float*)c.w(lw.alpha),
-                                 c.w(p.ga), c.w(p.gg), c.w(p.gb), grads + lo.fus_w, grads + lo.fus_b, c.M, m->cfg.use_adaptive_fusion);
+            // incoming gradient: the head's for the top layer, otherwise the three branch input gradients the layer above left behind (summed in-kernel)
+            const bool top = l == L - 1;
+            kasf_launch_gate_bwd(c.dt, c.s, top ? g_out : c.w(p.sc[0].g_in), top ? nullptr : c.w(p.sc[1].g_in), top ? nullptr : c.w(p.sc[2].g_in),
+                                 c.w(lw.b[1].x_out), c.w(lw.b[3].x_out), c.w(lw.b[5].x_out), params + lo.fus_w, (const float*)c.w(lw.alpha), c.w(p.ga), c.w(p.gg),
+                                 c.w(p.gb), grads + lo.fus_w, grads + lo.fus_b, c.M, m->cfg.use_adaptive_fusion, (float*)c.w(p.sc[0].wg_part), WG_PARTIAL_FLOATS);
             const int64_t gsrc[3] = {p.ga, p.gg, p.gb};
             HIPCHK(hipEventRecord(m->ev_fork, c.s));
             for (int br = 0; br < 3; ++br) {
@@ -645,7 +648,8 @@ int kasf_backward(const kasf_model* m, const float* params, const void* packed, 
                 }
             }
             // gradient w.r.t. the layer input = sum over the branches (layer 0: the bone branch fed on the bone embedding instead)
-            kasf_launch_add3(c.dt, c.s, g_in, c.w(p.sc[0].g_in), c.w(p.sc[1].g_in), l == 0 ? nullptr : c.w(p.sc[2].g_in), c.M * 128);
+            // Only the bottom layer materialises the sum (for the embedding backward); elsewhere the next gate_bwd adds the three on the fly.
+            if (l == 0) kasf_launch_add3(c.dt, c.s, g_in, c.w(p.sc[0].g_in), c.w(p.sc[1].g_in), nullptr, c.M * 128);
         } else {
             void* g_x = gbuf(L);
             const int64_t frames = (int64_t)batch * c.T;

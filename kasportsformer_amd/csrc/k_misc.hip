@@ -233,19 +233,29 @@ __global__ __launch_bounds__(256) void k_gate_fwd(const T* __restrict__ xa, cons
     }
 }
 
+// g = g0 (+ g1 + g2: the three branch input gradients of the layer above, summed here instead of by a separate pass).
+// Weight / bias gradients leave each workgroup as ONE partial row (part != nullptr; summed in fixed order by k_gate_reduce) so that
+// the grid can be large enough to hide HBM latency without contended atomics.
+constexpr int GATE_PART_LD = 1160;      // 3 x 384 weight gradients + 3 bias gradients, padded
 template <typename T>
-__global__ __launch_bounds__(256) void k_gate_bwd(const T* __restrict__ g, const T* __restrict__ xa, const T* __restrict__ xg, const T* __restrict__ xb,
-                                                  const float* __restrict__ W, const float* __restrict__ alpha, T* __restrict__ ga, T* __restrict__ gg,
-                                                  T* __restrict__ gb, float* __restrict__ dW, float* __restrict__ db, int64_t M, int adaptive) {
+__global__ __launch_bounds__(256) void k_gate_bwd(const T* __restrict__ g, const T* __restrict__ g1, const T* __restrict__ g2, const T* __restrict__ xa,
+                                                  const T* __restrict__ xg, const T* __restrict__ xb, const float* __restrict__ W,
+                                                  const float* __restrict__ alpha, T* __restrict__ ga, T* __restrict__ gg, T* __restrict__ gb,
+                                                  float* __restrict__ dW, float* __restrict__ db, float* __restrict__ part, int64_t M, int adaptive) {
     __shared__ float sRed[16][384];
+    __shared__ float sW[3][384];
+    __shared__ float sDb[3];
     const int sub = threadIdx.x & 15, rl = threadIdx.x >> 4;
-    float w[3][3][8], dw[3][3][8], dbl[3] = {0.f, 0.f, 0.f};
+    for (int c = threadIdx.x; c < 3 * 384; c += 256) sW[c / 384][c % 384] = W[c];
+    if (threadIdx.x < 3) sDb[threadIdx.x] = 0.f;
+    __syncthreads();
+    float dw[3][3][8], dbl[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 3; ++j)
 #pragma unroll
         for (int s = 0; s < 3; ++s)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { w[j][s][e] = W[j * 384 + s * 128 + sub * 8 + e]; dw[j][s][e] = 0.f; }
+            for (int e = 0; e < 8; ++e) dw[j][s][e] = 0.f;
     for (int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x; item < M * 16; item += (int64_t)gridDim.x * 256) {
         const int64_t tok = item >> 4;
         float x[3][8], gv[8];
@@ -253,6 +263,18 @@ __global__ __launch_bounds__(256) void k_gate_bwd(const T* __restrict__ g, const
         load8(xa + tok * 128 + sub * 8, x[0]);
         load8(xg + tok * 128 + sub * 8, x[1]);
         load8(xb + tok * 128 + sub * 8, x[2]);
+        if (g1 != nullptr) {
+            float t[8];
+            load8(g1 + tok * 128 + sub * 8, t);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) gv[e] += t[e];
+        }
+        if (g2 != nullptr) {
+            float t[8];
+            load8(g2 + tok * 128 + sub * 8, t);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) gv[e] += t[e];
+        }
         const float a[3] = {alpha[tok * 4], alpha[tok * 4 + 1], alpha[tok * 4 + 2]};
         float dl[3] = {0.f, 0.f, 0.f};
         if (adaptive) {
@@ -272,7 +294,8 @@ __global__ __launch_bounds__(256) void k_gate_bwd(const T* __restrict__ g, const
         for (int s = 0; s < 3; ++s)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                o[s][e] = a[s] * gv[e] + dl[0] * w[0][s][e] + dl[1] * w[1][s][e] + dl[2] * w[2][s][e];
+                const int c = s * 128 + sub * 8 + e;
+                o[s][e] = a[s] * gv[e] + dl[0] * sW[0][c] + dl[1] * sW[1][c] + dl[2] * sW[2][c];
 #pragma unroll
                 for (int j = 0; j < 3; ++j) dw[j][s][e] += dl[j] * x[s][e];
             }
@@ -281,6 +304,7 @@ __global__ __launch_bounds__(256) void k_gate_bwd(const T* __restrict__ g, const
         store8(gb + tok * 128 + sub * 8, o[2]);
     }
     if (!adaptive) return;
+    float* prow = part != nullptr ? part + (int64_t)blockIdx.x * GATE_PART_LD : nullptr;
     for (int j = 0; j < 3; ++j) {
         __syncthreads();
 #pragma unroll
@@ -292,10 +316,31 @@ __global__ __launch_bounds__(256) void k_gate_bwd(const T* __restrict__ g, const
             float s = 0.f;
 #pragma unroll
             for (int k = 0; k < 16; ++k) s += sRed[k][c];
-            atomicAdd(dW + j * 384 + c, s);
+            if (prow != nullptr) prow[j * 384 + c] = s;
+            else atomicAdd(dW + j * 384 + c, s);
         }
     }
-    if (sub == 0) { atomicAdd(db, dbl[0]); atomicAdd(db + 1, dbl[1]); atomicAdd(db + 2, dbl[2]); }
+    if (sub == 0) { atomicAdd(&sDb[0], dbl[0]); atomicAdd(&sDb[1], dbl[1]); atomicAdd(&sDb[2], dbl[2]); }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        if (prow != nullptr) prow[1152 + threadIdx.x] = sDb[threadIdx.x];
+        else atomicAdd(db + threadIdx.x, sDb[threadIdx.x]);
+    }
+}
+
+// dW[1152] / db[3] += column sums of part[nb][GATE_PART_LD]
+__global__ __launch_bounds__(256) void k_gate_reduce(const float* __restrict__ part, float* __restrict__ dW, float* __restrict__ db, int nb) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+    __shared__ float sP[4][64];
+    float s = 0.f;
+    if (c < 1155)
+        for (int k = q; k < nb; k += 4) s += part[(int64_t)k * GATE_PART_LD + c];
+    sP[q][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (q == 0 && c < 1155) {
+        const float t = (sP[0][threadIdx.x] + sP[1][threadIdx.x]) + (sP[2][threadIdx.x] + sP[3][threadIdx.x]);
+        if (c < 1152) dW[c] += t; else db[c - 1152] += t;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -558,11 +603,14 @@ void kasf_launch_gate_fwd(int dt, hipStream_t s, const void* xa, const void* xg,
     if (dt == KASF_F32) hipLaunchKernelGGL(k_gate_fwd<float>, dim3(grid), dim3(256), 0, s, (const float*)xa, (const float*)xg, (const float*)xb, W, b, (float*)out, alpha, M, adaptive);
     else hipLaunchKernelGGL(k_gate_fwd<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)xa, (const bf16*)xg, (const bf16*)xb, W, b, (bf16*)out, alpha, M, adaptive);
 }
-void kasf_launch_gate_bwd(int dt, hipStream_t s, const void* g, const void* xa, const void* xg, const void* xb, const float* W, const float* alpha,
-                          void* ga, void* gg, void* gb, float* dW, float* db, int64_t M, int adaptive) {
-    const unsigned grid = ew_grid(M * 16, 256);         // each block ends with 1,155 same-address atomics: keep the block count low
-    if (dt == KASF_F32) hipLaunchKernelGGL(k_gate_bwd<float>, dim3(grid), dim3(256), 0, s, (const float*)g, (const float*)xa, (const float*)xg, (const float*)xb, W, alpha, (float*)ga, (float*)gg, (float*)gb, dW, db, M, adaptive);
-    else hipLaunchKernelGGL(k_gate_bwd<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)g, (const bf16*)xa, (const bf16*)xg, (const bf16*)xb, W, alpha, (bf16*)ga, (bf16*)gg, (bf16*)gb, dW, db, M, adaptive);
+void kasf_launch_gate_bwd(int dt, hipStream_t s, const void* g, const void* g1, const void* g2, const void* xa, const void* xg, const void* xb,
+                          const float* W, const float* alpha, void* ga, void* gg, void* gb, float* dW, float* db, int64_t M, int adaptive, float* part,
+                          int64_t part_floats) {
+    unsigned grid = ew_grid(M * 16, 1024);              // 4 workgroups per CU: enough loads in flight for an HBM stream of 7-9 tensors
+    if (part == nullptr || (int64_t)grid * GATE_PART_LD > part_floats) { part = nullptr; if (grid > 256) grid = 256; }   // atomics: few workgroups
+    if (dt == KASF_F32) hipLaunchKernelGGL(k_gate_bwd<float>, dim3(grid), dim3(256), 0, s, (const float*)g, (const float*)g1, (const float*)g2, (const float*)xa, (const float*)xg, (const float*)xb, W, alpha, (float*)ga, (float*)gg, (float*)gb, dW, db, part, M, adaptive);
+    else hipLaunchKernelGGL(k_gate_bwd<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)g, (const bf16*)g1, (const bf16*)g2, (const bf16*)xa, (const bf16*)xg, (const bf16*)xb, W, alpha, (bf16*)ga, (bf16*)gg, (bf16*)gb, dW, db, part, M, adaptive);
+    if (part != nullptr && adaptive) hipLaunchKernelGGL(k_gate_reduce, dim3(19), dim3(256), 0, s, part, dW, db, (int)grid);
 }
 void kasf_launch_head_fwd(int dt, hipStream_t s, const void* rep, const float* W, const float* b, float* out, int64_t M) {
     const unsigned grid = ew_grid(M * 16);

@@ -95,8 +95,9 @@ void kasf_launch_refusion_bwd(hipStream_t s, const float* x, const float* dlimb3
                               int64_t frames);
 void kasf_launch_gate_fwd(int dt, hipStream_t s, const void* xa, const void* xg, const void* xb, const float* W, const float* b, void* out,
                           float* alpha, int64_t M, int adaptive);
-void kasf_launch_gate_bwd(int dt, hipStream_t s, const void* g, const void* xa, const void* xg, const void* xb, const float* W, const float* alpha,
-                          void* ga, void* gg, void* gb, float* dW, float* db, int64_t M, int adaptive);
+void kasf_launch_gate_bwd(int dt, hipStream_t s, const void* g, const void* g1, const void* g2, const void* xa, const void* xg, const void* xb,
+                          const float* W, const float* alpha, void* ga, void* gg, void* gb, float* dW, float* db, int64_t M, int adaptive, float* part,
+                          int64_t part_floats);   // g1/g2: optional extra addends of the incoming gradient; part: scratch for per-workgroup partials
 void kasf_launch_head_fwd(int dt, hipStream_t s, const void* rep, const float* W, const float* b, float* out, int64_t M);
 void kasf_launch_head_bwd(int dt, hipStream_t s, const float* dy, const void* rep, const float* W, void* dpre, float* dW, float* db, int64_t M);
 void kasf_launch_cast_to_f32(int dt, hipStream_t s, const void* src, float* dst, int64_t n);
