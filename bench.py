@@ -63,11 +63,12 @@ def kernel_rooflines(M):
     part = torch.empty(256 * 128 * 128, device=dev)
     st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
     p = lambda t: C.c_void_p(t.data_ptr())
-    fwd = lambda: lib.kasf_op_mlp_fwd(1, p(x), p(gam), p(bet), p(w1), p(b1), p(w2), p(b2), p(ls), p(out), M, st())
+    xn = torch.empty_like(x)
+    fwd = lambda: lib.kasf_op_mlp_fwd(1, p(x), p(gam), p(bet), p(w1), p(b1), p(w2), p(b2), p(ls), p(out), M, p(xn), st())    # training-mode forward: also stores LN(x)
     dap = torch.empty(4 * M * 128, device=dev, dtype=bf)
     part2 = torch.empty(2 * 64 * 65536, device=dev)
     # the engine's bf16 backward: data gradient + both weight gradients + LayerNorm backward in k_mlp_bwd_q / k_lnbwd_sum4 / k_wgrad_reduce
-    bwd = lambda: lib.kasf_op_mlp_bwd_fused(p(x), p(gout), p(gam), p(bet), p(w1), p(b1), p(w2ts), p(w1t), p(dap), p(part2), p(dW1), p(dW2), p(db1),
+    bwd = lambda: lib.kasf_op_mlp_bwd_fused(p(x), p(xn), p(gout), p(gam), p(w1), p(b1), p(w2ts), p(w1t), p(dap), p(part2), p(dW1), p(dW2), p(db1),
                                             p(gs), p(gin), p(dg), p(db), M, st())
     wg1 = lambda: lib.kasf_op_wgrad(1, p(dZ), 512, p(x), 128, None, None, p(dW1), p(db1), M, p(part), part.numel(), st())   # engine path: X = LN(x) emitted by k_mlp_bwd
     wg2 = lambda: lib.kasf_op_wgrad(1, p(gout), 128, p(H), 512, None, None, p(dW2), p(gs), M, p(part), part.numel(), st())

@@ -122,15 +122,16 @@ int kasf_ws_entry(const kasf_model* m, int32_t batch, int32_t flags, int32_t idx
 int kasf_op_linear(int32_t dtype, const void* a, const void* w, const float* bias, void* y, int64_t M, int32_t N, const float* ln_g, const float* ln_b,
                    void* xn_out, int32_t act, void* stream);
 /* modules/mlp.py inside a FormerModule: out = x + ls2 * (GELU(LN(x) W1^T + b1) W2^T + b2) */
+/* xn_out (optional; bf16 only): also receives LN(x), which kasf_op_mlp_bwd_fused streams instead of recomputing (what training mode does) */
 int kasf_op_mlp_fwd(int32_t dtype, const void* x, const float* ln_g, const float* ln_b, const void* w1, const float* b1, const void* w2, const float* b2,
-                    const float* ls2, void* out, int64_t M, void* stream);
+                    const float* ls2, void* out, int64_t M, void* xn_out, void* stream);
 int kasf_op_mlp_bwd(int32_t dtype, const void* x, const void* g, const float* ln_g, const float* ln_b, const void* w1, const float* b1,
                     const void* w2t_scaled, const void* w1t, void* hbuf, void* dzbuf, void* g_in, float* dgamma, float* dbeta, int64_t M, void* stream);
 /* bf16 only: fused MLP backward (hidden-quarter ownership, weights in registers): data gradient AND both weight gradients.
  * g_in = g + LNbwd(dA); dw1 [512,128] += dZ^T LN(x); db1 [512] += colsum(dZ); dw2_unscaled [128,512] += g^T H;
  * gsum [128] += colsum(g); dgamma/dbeta += LayerNorm parameter gradients.  dapart: 4*M*128 elements of scratch (bf16);
  * partial: >= 2*64*65536 floats of scratch. */
-int kasf_op_mlp_bwd_fused(const void* x, const void* g, const float* ln_g, const float* ln_b, const void* w1, const float* b1, const void* w2t_scaled,
+int kasf_op_mlp_bwd_fused(const void* x, const void* xn /* LN(x) from kasf_op_mlp_fwd */, const void* g, const float* ln_g, const void* w1, const float* b1, const void* w2t_scaled,
                           const void* w1t, void* dapart, float* partial, float* dw1, float* dw2_unscaled, float* db1, float* gsum, void* g_in,
                           float* dgamma, float* dbeta, int64_t M, void* stream);
 /* dW[N,K] += G^T LN?(X), dbias[N] += colsum(G): G [M,N], X [M,K].  partial: optional fp32 scratch of partial_floats

@@ -57,7 +57,7 @@ SIGNATURES = {
     "kasf_ws_entries": (_i32, [_vp, _i32, _i32]),
     "kasf_ws_entry": (_i32, [_vp, _i32, _i32, _i32, C.c_char_p, _i32, _pi64, _pi64, _pi32]),
     "kasf_op_linear": (_i32, [_i32, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _vp]),
-    "kasf_op_mlp_fwd": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "kasf_op_mlp_fwd": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "kasf_op_mlp_bwd": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "kasf_op_mlp_bwd_fused": (_i32, [_vp] * 17 + [_i64, _vp]),
     "kasf_op_wgrad": (_i32, [_i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp]),

@@ -34,7 +34,7 @@ struct TopOff { int64_t norm_w, norm_b, fc_w, fc_b, head_w, head_b, p_fc, p_fcT,
 
 constexpr int64_t WG_PARTIAL_FLOATS = 2 * 64 * 65536;       // per-split weight-gradient tiles: 256 workgroups x 128x128, or 64 ranges x (dW1 + dW2) of the MLP
 
-struct BlkWs { int64_t qkv, kv, o, xn, y, mask, x_mid, x_out, stats, bstats, coef; };
+struct BlkWs { int64_t qkv, kv, o, xn, y, mask, x_mid, xn2, x_out, stats, bstats, coef; };
 struct LayerWs { BlkWs b[6]; int64_t gate_out, alpha; };
 struct WsEntry { std::string name; int64_t off, numel; int kind; };
 struct Scratch { int64_t uv, t1, t2, hbuf, dzbuf, d_o, dqkv, rbuf, duv, xn_a, xn_b, wg_part, g_in; };   // per-branch (att / graph / bone)
@@ -273,6 +273,7 @@ void build_plan(const kasf_model* m, int B, bool train, bool names, Plan& p) {
                 w.mask = (b & 1) ? take(groupsT * T * 3, 3, "adj_mask", l, b) : -1;
             }
             w.x_mid = take(M * 128, 0, "x_mid", l, b);
+            w.xn2 = (train && m->cfg.dtype == KASF_BF16) ? take(M * 128, 0, "xn2", l, b) : -1;   // LN2(x_mid), streamed by the fused MLP backward
             w.x_out = take(M * 128, 0, "x_out", l, b);
         }
         lw.gate_out = take(M * 128, 0, "gate_out", l);
@@ -348,7 +349,8 @@ void block_forward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void* 
     }
     if (o.kind != KIND_GRAPH)
         kasf_launch_linear_res(c.dt, c.s, c.w(w.o), c.pk(o.p_proj), P + o.proj_b, P + o.ls1, x_in, c.w(w.x_mid), c.M);
-    kasf_launch_mlp_fwd(c.dt, c.s, c.w(w.x_mid), P + o.n2w, P + o.n2b, c.pk(o.p_fc1), P + o.fc1b, c.pk(o.p_fc2), P + o.fc2b, P + o.ls2, c.w(w.x_out), c.M);
+    kasf_launch_mlp_fwd(c.dt, c.s, c.w(w.x_mid), P + o.n2w, P + o.n2b, c.pk(o.p_fc1), P + o.fc1b, c.pk(o.p_fc2), P + o.fc2b, P + o.ls2, c.w(w.x_out), c.M,
+                        w.xn2 >= 0 ? c.w(w.xn2) : nullptr);
 }
 
 // g_out: gradient w.r.t. the block output; writes (or accumulates) the gradient w.r.t. x_in into dst
@@ -360,7 +362,7 @@ void block_backward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void*
     // ---- MLP half ----
     if (c.dt == KASF_BF16) {
         // hidden-quarter kernel: dgrad + both weight gradients fused, then the 4-way partial sum + LayerNorm backward
-        kasf_launch_mlp_bwd_q(c.s, c.w(w.x_mid), g_out, P + o.n2w, P + o.n2b, c.pk(o.p_fc1), P + o.fc1b, c.pk(o.p_fc2Ts), c.pk(o.p_fc1T), c.w(sc.hbuf),
+        kasf_launch_mlp_bwd_q(c.s, c.w(w.x_mid), c.w(w.xn2), g_out, P + o.n2w, c.pk(o.p_fc1), P + o.fc1b, c.pk(o.p_fc2Ts), c.pk(o.p_fc1T), c.w(sc.hbuf),
                               (float*)c.w(sc.wg_part), G + o.fc1w, G + o.fc2w, G + o.fc1b, G + o.fc2b, g_mid, G + o.n2w, G + o.n2b, c.M);
     } else {
         kasf_launch_mlp_bwd(c.dt, c.s, c.w(w.x_mid), g_out, P + o.n2w, P + o.n2b, c.pk(o.p_fc1), P + o.fc1b, c.pk(o.p_fc2Ts), c.pk(o.p_fc1T), c.w(sc.hbuf),
@@ -727,9 +729,9 @@ int kasf_op_linear(int32_t dtype, const void* a, const void* w, const float* bia
     return 0;
 }
 int kasf_op_mlp_fwd(int32_t dtype, const void* x, const float* ln_g, const float* ln_b, const void* w1, const float* b1, const void* w2, const float* b2,
-                    const float* ls2, void* out, int64_t M, void* stream) {
+                    const float* ls2, void* out, int64_t M, void* xn_out, void* stream) {
     OP_DT_CHECK(dtype);
-    kasf_launch_mlp_fwd(dtype, (hipStream_t)stream, x, ln_g, ln_b, w1, b1, w2, b2, ls2, out, M);
+    kasf_launch_mlp_fwd(dtype, (hipStream_t)stream, x, ln_g, ln_b, w1, b1, w2, b2, ls2, out, M, xn_out);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -740,11 +742,11 @@ int kasf_op_mlp_bwd(int32_t dtype, const void* x, const void* g, const float* ln
     HIPCHK(hipGetLastError());
     return 0;
 }
-int kasf_op_mlp_bwd_fused(const void* x, const void* g, const float* ln_g, const float* ln_b, const void* w1, const float* b1, const void* w2t_scaled,
+int kasf_op_mlp_bwd_fused(const void* x, const void* xn, const void* g, const float* ln_g, const void* w1, const float* b1, const void* w2t_scaled,
                           const void* w1t, void* dapart, float* partial, float* dw1, float* dw2_unscaled, float* db1, float* gsum, void* g_in,
                           float* dgamma, float* dbeta, int64_t M, void* stream) {
-    if (!x || !g || !dapart || !partial || !dw1 || !dw2_unscaled || !db1 || !gsum || !g_in) return kasf_set_error(2, "null pointer argument");
-    kasf_launch_mlp_bwd_q((hipStream_t)stream, x, g, ln_g, ln_b, w1, b1, w2t_scaled, w1t, dapart, partial, dw1, dw2_unscaled, db1, gsum, g_in, dgamma,
+    if (!x || !xn || !g || !dapart || !partial || !dw1 || !dw2_unscaled || !db1 || !gsum || !g_in) return kasf_set_error(2, "null pointer argument");
+    kasf_launch_mlp_bwd_q((hipStream_t)stream, x, xn, g, ln_g, w1, b1, w2t_scaled, w1t, dapart, partial, dw1, dw2_unscaled, db1, gsum, g_in, dgamma,
                           dbeta, M);
     HIPCHK(hipGetLastError());
     return 0;

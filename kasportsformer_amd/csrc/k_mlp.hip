@@ -212,9 +212,9 @@ void mlp_bwd_T(hipStream_t s, const void* x, const void* g, const float* ln_g, c
 }  // namespace
 
 void kasf_launch_mlp_fwd(int dt, hipStream_t s, const void* x, const float* ln_g, const float* ln_b, const void* W1, const float* b1, const void* W2,
-                         const float* b2, const float* ls2, void* out, int64_t M) {
+                         const float* b2, const float* ls2, void* out, int64_t M, void* xn_out) {
     if (dt == KASF_F32) mlp_fwd_T<float>(s, x, ln_g, ln_b, W1, b1, W2, b2, ls2, out, M);
-    else kasf_launch_mlp_fwd_r(s, x, ln_g, ln_b, W1, b1, W2, b2, ls2, out, M);      // first generation: mlp_fwd_T<bf16>
+    else kasf_launch_mlp_fwd_r(s, x, ln_g, ln_b, W1, b1, W2, b2, ls2, out, M, xn_out);      // first generation: mlp_fwd_T<bf16>
 }
 void kasf_launch_mlp_bwd(int dt, hipStream_t s, const void* x, const void* g, const float* ln_g, const float* ln_b, const void* W1, const float* b1,
                          const void* W2ts, const void* W1t, void* Hbuf, void* dZbuf, void* xn_buf, void* g_in, float* dgamma, float* dbeta,

@@ -37,19 +37,18 @@ __device__ __forceinline__ bf16x8 tok_frag(const bf16* s, int row, int ks) {
 // compiler to batch LDS operand reads ahead of the MFMAs).  A wave owns HW = 128/NW hidden units (Z, dH), HW channels
 // (dA) and a 32 x (1024/NW) block of each 128 x 128 weight-gradient quarter.
 template <int NW>
-__global__ __launch_bounds__(NW * 64) void k_mlp_bwd_q(const bf16* __restrict__ X, const bf16* __restrict__ G, const float* __restrict__ ln_g,
-                                                       const float* __restrict__ ln_b, const bf16* __restrict__ W1, const float* __restrict__ b1,
+__global__ __launch_bounds__(NW * 64) void k_mlp_bwd_q(const bf16* __restrict__ XN, const bf16* __restrict__ G, const bf16* __restrict__ W1,
+                                                       const float* __restrict__ b1,
                                                        const bf16* __restrict__ W2ts, const bf16* __restrict__ W1t, bf16* __restrict__ dApart,
                                                        float* __restrict__ dW1part, float* __restrict__ dW2part, float* __restrict__ db1,
                                                        int64_t M, int tiles_per_range) {
     constexpr int NTHR = NW * 64, NTW = 8 / NW;           // 16-row tiles of hidden units / channels per wave
     constexpr int CT = 32 / NW;                           // 16-column tiles of the weight-gradient block per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16* sA = reinterpret_cast<bf16*>(smem);            // [2][BM][128] LN(x), double buffered
-    bf16* sG = sA + 2 * Q_BM * 128;                      // [3][BM][128] upstream gradient: in use / landed / in flight
+    bf16* sA = reinterpret_cast<bf16*>(smem);            // [3][BM][128] LN(x) as the forward pass stored it: in use / landed / in flight
+    bf16* sG = sA + 3 * Q_BM * 128;                      // [3][BM][128] upstream gradient, same ring
     bf16* sH = sG + 3 * Q_BM * 128;                      // [BM][128]    H of this quarter
     bf16* sD = sH + Q_BM * 128;                          // [BM][128]    dZ of this quarter
-    bf16* sXr = sD + Q_BM * 128;                         // [2][BM][128] raw x rows (LDS-direct landing zone), two tiles ahead
     // XCD-aware mapping: workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), so the four hidden quarters of one token range
     // sit at blockIdx b, b+8, b+16, b+24: same XCD, same L2 -> x and g cross the fabric once, not four times.
     int q, range;
@@ -86,63 +85,26 @@ __global__ __launch_bounds__(NW * 64) void k_mlp_bwd_q(const bf16* __restrict__ 
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) db1acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int sub = threadIdx.x & 15;
-    // phase 1 (right after B2): request g by LDS-direct loads and x into registers; phase 2 (after the GEMMs): LayerNorm -> LDS
-    // Tile t's g and raw x are requested TWO tiles ahead (HBM latency is longer than one tile's work); every request is
-    // exactly LPI LDS-direct loads per wave, so "all but the youngest LPI" == "everything requested before the last issue".
+    // Tile t's g and LN(x) rows are requested TWO tiles ahead by LDS-direct loads (HBM latency is longer than one tile's work) and are
+    // consumed straight from the landing tiles: no LayerNorm is recomputed here.  Every request is exactly LPI loads per wave, so
+    // "all but the youngest LPI" == "everything requested before the last issue".  Rows past M are clamped copies; their H / dZ are
+    // zeroed below, so they reach neither weight gradient.
     constexpr int LPI = 2 * (Q_BM / 4 / NW);
     auto stage_issue = [&](int64_t t) {
         if (t < ntiles) {
             const int64_t row0 = (tile0 + t) * Q_BM;
             const int nvalid = (int)((M - row0) < Q_BM ? (M - row0) : Q_BM);
             stage_tile_async<bf16, Q_BM, NTHR>(sG + (int)(t % 3) * Q_BM * 128, G + row0 * 128, 128, nvalid);
-            stage_tile_async<bf16, Q_BM, NTHR>(sXr + (int)(t & 1) * Q_BM * 128, X + row0 * 128, 128, nvalid);
-        } else {                                         // keep the per-issue load count constant (harmless re-read of the last tile)
+            stage_tile_async<bf16, Q_BM, NTHR>(sA + (int)(t % 3) * Q_BM * 128, XN + row0 * 128, 128, nvalid);
+        } else {                                         // keep the per-issue load count constant (harmless re-read of the first row)
             stage_tile_async<bf16, Q_BM, NTHR>(sG + (int)(t % 3) * Q_BM * 128, G, 128, 1);
-            stage_tile_async<bf16, Q_BM, NTHR>(sXr + (int)(t & 1) * Q_BM * 128, X, 128, 1);
-        }
-    };
-    auto stage_finish = [&](int64_t t, int buf) {
-        const int64_t row0 = (tile0 + t) * Q_BM;
-        // gamma / beta as unconditional vector loads (L1 hits).  A per-element "cond ? f(load) : 0" makes hipcc branch
-        // around every scalar load with a full vmcnt(0) each: 32 dependent round trips per tile.
-        float gmv[8], btv[8];
-        {
-            const f32x4 g0 = *reinterpret_cast<const f32x4*>(ln_g + sub * 8), g1 = *reinterpret_cast<const f32x4*>(ln_g + sub * 8 + 4);
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(ln_b + sub * 8), b1v = *reinterpret_cast<const f32x4*>(ln_b + sub * 8 + 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { gmv[e] = g0[e]; gmv[4 + e] = g1[e]; btv[e] = b0[e]; btv[4 + e] = b1v[e]; }
-        }
-        // wave w normalises exactly the rows its own LDS-direct loads delivered (rows [w*BM/NW, (w+1)*BM/NW)), so its own
-        // counted vmcnt is all the synchronisation this needs (the caller has waited for everything but the youngest issue)
-        constexpr int RPW = Q_BM / NW;
-        const bf16* xr = sXr + (int)(t & 1) * Q_BM * 128;
-        static_assert(RPW % 4 == 0, "each wave normalises whole groups of 4 rows");
-#pragma unroll
-        for (int b = 0; b < RPW / 4; ++b) {
-            const int r = w * RPW + 4 * b + (lane >> 4);
-            float v[8];
-            tile_load8(xr, r, sub * 8, v);
-            float s = 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) s += v[e];
-            const float mean = reduce16(s) * (1.0f / 128.0f);
-            float qv = 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { v[e] -= mean; qv += v[e] * v[e]; }
-            const float rstd = rsqrtf(reduce16(qv) * (1.0f / 128.0f) + KASF_LN_EPS);
-            const float keep = row0 + r < M ? 1.0f : 0.0f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (v[e] * rstd * gmv[e] + btv[e]) * keep;
-            tile_store8(sA + buf * Q_BM * 128, r, sub * 8, v);
+            stage_tile_async<bf16, Q_BM, NTHR>(sA + (int)(t % 3) * Q_BM * 128, XN, 128, 1);
         }
     };
     stage_issue(0);
     stage_issue(1);
-    wait_async_le<LPI>();                                // tile 0 landed, tile 1 may still be in flight
-    if (ntiles > 0) stage_finish(0, 0);
     for (int64_t t = 0; t < ntiles; ++t) {
-        const int buf = (int)(t & 1);
-        const bf16* cA = sA + buf * Q_BM * 128;
+        const bf16* cA = sA + (int)(t % 3) * Q_BM * 128;
         const bf16* cG = sG + (int)(t % 3) * Q_BM * 128;
         const int64_t row0 = (tile0 + t) * Q_BM;
         const int nvalid = (int)((M - row0) < Q_BM ? (M - row0) : Q_BM);
@@ -253,8 +215,6 @@ __global__ __launch_bounds__(NW * 64) void k_mlp_bwd_q(const bf16* __restrict__ 
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        wait_async_le<LPI>();                            // x(t+1), requested during tile t-1, has landed
-        if (t + 1 < ntiles) stage_finish(t + 1, buf ^ 1);
     }
     wait_async();                                        // drain the look-ahead requests before the wave retires
     // ---- leave: per-range partial tiles (summed by k_wgrad_reduce), bias partials by atomics ----
@@ -353,7 +313,8 @@ constexpr int F_BM = 32, F_NW = 8, F_THR = F_NW * 64;
 
 __global__ __launch_bounds__(F_THR) void k_mlp_fwd_r(const bf16* __restrict__ X, const float* __restrict__ ln_g, const float* __restrict__ ln_b,
                                                      const bf16* __restrict__ W1, const float* __restrict__ b1, const bf16* __restrict__ W2,
-                                                     const float* __restrict__ b2, const float* __restrict__ ls2, bf16* __restrict__ out, int64_t M) {
+                                                     const float* __restrict__ b2, const float* __restrict__ ls2, bf16* __restrict__ out, int64_t M,
+                                                     bf16* __restrict__ xn_out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* sA = reinterpret_cast<bf16*>(smem);            // [2][32][128]  LN(x)
     bf16* sH = sA + 2 * F_BM * 128;                      // [4][32][128]  GELU output, hidden chunk major
@@ -406,6 +367,10 @@ __global__ __launch_bounds__(F_THR) void k_mlp_fwd_r(const bf16* __restrict__ X,
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = v[e] * rstd * gmv[e] + btv[e];
         tile_store8(sA + (int)(t & 1) * F_BM * 128, r, sub * 8, v);
+        if (xn_out != nullptr) {                         // training: the backward pass streams LN(x) instead of recomputing it
+            const int64_t row = (tile0 + t) * F_BM + r;
+            if (row < M) store8(xn_out + row * 128 + sub * 8, v);
+        }
     };
     issue(0);
     issue(1);
@@ -489,7 +454,7 @@ int kasf_mlp_bwd_q_ranges(int64_t M) {
     const int64_t tiles = (M + Q_BM - 1) / Q_BM;
     return (int)(tiles < 64 ? tiles : 64);
 }
-void kasf_launch_mlp_bwd_q(hipStream_t s, const void* x, const void* g, const float* ln_g, const float* ln_b, const void* W1, const float* b1,
+void kasf_launch_mlp_bwd_q(hipStream_t s, const void* x, const void* xn, const void* g, const float* ln_g, const void* W1, const float* b1,
                            const void* W2ts, const void* W1t, void* dApart, float* partial, float* dW1, float* dW2, float* db1, float* gsum, void* g_in,
                            float* dgamma, float* dbeta, int64_t M) {
     const int ranges = kasf_mlp_bwd_q_ranges(M);
@@ -498,9 +463,9 @@ void kasf_launch_mlp_bwd_q(hipStream_t s, const void* x, const void* g, const fl
     const int used = (int)((tiles + tpr - 1) / tpr);             // ranges that own at least one tile
     float* p1 = partial;
     float* p2 = partial + (int64_t)used * 512 * 128;
-    const size_t sh = (size_t)(9 * Q_BM * 128) * sizeof(bf16);
+    const size_t sh = (size_t)(8 * Q_BM * 128) * sizeof(bf16);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_bwd_q<Q_NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    hipLaunchKernelGGL(k_mlp_bwd_q<Q_NW>, dim3(4 * used), dim3(Q_NW * 64), sh, s, (const bf16*)x, (const bf16*)g, ln_g, ln_b, (const bf16*)W1, b1, (const bf16*)W2ts,
+    hipLaunchKernelGGL(k_mlp_bwd_q<Q_NW>, dim3(4 * used), dim3(Q_NW * 64), sh, s, (const bf16*)xn, (const bf16*)g, (const bf16*)W1, b1, (const bf16*)W2ts,
                        (const bf16*)W1t, (bf16*)dApart, p1, p2, db1, M, tpr);
     kasf_launch_wgrad_reduce(s, p1, dW1, 128, 512, 128, used);
     kasf_launch_wgrad_reduce(s, p2, dW2, 512, 128, 512, used);
@@ -511,10 +476,10 @@ void kasf_launch_mlp_bwd_q(hipStream_t s, const void* x, const void* g, const fl
 }
 
 void kasf_launch_mlp_fwd_r(hipStream_t s, const void* x, const float* ln_g, const float* ln_b, const void* W1, const float* b1, const void* W2,
-                           const float* b2, const float* ls2, void* out, int64_t M) {
+                           const float* b2, const float* ls2, void* out, int64_t M, void* xn_out) {
     const int64_t tiles = (M + F_BM - 1) / F_BM;
     const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
     const size_t sh = (size_t)(9 * F_BM * 128) * sizeof(bf16);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_fwd_r), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    hipLaunchKernelGGL(k_mlp_fwd_r, dim3(grid), dim3(F_THR), sh, s, (const bf16*)x, ln_g, ln_b, (const bf16*)W1, b1, (const bf16*)W2, b2, ls2, (bf16*)out, M);
+    hipLaunchKernelGGL(k_mlp_fwd_r, dim3(grid), dim3(F_THR), sh, s, (const bf16*)x, ln_g, ln_b, (const bf16*)W1, b1, (const bf16*)W2, b2, ls2, (bf16*)out, M, (bf16*)xn_out);
 }

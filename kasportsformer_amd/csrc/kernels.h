@@ -43,8 +43,9 @@ void kasf_launch_pack(int dt, hipStream_t s, const float* params, void* arena, c
 
 // ---- k_mlp.hip ----
 // out = x + ls2 * (GELU(LN(x) W1^T + b1) W2^T + b2)
+// xn_out (optional, bf16 path): also store LN(x) for kasf_launch_mlp_bwd_q
 void kasf_launch_mlp_fwd(int dt, hipStream_t s, const void* x, const float* ln_g, const float* ln_b, const void* W1, const float* b1, const void* W2,
-                         const float* b2, const float* ls2, void* out, int64_t M);
+                         const float* b2, const float* ls2, void* out, int64_t M, void* xn_out = nullptr);
 // g_in = g + LNbwd(dA), also writes H = GELU(Z) and dZ ([M x 512] each) for the weight-gradient GEMMs
 void kasf_launch_mlp_bwd(int dt, hipStream_t s, const void* x, const void* g, const float* ln_g, const float* ln_b, const void* W1, const float* b1,
                          const void* W2t_scaled, const void* W1t, void* Hbuf, void* dZbuf, void* xn_buf, void* g_in, float* dgamma, float* dbeta,
@@ -53,12 +54,13 @@ void kasf_launch_mlp_bwd(int dt, hipStream_t s, const void* x, const void* g, co
 // ---- k_mlp2.hip (bf16): hidden-quarter MLP backward with fused weight gradients ----
 // dApart: 4*M*128 bf16 scratch; partial: >= 2*64*65536 floats; dW2 / gsum are the UNSCALED fc2 weight gradient and colsum(g)
 // (finish with kasf_launch_finalize_ls).  Writes g_in = g + LNbwd(dA) and accumulates dgamma/dbeta, dW1, db1.
-void kasf_launch_mlp_bwd_q(hipStream_t s, const void* x, const void* g, const float* ln_g, const float* ln_b, const void* W1, const float* b1,
+// xn = LN(x) as stored by the forward pass.
+void kasf_launch_mlp_bwd_q(hipStream_t s, const void* x, const void* xn, const void* g, const float* ln_g, const void* W1, const float* b1,
                            const void* W2ts, const void* W1t, void* dApart, float* partial, float* dW1, float* dW2, float* db1, float* gsum, void* g_in,
                            float* dgamma, float* dbeta, int64_t M);
 // bf16 forward with all weights resident in registers (persistent workgroups)
 void kasf_launch_mlp_fwd_r(hipStream_t s, const void* x, const float* ln_g, const float* ln_b, const void* W1, const float* b1, const void* W2,
-                           const float* b2, const float* ls2, void* out, int64_t M);
+                           const float* b2, const float* ls2, void* out, int64_t M, void* xn_out);
 void kasf_launch_wgrad_reduce(hipStream_t s, const float* partial, float* out, int64_t ldo, int N, int K, int splits);
 
 // ---- k_attn.hip ----

@@ -97,9 +97,12 @@ def test_mlp_forward(lib, cd, M):
     x = _rand(M, 128, seed=5)
     xd, w1, w2 = _dev(x, cd), _dev(p["W1"], cd), _dev(p["W2"], cd)
     out = torch.empty_like(xd)
+    xn = torch.empty_like(xd) if cd == "bf16" else None          # training mode also stores LN(x) for the fused backward
     _lib.check(lib.kasf_op_mlp_fwd(DT[cd][0], ptr(xd), ptr(_f32(p["g"])), ptr(_f32(p["b"])), ptr(w1), ptr(_f32(p["b1"])), ptr(w2),
-                                   ptr(_f32(p["b2"])), ptr(_f32(p["ls"])), ptr(out), M, stream()))
+                                   ptr(_f32(p["b2"])), ptr(_f32(p["ls"])), ptr(out), M, ptr(xn), stream()))
     torch.cuda.synchronize()
+    if xn is not None:
+        assert rel_err(_back(xn), _ln(_back(xd), p["g"], p["b"])) < TOL[cd]
     pr = dict(p, W1=_back(w1), W2=_back(w2))
     assert rel_err(_back(out), _mlp_ref(_back(xd), pr)) < TOL[cd]
 
@@ -158,7 +161,10 @@ def test_mlp_backward_fused_bf16(lib, M):
     gin = torch.empty_like(xd)
     z = lambda *s: torch.zeros(*s, device="cuda")
     dW1, dW2, db1, gsum, dg, db = z(512, 128), z(128, 512), z(512), z(128), z(128), z(128)
-    _lib.check(lib.kasf_op_mlp_bwd_fused(ptr(xd), ptr(gd), ptr(_f32(p["g"])), ptr(_f32(p["b"])), ptr(w1), ptr(_f32(p["b1"])), ptr(w2ts), ptr(w1t),
+    out, xn = torch.empty_like(xd), torch.empty_like(xd)           # the forward pass leaves LN(x) behind for the backward kernel
+    _lib.check(lib.kasf_op_mlp_fwd(1, ptr(xd), ptr(_f32(p["g"])), ptr(_f32(p["b"])), ptr(w1), ptr(_f32(p["b1"])), ptr(_dev(p["W2"], cd)), ptr(_f32(p["b2"])),
+                                   ptr(_f32(p["ls"])), ptr(out), M, ptr(xn), stream()))
+    _lib.check(lib.kasf_op_mlp_bwd_fused(ptr(xd), ptr(xn), ptr(gd), ptr(_f32(p["g"])), ptr(w1), ptr(_f32(p["b1"])), ptr(w2ts), ptr(w1t),
                                          ptr(dap), ptr(part), ptr(dW1), ptr(dW2), ptr(db1), ptr(gsum), ptr(gin), ptr(dg), ptr(db), M, stream()))
     torch.cuda.synchronize()
     xr = _back(xd).requires_grad_(True)
