@@ -51,11 +51,12 @@ __global__ __launch_bounds__(R_THR) void k_dgrad_r(const bf16* __restrict__ dY, 
 #pragma unroll
     for (int e = 0; e < 8; ++e) { gm[e] = gamma[sub * 8 + e]; bt[e] = XN ? beta[sub * 8 + e] : 0.f; dg[e] = 0.f; db[e] = 0.f; }
 
-    auto issue = [&](int64_t t) {                        // exactly NSTREAM LDS-direct loads per wave per call
+    auto nxr = [](int sl) { return sl == RING - 1 ? 0 : sl + 1; };   // ring slots roll (no 64-bit modulo in the loop)
+    auto issue = [&](int64_t t, int sl) {                // exactly NSTREAM LDS-direct loads per wave per call
         const int64_t tt = t < ntiles ? t : ntiles - 1;
         const int64_t row0 = (tile0 + tt) * R_BM;
         const int nvalid = (int)((M - row0) < R_BM ? (M - row0) : R_BM);
-        bf16* slot = sRing + (int)(t % RING) * SLOT;
+        bf16* slot = sRing + sl * SLOT;
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) stage_tile_async<bf16, R_BM, R_THR>(slot + kc * R_TILE, dY + row0 * Kd + kc * 128, Kd, nvalid);
         stage_tile_async<bf16, R_BM, R_THR>(slot + O_X, X + row0 * 128, 128, nvalid);
@@ -63,14 +64,15 @@ __global__ __launch_bounds__(R_THR) void k_dgrad_r(const bf16* __restrict__ dY, 
         if (ADD) stage_tile_async<bf16, R_BM, R_THR>(slot + O_ADD, dxn_add + row0 * 128, 128, nvalid);
         if (ACC) stage_tile_async<bf16, R_BM, R_THR>(slot + O_ACC, out + row0 * 128, 128, nvalid);
     };
-    issue(0);
-    if (RING == 3) { issue(1); wait_async_le<NSTREAM>(); }   // tile 0 landed, tile 1 in flight
-    for (int64_t t = 0; t < ntiles; ++t) {
-        const bf16* slot = sRing + (int)(t % RING) * SLOT;
+    issue(0, 0);
+    if (RING == 3) { issue(1, 1); wait_async_le<NSTREAM>(); }   // tile 0 landed, tile 1 in flight
+    int sl = 0;
+    for (int64_t t = 0; t < ntiles; ++t, sl = nxr(sl)) {
+        const bf16* slot = sRing + sl * SLOT;
         const int64_t row0 = (tile0 + t) * R_BM;
         if (RING == 2) wait_async();
         barrier_keep_async();                            // B1: tile t visible to every wave; everyone is past tile t-1
-        if (RING == 2) issue(t + 1);
+        if (RING == 2) issue(t + 1, nxr(sl));
         {   // ---- GEMM: 16 features x 32 tokens per wave ----
             f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
             bf16x8 fb[2][2];
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(R_THR) void k_dgrad_r(const bf16* __restrict__ dY, 
             }
         }
         barrier_keep_async();                            // B2: the [32][128] dxn tile is complete
-        if (RING == 3) issue(t + 2);                     // slot (t+2)%3 held tile t-1, which everyone finished before B1
+        if (RING == 3) issue(t + 2, nxr(nxr(sl)));       // slot (t+2)%3 held tile t-1, which everyone finished before B1
         {   // ---- LayerNorm backward: one 16-lane group per token row ----
             const int64_t row = row0 + rl;
             float d[8], x[8], o[8];
@@ -218,17 +220,18 @@ __global__ __launch_bounds__(R_THR) void k_linear_r(const bf16* __restrict__ A, 
 #pragma unroll
     for (int e = 0; e < 8; ++e) { gm[e] = LN ? ln_g[sub * 8 + e] : 1.f; bt[e] = LN ? ln_b[sub * 8 + e] : 0.f; }
 
-    auto issue = [&](int64_t t) {
+    auto nx3 = [](int sl) { return sl == 2 ? 0 : sl + 1; };
+    auto issue = [&](int64_t t, int sl) {
         const int64_t tt = t < ntiles ? t : ntiles - 1;
         const int64_t row0 = (tile0 + tt) * R_BM;
         const int nvalid = (int)((M - row0) < R_BM ? (M - row0) : R_BM);
-        bf16* slot = sRing + (int)(t % 3) * SLOT;
+        bf16* slot = sRing + sl * SLOT;
         stage_tile_async<bf16, R_BM, R_THR>(slot, A + row0 * 128, 128, nvalid);
         if (RES) stage_tile_async<bf16, R_BM, R_THR>(slot + R_TILE, resid + row0 * 128, 128, nvalid);
     };
-    auto layernorm = [&](int64_t t) {                    // row rl of tile t: raw slot -> sA[t & 1] (+ xn_out)
+    auto layernorm = [&](int64_t t, int sl) {            // row rl of tile t: raw slot -> sA[t & 1] (+ xn_out)
         float v[8];
-        tile_load8(sRing + (int)(t % 3) * SLOT, rl, sub * 8, v);
+        tile_load8(sRing + sl * SLOT, rl, sub * 8, v);
         float s = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) s += v[e];
@@ -243,12 +246,13 @@ __global__ __launch_bounds__(R_THR) void k_linear_r(const bf16* __restrict__ A, 
         const int64_t row = (tile0 + t) * R_BM + rl;
         if (xn_out != nullptr && row < M) store8(xn_out + row * 128 + sub * 8, v);
     };
-    issue(0);
-    issue(1);
+    issue(0, 0);
+    issue(1, 1);
     wait_async_le<NSTREAM>();
-    if (LN) layernorm(0);
-    for (int64_t t = 0; t < ntiles; ++t) {
-        const bf16* slot = sRing + (int)(t % 3) * SLOT;
+    if (LN) layernorm(0, 0);
+    int sl = 0;
+    for (int64_t t = 0; t < ntiles; ++t, sl = nx3(sl)) {
+        const bf16* slot = sRing + sl * SLOT;
         const bf16* cA = LN ? sA + (int)(t & 1) * R_TILE : slot;
         const int64_t row0 = (tile0 + t) * R_BM;
         barrier_keep_async();                            // B1: operand tile t complete and visible; everyone is past the copy-out of tile t-1
@@ -285,9 +289,9 @@ __global__ __launch_bounds__(R_THR) void k_linear_r(const bf16* __restrict__ A, 
                 }
         }
         barrier_keep_async();                            // B2: output tile complete
-        issue(t + 2);                                    // slot (t+2)%3 held tile t-1: its last reader (epilogue of t-1) is behind B1
+        issue(t + 2, nx3(nx3(sl)));                      // slot (t+2)%3 held tile t-1: its last reader (epilogue of t-1) is behind B1
         wait_async_le<NSTREAM>();                        // tile t+1 landed (only tile t+2 outstanding); this tile's stores come after
-        if (LN && t + 1 < ntiles) layernorm(t + 1);
+        if (LN && t + 1 < ntiles) layernorm(t + 1, nx3(sl));
 #pragma unroll
         for (int c = 0; c < NC; ++c) {                   // 32 rows x 16 NC chunks of 16 bytes over 512 threads
             const int chunk = c * R_THR + threadIdx.x, r = chunk / (16 * NC), cc = chunk % (16 * NC);

@@ -18,6 +18,7 @@
 #include "common.h"
 #include "kernels.h"
 #include "tile_ops.h"
+#include <type_traits>
 
 namespace {
 
@@ -90,22 +91,24 @@ __global__ __launch_bounds__(NW * 64) void k_mlp_bwd_q(const bf16* __restrict__ 
     // "all but the youngest LPI" == "everything requested before the last issue".  Rows past M are clamped copies; their H / dZ are
     // zeroed below, so they reach neither weight gradient.
     constexpr int LPI = 2 * (Q_BM / 4 / NW);
-    auto stage_issue = [&](int64_t t) {
+    auto nx3 = [](int sl) { return sl == 2 ? 0 : sl + 1; };     // ring slots roll (a 64-bit "% 3" is a dozen scalar instructions)
+    auto stage_issue = [&](int64_t t, int sl) {
         if (t < ntiles) {
             const int64_t row0 = (tile0 + t) * Q_BM;
             const int nvalid = (int)((M - row0) < Q_BM ? (M - row0) : Q_BM);
-            stage_tile_async<bf16, Q_BM, NTHR>(sG + (int)(t % 3) * Q_BM * 128, G + row0 * 128, 128, nvalid);
-            stage_tile_async<bf16, Q_BM, NTHR>(sA + (int)(t % 3) * Q_BM * 128, XN + row0 * 128, 128, nvalid);
+            stage_tile_async<bf16, Q_BM, NTHR>(sG + sl * Q_BM * 128, G + row0 * 128, 128, nvalid);
+            stage_tile_async<bf16, Q_BM, NTHR>(sA + sl * Q_BM * 128, XN + row0 * 128, 128, nvalid);
         } else {                                         // keep the per-issue load count constant (harmless re-read of the first row)
-            stage_tile_async<bf16, Q_BM, NTHR>(sG + (int)(t % 3) * Q_BM * 128, G, 128, 1);
-            stage_tile_async<bf16, Q_BM, NTHR>(sA + (int)(t % 3) * Q_BM * 128, XN, 128, 1);
+            stage_tile_async<bf16, Q_BM, NTHR>(sG + sl * Q_BM * 128, G, 128, 1);
+            stage_tile_async<bf16, Q_BM, NTHR>(sA + sl * Q_BM * 128, XN, 128, 1);
         }
     };
-    stage_issue(0);
-    stage_issue(1);
-    for (int64_t t = 0; t < ntiles; ++t) {
-        const bf16* cA = sA + (int)(t % 3) * Q_BM * 128;
-        const bf16* cG = sG + (int)(t % 3) * Q_BM * 128;
+    stage_issue(0, 0);
+    stage_issue(1, 1);
+    int sl = 0;
+    for (int64_t t = 0; t < ntiles; ++t, sl = nx3(sl)) {
+        const bf16* cA = sA + sl * Q_BM * 128;
+        const bf16* cG = sG + sl * Q_BM * 128;
         const int64_t row0 = (tile0 + t) * Q_BM;
         const int nvalid = (int)((M - row0) < Q_BM ? (M - row0) : Q_BM);
         wait_async_le<LPI>();                            // g(t) (requested two tiles ago) is complete; the youngest issue stays in flight
@@ -136,23 +139,28 @@ __global__ __launch_bounds__(NW * 64) void k_mlp_bwd_q(const bf16* __restrict__ 
                     }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            // rows past M (only the last tile of the last range has any) must not leak GELU(b1) into anything: masked variant there only
+            auto epilogue = [&](auto MASKED) {
+                constexpr bool masked = decltype(MASKED)::value;
 #pragma unroll
-            for (int nt = 0; nt < NTW; ++nt)
+                for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < Q_MT; ++mt) {
-                    float h[4], dz[4];
-                    const float live = mt * 16 + i < nvalid ? 1.0f : 0.0f;     // padded tokens must not leak GELU(b1) into anything
+                    for (int mt = 0; mt < Q_MT; ++mt) {
+                        float h[4], dz[4];
+                        const float live = (!masked || mt * 16 + i < nvalid) ? 1.0f : 0.0f;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float dg;
-                        gelu_and_grad<bf16>(accZ[nt][mt][r] + bias4[nt][r], h[r], dg);
-                        h[r] *= live;
-                        dz[r] = accH[nt][mt][r] * dg * live;
-                        db1acc[nt][r] += dz[r];
+                        for (int r = 0; r < 4; ++r) {
+                            float dg;
+                            gelu_and_grad<bf16>(accZ[nt][mt][r] + bias4[nt][r], h[r], dg);
+                            dz[r] = accH[nt][mt][r] * dg;
+                            if (masked) { h[r] *= live; dz[r] *= live; }
+                            db1acc[nt][r] += dz[r];
+                        }
+                        store4(sH + Tile<bf16>::off4(mt * 16 + i, h0 + 16 * nt + 4 * g), h);
+                        store4(sD + Tile<bf16>::off4(mt * 16 + i, h0 + 16 * nt + 4 * g), dz);
                     }
-                    store4(sH + Tile<bf16>::off4(mt * 16 + i, h0 + 16 * nt + 4 * g), h);
-                    store4(sD + Tile<bf16>::off4(mt * 16 + i, h0 + 16 * nt + 4 * g), dz);
-                }
+            };
+            if (nvalid == Q_BM) epilogue(std::false_type{}); else epilogue(std::true_type{});
         }
         barrier_keep_async();                            // B2: H_q / dZ_q of all 128 hidden units are in LDS
         // ---- dA_q partial: this wave's channels x 64 tokens ----
@@ -187,7 +195,7 @@ __global__ __launch_bounds__(NW * 64) void k_mlp_bwd_q(const bf16* __restrict__ 
                 }
             }
         }
-        stage_issue(t + 2);                              // after the dA stores: older than this issue == safe to count on
+        stage_issue(t + 2, nx3(nx3(sl)));                // after the dA stores: older than this issue == safe to count on
         // ---- weight gradients: reduction over the tokens of the tile (32-token k-steps), pipelined stages ----
         {
             bf16x8 ra[2][2], cb[2][CT];
@@ -339,13 +347,14 @@ __global__ __launch_bounds__(F_THR) void k_mlp_fwd_r(const bf16* __restrict__ X,
     for (int nt = 0; nt < 4; ++nt) b1v[nt] = *reinterpret_cast<const f32x4*>(b1 + 64 * w + 16 * nt + 4 * g);
     const f32x4 b2v = *reinterpret_cast<const f32x4*>(b2 + 16 * w + 4 * g), lsv = *reinterpret_cast<const f32x4*>(ls2 + 16 * w + 4 * g);
 
-    auto issue = [&](int64_t t) {                        // exactly one LDS-direct load per wave per call
+    auto nx3 = [](int sl) { return sl == 2 ? 0 : sl + 1; };
+    auto issue = [&](int64_t t, int sl) {                // exactly one LDS-direct load per wave per call
         const int64_t tt = t < ntiles ? t : ntiles - 1;
         const int64_t row0 = (tile0 + tt) * F_BM;
         const int nvalid = (int)((M - row0) < F_BM ? (M - row0) : F_BM);
-        stage_tile_async<bf16, F_BM, F_THR>(sXr + (int)(t % 3) * F_BM * 128, X + row0 * 128, 128, nvalid);
+        stage_tile_async<bf16, F_BM, F_THR>(sXr + sl * F_BM * 128, X + row0 * 128, 128, nvalid);
     };
-    auto layernorm = [&](int64_t t) {                    // wave w normalises the 4 rows its own load delivered
+    auto layernorm = [&](int64_t t, int sl) {            // wave w normalises the 4 rows its own load delivered
         float gmv[8], btv[8];
         {
             const f32x4 g0 = *reinterpret_cast<const f32x4*>(ln_g + sub * 8), g1 = *reinterpret_cast<const f32x4*>(ln_g + sub * 8 + 4);
@@ -355,7 +364,7 @@ __global__ __launch_bounds__(F_THR) void k_mlp_fwd_r(const bf16* __restrict__ X,
         }
         const int r = 4 * w + (lane >> 4);
         float v[8];
-        tile_load8(sXr + (int)(t % 3) * F_BM * 128, r, sub * 8, v);
+        tile_load8(sXr + sl * F_BM * 128, r, sub * 8, v);
         float s = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) s += v[e];
@@ -372,13 +381,14 @@ __global__ __launch_bounds__(F_THR) void k_mlp_fwd_r(const bf16* __restrict__ X,
             if (row < M) store8(xn_out + row * 128 + sub * 8, v);
         }
     };
-    issue(0);
-    issue(1);
+    issue(0, 0);
+    issue(1, 1);
     wait_async_le<1>();
-    layernorm(0);
-    for (int64_t t = 0; t < ntiles; ++t) {
+    layernorm(0, 0);
+    int sl = 0;
+    for (int64_t t = 0; t < ntiles; ++t, sl = nx3(sl)) {
         const bf16* cA = sA + (int)(t & 1) * F_BM * 128;
-        const bf16* cX = sXr + (int)(t % 3) * F_BM * 128;
+        const bf16* cX = sXr + sl * F_BM * 128;
         const int64_t row0 = (tile0 + t) * F_BM;
         barrier_keep_async();                            // B1: LN(x_t) complete; everyone is past tile t-1
         {   // ---- GEMM1: this wave's 64 hidden units x 32 tokens, then GELU -> sH ----
@@ -409,7 +419,7 @@ __global__ __launch_bounds__(F_THR) void k_mlp_fwd_r(const bf16* __restrict__ X,
                 }
         }
         barrier_keep_async();                            // B2: the whole [32][512] hidden tile is in LDS
-        issue(t + 2);
+        issue(t + 2, nx3(nx3(sl)));
         {   // ---- GEMM2: this wave's 16 output channels x 32 tokens over all 512 hidden units ----
             f32x4 acc2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
             bf16x8 fh[2][2];
@@ -430,7 +440,7 @@ __global__ __launch_bounds__(F_THR) void k_mlp_fwd_r(const bf16* __restrict__ X,
             // x(t+1) has landed when only the youngest request (t+2) is still outstanding; this tile's output stores are
             // issued AFTER this wait so that they never count as "youngest" (they get the whole next tile to drain)
             wait_async_le<1>();
-            if (t + 1 < ntiles) layernorm(t + 1);
+            if (t + 1 < ntiles) layernorm(t + 1, nx3(sl));
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 const int64_t row = row0 + mt * 16 + i;
