@@ -328,17 +328,26 @@ __global__ __launch_bounds__(256) void k_gate_bwd(const T* __restrict__ g, const
     }
 }
 
-// dW[1152] / db[3] += column sums of part[nb][GATE_PART_LD]
+// dW[1152] / db[3] += column sums of part[nb][GATE_PART_LD].  A workgroup owns 16 columns; its 16 row groups each sum every 16th partial
+// row with 8 independent loads in flight, then meet in LDS (fixed order => bitwise reproducible).
 __global__ __launch_bounds__(256) void k_gate_reduce(const float* __restrict__ part, float* __restrict__ dW, float* __restrict__ db, int nb) {
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
-    __shared__ float sP[4][64];
-    float s = 0.f;
-    if (c < 1155)
-        for (int k = q; k < nb; k += 4) s += part[(int64_t)k * GATE_PART_LD + c];
-    sP[q][threadIdx.x & 63] = s;
+    const int cl = threadIdx.x & 15, q = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
+    __shared__ float sP[16][17];
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (c < 1155) {
+        int k = q;
+        for (; k + 7 * 16 < nb; k += 8 * 16) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s[u] += part[(int64_t)(k + 16 * u) * GATE_PART_LD + c];
+        }
+        for (; k < nb; k += 16) s[0] += part[(int64_t)k * GATE_PART_LD + c];
+    }
+    sP[q][cl] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
     __syncthreads();
     if (q == 0 && c < 1155) {
-        const float t = (sP[0][threadIdx.x] + sP[1][threadIdx.x]) + (sP[2][threadIdx.x] + sP[3][threadIdx.x]);
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sP[k][cl];
         if (c < 1152) dW[c] += t; else db[c - 1152] += t;
     }
 }
@@ -610,7 +619,7 @@ void kasf_launch_gate_bwd(int dt, hipStream_t s, const void* g, const void* g1, 
     if (part == nullptr || (int64_t)grid * GATE_PART_LD > part_floats) { part = nullptr; if (grid > 256) grid = 256; }   // atomics: few workgroups
     if (dt == KASF_F32) hipLaunchKernelGGL(k_gate_bwd<float>, dim3(grid), dim3(256), 0, s, (const float*)g, (const float*)g1, (const float*)g2, (const float*)xa, (const float*)xg, (const float*)xb, W, alpha, (float*)ga, (float*)gg, (float*)gb, dW, db, part, M, adaptive);
     else hipLaunchKernelGGL(k_gate_bwd<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)g, (const bf16*)g1, (const bf16*)g2, (const bf16*)xa, (const bf16*)xg, (const bf16*)xb, W, alpha, (bf16*)ga, (bf16*)gg, (bf16*)gb, dW, db, part, M, adaptive);
-    if (part != nullptr && adaptive) hipLaunchKernelGGL(k_gate_reduce, dim3(19), dim3(256), 0, s, part, dW, db, (int)grid);
+    if (part != nullptr && adaptive) hipLaunchKernelGGL(k_gate_reduce, dim3(73), dim3(256), 0, s, part, dW, db, (int)grid);
 }
 void kasf_launch_head_fwd(int dt, hipStream_t s, const void* rep, const float* W, const float* b, float* out, int64_t M) {
     const unsigned grid = ew_grid(M * 16);

@@ -8,11 +8,11 @@
 Corrections (MI355X_MICROARCH.md, HBM section): counters are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of wide
 (16 B/lane) coalesced reads, so it is doubled; WRITE_SIZE is exact for 16 B/lane stores and float atomics.
 """
-import collections, csv, glob, json, re, sys
+import collections, csv, glob, json, os, re, sys
 
 
 def per_kernel(d, counter):
-    f = glob.glob(f"{d}/*/*counter_collection.csv")[0]
+    f = max(glob.glob(f"{d}/*/*counter_collection.csv"), key=os.path.getmtime)     # newest run in the directory
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == counter:
