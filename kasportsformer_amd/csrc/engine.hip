@@ -363,7 +363,8 @@ void block_backward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void*
     if (c.dt == KASF_BF16) {
         // hidden-quarter kernel: dgrad + both weight gradients fused, then the 4-way partial sum + LayerNorm backward
         kasf_launch_mlp_bwd_q(c.s, c.w(w.x_mid), c.w(w.xn2), g_out, P + o.n2w, c.pk(o.p_fc1), P + o.fc1b, c.pk(o.p_fc2Ts), c.pk(o.p_fc1T), c.w(sc.hbuf),
-                              (float*)c.w(sc.wg_part), G + o.fc1w, G + o.fc2w, G + o.fc1b, G + o.fc2b, g_mid, G + o.n2w, G + o.n2b, c.M);
+                              (float*)c.w(sc.wg_part), G + o.fc1w, G + o.fc2w, G + o.fc1b, G + o.fc2b, g_mid, G + o.n2w, G + o.n2b, c.M, P + o.fc2w, P + o.fc2b,
+                              P + o.ls2, G + o.ls2);        // includes the fc2 layer-scale finish
     } else {
         kasf_launch_mlp_bwd(c.dt, c.s, c.w(w.x_mid), g_out, P + o.n2w, P + o.n2b, c.pk(o.p_fc1), P + o.fc1b, c.pk(o.p_fc2Ts), c.pk(o.p_fc1T), c.w(sc.hbuf),
                             c.w(sc.dzbuf), c.w(sc.xn_a), g_mid, G + o.n2w, G + o.n2b, c.M);
@@ -371,8 +372,8 @@ void block_backward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void*
                           (float*)c.w(sc.wg_part), WG_PARTIAL_FLOATS);
         kasf_launch_wgrad(c.dt, c.s, g_out, 128, 128, c.w(sc.hbuf), 512, 512, nullptr, nullptr, G + o.fc2w, 512, G + o.fc2b, c.M, (float*)c.w(sc.wg_part),
                           WG_PARTIAL_FLOATS);
+        kasf_launch_finalize_ls(c.s, G + o.fc2w, P + o.fc2w, P + o.fc2b, P + o.ls2, G + o.fc2b, G + o.ls2, 128, 512);
     }
-    kasf_launch_finalize_ls(c.s, G + o.fc2w, P + o.fc2w, P + o.fc2b, P + o.ls2, G + o.fc2b, G + o.ls2, 128, 512);
     // ---- mixer half ----
     if (o.kind == KIND_GRAPH) {
         kasf_launch_gcn_bwd1(c.dt, c.s, g_mid, c.w(w.xn), c.w(w.y), (const float*)c.w(w.coef), P + o.ls1, c.w(sc.rbuf), G + o.ls1, (double*)c.w(w.bstats),

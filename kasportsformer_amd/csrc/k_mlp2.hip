@@ -457,6 +457,73 @@ __global__ __launch_bounds__(F_THR) void k_mlp_fwd_r(const bf16* __restrict__ X,
     wait_async();
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// End of the MLP backward in ONE launch: sums the per-range partial tiles of dW1 [512][128] and dW2 [128][512] (fixed order)
+// and, for fc2, applies the layer-scale algebra that k_finalize_ls would: with G = g^T H (unscaled),
+//   dls[c] += sum_k W2[c][k] G[c][k] + b2[c] gsum[c];   dW2[c][:] += ls[c] G[c][:];   db2[c] = ls[c] gsum[c].
+// Workgroups 0..127 own 4 rows of dW1 each, workgroups 128..255 one row of dW2 each (512 floats per workgroup); the two
+// halves of a workgroup take the even / odd splits.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mlp_wfinish(const float* __restrict__ p1, const float* __restrict__ p2, float* __restrict__ dW1,
+                                                     float* __restrict__ dW2, int splits, const float* __restrict__ W2, const float* __restrict__ b2,
+                                                     const float* __restrict__ ls, float* __restrict__ gsum_db2, float* __restrict__ dls) {
+    __shared__ f32x4 sHalf[128];
+    __shared__ float sDot[2];
+    const int lane = threadIdx.x & 127, half = threadIdx.x >> 7;
+    const bool second = blockIdx.x >= 128;
+    const int blk = second ? blockIdx.x - 128 : blockIdx.x;
+    const float* part = second ? p2 : p1;
+    const int64_t e = (int64_t)blk * 512 + lane * 4;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
+    int z = half;
+    for (; z + 2 < splits; z += 4) {
+        const f32x4 u = *reinterpret_cast<const f32x4*>(part + (int64_t)z * 65536 + e);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(part + (int64_t)(z + 2) * 65536 + e);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { a[q] += u[q]; b[q] += v[q]; }
+    }
+    if (z < splits) {
+        const f32x4 u = *reinterpret_cast<const f32x4*>(part + (int64_t)z * 65536 + e);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[q] += u[q];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a[q] += b[q];
+    if (half == 1) sHalf[lane] = a;
+    __syncthreads();
+    if (half == 0) {
+        const f32x4 o = sHalf[lane];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[q] += o[q];                    // a = the summed gradient (G for fc2)
+    }
+    const bool fin = second && W2 != nullptr;
+    float dot = 0.f;
+    if (half == 0) {
+        float* dst = (second ? dW2 : dW1) + e;
+        f32x4 cur = *reinterpret_cast<f32x4*>(dst);
+        const float l = fin ? ls[blk] : 1.0f;
+        if (fin) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(W2 + e);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dot += w[q] * a[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cur[q] += l * a[q];
+        *reinterpret_cast<f32x4*>(dst) = cur;
+    }
+    if (fin) {
+        dot = reduce64(dot);
+        if (half == 0 && (threadIdx.x & 63) == 0) sDot[threadIdx.x >> 6] = dot;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float gs = gsum_db2[blk];
+            dls[blk] += sDot[0] + sDot[1] + b2[blk] * gs;
+            gsum_db2[blk] = gs * ls[blk];
+        }
+    }
+}
+
 }  // namespace
 
 // scratch needs: dApart = 4*M*128 bf16;  partial >= 2 * ranges * 65536 floats (returned through *ranges_out)
@@ -466,7 +533,7 @@ int kasf_mlp_bwd_q_ranges(int64_t M) {
 }
 void kasf_launch_mlp_bwd_q(hipStream_t s, const void* x, const void* xn, const void* g, const float* ln_g, const void* W1, const float* b1,
                            const void* W2ts, const void* W1t, void* dApart, float* partial, float* dW1, float* dW2, float* db1, float* gsum, void* g_in,
-                           float* dgamma, float* dbeta, int64_t M) {
+                           float* dgamma, float* dbeta, int64_t M, const float* W2, const float* b2, const float* ls2, float* dls2) {
     const int ranges = kasf_mlp_bwd_q_ranges(M);
     const int64_t tiles = (M + Q_BM - 1) / Q_BM;
     const int tpr = (int)((tiles + ranges - 1) / ranges);
@@ -477,12 +544,12 @@ void kasf_launch_mlp_bwd_q(hipStream_t s, const void* x, const void* xn, const v
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_bwd_q<Q_NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     hipLaunchKernelGGL(k_mlp_bwd_q<Q_NW>, dim3(4 * used), dim3(Q_NW * 64), sh, s, (const bf16*)xn, (const bf16*)g, (const bf16*)W1, b1, (const bf16*)W2ts,
                        (const bf16*)W1t, (bf16*)dApart, p1, p2, db1, M, tpr);
-    kasf_launch_wgrad_reduce(s, p1, dW1, 128, 512, 128, used);
-    kasf_launch_wgrad_reduce(s, p2, dW2, 512, 128, 512, used);
     int64_t blocks = (M + 15) / 16;
     if (blocks > 512) blocks = 512;                     // few blocks: every block ends with 384 same-address atomics (contended atomics serialise)
     hipLaunchKernelGGL(k_lnbwd_sum4, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16*)dApart, (const bf16*)x, (const bf16*)g, ln_g, (bf16*)g_in, dgamma,
                        dbeta, gsum, M);
+    // after k_lnbwd_sum4 (gsum complete): both partial reductions + the fc2 layer-scale algebra (W2 == nullptr: dW2 stays unscaled)
+    hipLaunchKernelGGL(k_mlp_wfinish, dim3(256), dim3(256), 0, s, p1, p2, dW1, dW2, used, W2, b2, ls2, gsum, dls2);
 }
 
 void kasf_launch_mlp_fwd_r(hipStream_t s, const void* x, const float* ln_g, const float* ln_b, const void* W1, const float* b1, const void* W2,

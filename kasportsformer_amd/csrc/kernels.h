@@ -57,7 +57,8 @@ void kasf_launch_mlp_bwd(int dt, hipStream_t s, const void* x, const void* g, co
 // xn = LN(x) as stored by the forward pass.
 void kasf_launch_mlp_bwd_q(hipStream_t s, const void* x, const void* xn, const void* g, const float* ln_g, const void* W1, const float* b1,
                            const void* W2ts, const void* W1t, void* dApart, float* partial, float* dW1, float* dW2, float* db1, float* gsum, void* g_in,
-                           float* dgamma, float* dbeta, int64_t M);
+                           float* dgamma, float* dbeta, int64_t M, const float* W2 = nullptr, const float* b2 = nullptr, const float* ls2 = nullptr,
+                           float* dls2 = nullptr);   // W2/b2/ls2/dls2 (fp32 masters): also finish fc2 (dls2, scaled dW2, db2 = ls2 * gsum in place)
 // bf16 forward with all weights resident in registers (persistent workgroups)
 void kasf_launch_mlp_fwd_r(hipStream_t s, const void* x, const float* ln_g, const float* ln_b, const void* W1, const float* b1, const void* W2,
                            const float* b2, const float* ls2, void* out, int64_t M, void* xn_out);
