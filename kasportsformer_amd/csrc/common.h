@@ -264,6 +264,20 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_base) {
                  : "v"(gsrc), "s"(lds_base)
                  : "memory");
 }
+// Same, with the address split into a wave-uniform 64-bit base (SGPR pair) and a 32-bit per-lane byte offset: per tile only the base moves
+// (two scalar adds) instead of a 64-bit vector address per lane.
+__device__ __forceinline__ void glds16_s(const void* ubase, unsigned lane_off, unsigned lds_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(lane_off), "s"(ubase), "s"(lds_base)
+                 : "memory");
+}
+__device__ __forceinline__ const void* uniform_ptr(const void* p) {      // tells the compiler the pointer is wave-uniform (lives in SGPRs)
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const void*)(((unsigned long long)hi << 32) | lo);
+}
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
 }
@@ -276,12 +290,14 @@ __device__ __forceinline__ void stage_tile_async(T* sT, const T* src, int64_t ld
     static_assert(IPW >= 1, "tile too small for this workgroup size");
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const unsigned base = __builtin_amdgcn_readfirstlane(lds_addr(sT));
+    const void* ub = uniform_ptr(src);                   // every caller passes a per-tile (wave-uniform) base
+    const unsigned ldb = (unsigned)ld * (unsigned)sizeof(T);
 #pragma unroll
     for (int t = 0; t < IPW; ++t) {
         const int inst = w * IPW + t;
         const int row = inst * RPI + lane / CPR, pc = lane % CPR, c = pc ^ (row & 15);
         const int srow = row < nvalid ? row : nvalid - 1;
-        glds16(src + (int64_t)srow * ld + c * EPC, base + (unsigned)inst * 1024u);
+        glds16_s(ub, (unsigned)srow * ldb + (unsigned)(c * EPC) * (unsigned)sizeof(T), base + (unsigned)inst * 1024u);
     }
 }
 __device__ __forceinline__ void wait_async() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
