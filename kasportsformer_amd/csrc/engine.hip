@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -32,6 +33,11 @@ struct BlockOff {
 struct LayerOff { BlockOff blk[6]; int64_t fus_w, fus_b, begin, end; };
 struct TopOff { int64_t norm_w, norm_b, fc_w, fc_b, head_w, head_b, p_fc, p_fcT, begin, end; };
 
+// KASF_SINGLE_STREAM=1: run the three branches of a layer back to back on the caller's stream (measurement / debugging switch)
+static bool single_stream() {
+    static const bool v = getenv("KASF_SINGLE_STREAM") != nullptr;
+    return v;
+}
 constexpr int64_t WG_PARTIAL_FLOATS = 2 * 64 * 65536;       // per-split weight-gradient tiles: 256 workgroups x 128x128, or 64 ranges x (dW1 + dW2) of the MLP
 
 struct BlkWs { int64_t qkv, kv, o, xn, y, mask, x_mid, xn2, x_out, stats, bstats, coef; };
@@ -571,15 +577,19 @@ int kasf_forward(const kasf_model* m, const float* params, const void* packed, f
         for (int br = 0; br < 3; ++br) {
             Ctx cb = c;
             if (br > 0) {
-                cb.s = m->side[br - 1];
-                HIPCHK(hipStreamWaitEvent(cb.s, m->ev_fork, 0));
+                cb.s = single_stream() ? c.s : m->side[br - 1];
+                if (!single_stream()) HIPCHK(hipStreamWaitEvent(cb.s, m->ev_fork, 0));
             }
             const void* in0 = (br == 2 && l == 0) ? c.w(p.xb) : xcur;         // layer 0: bone branch starts from the bone embedding (:332-336)
             block_forward(cb, lo.blk[2 * br], lw.b[2 * br], in0, c.w(p.xl), p, p.sc[br]);
             block_forward(cb, lo.blk[2 * br + 1], lw.b[2 * br + 1], c.w(lw.b[2 * br].x_out), c.w(p.xl), p, p.sc[br]);
             if (br > 0) {
-                HIPCHK(hipEventRecord(m->ev_join[br - 1], cb.s));
-                HIPCHK(hipStreamWaitEvent(c.s, m->ev_join[br - 1], 0));
+                if (!single_stream()) {
+                    if (!single_stream()) {
+                        HIPCHK(hipEventRecord(m->ev_join[br - 1], cb.s));
+                        HIPCHK(hipStreamWaitEvent(c.s, m->ev_join[br - 1], 0));
+                    }
+                }
             }
         }
         kasf_launch_gate_fwd(c.dt, c.s, c.w(lw.b[1].x_out), c.w(lw.b[3].x_out), c.w(lw.b[5].x_out), params + lo.fus_w, params + lo.fus_b, c.w(lw.gate_out),
@@ -637,8 +647,8 @@ int kasf_backward(const kasf_model* m, const float* params, const void* packed, 
             for (int br = 0; br < 3; ++br) {
                 Ctx cb = c;
                 if (br > 0) {
-                    cb.s = m->side[br - 1];
-                    HIPCHK(hipStreamWaitEvent(cb.s, m->ev_fork, 0));
+                    cb.s = single_stream() ? c.s : m->side[br - 1];
+                    if (!single_stream()) HIPCHK(hipStreamWaitEvent(cb.s, m->ev_fork, 0));
                 }
                 const Scratch& sc = p.sc[br];
                 const bool bone0 = (br == 2 && l == 0);
@@ -646,8 +656,10 @@ int kasf_backward(const kasf_model* m, const float* params, const void* packed, 
                 block_backward(cb, lo.blk[2 * br + 1], lw.b[2 * br + 1], c.w(lw.b[2 * br].x_out), c.w(p.xl), c.w(gsrc[br]), c.w(sc.t1), 0, p, sc);
                 block_backward(cb, lo.blk[2 * br], lw.b[2 * br], in0, c.w(p.xl), c.w(sc.t1), bone0 ? c.w(p.g_bone) : c.w(sc.g_in), 0, p, sc);
                 if (br > 0) {
-                    HIPCHK(hipEventRecord(m->ev_join[br - 1], cb.s));
-                    HIPCHK(hipStreamWaitEvent(c.s, m->ev_join[br - 1], 0));
+                    if (!single_stream()) {
+                        HIPCHK(hipEventRecord(m->ev_join[br - 1], cb.s));
+                        HIPCHK(hipStreamWaitEvent(c.s, m->ev_join[br - 1], 0));
+                    }
                 }
             }
             // gradient w.r.t. the layer input = sum over the branches (layer 0: the bone branch fed on the bone embedding instead)

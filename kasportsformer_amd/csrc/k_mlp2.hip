@@ -19,6 +19,7 @@
 #include "kernels.h"
 #include "tile_ops.h"
 #include <type_traits>
+#include <cstdlib>
 
 namespace {
 
@@ -529,7 +530,8 @@ __global__ __launch_bounds__(256) void k_mlp_wfinish(const float* __restrict__ p
 // scratch needs: dApart = 4*M*128 bf16;  partial >= 2 * ranges * 65536 floats (returned through *ranges_out)
 int kasf_mlp_bwd_q_ranges(int64_t M) {
     const int64_t tiles = (M + Q_BM - 1) / Q_BM;
-    return (int)(tiles < 64 ? tiles : 64);
+    static const int cap = getenv("KASF_MLP_BWD_RANGES") ? atoi(getenv("KASF_MLP_BWD_RANGES")) : 64;   // measurement switch
+    return (int)(tiles < cap ? tiles : cap);
 }
 void kasf_launch_mlp_bwd_q(hipStream_t s, const void* x, const void* xn, const void* g, const float* ln_g, const void* W1, const float* b1,
                            const void* W2ts, const void* W1t, void* dApart, float* partial, float* dW1, float* dW2, float* db1, float* gsum, void* g_in,
@@ -555,7 +557,8 @@ void kasf_launch_mlp_bwd_q(hipStream_t s, const void* x, const void* xn, const v
 void kasf_launch_mlp_fwd_r(hipStream_t s, const void* x, const float* ln_g, const float* ln_b, const void* W1, const float* b1, const void* W2,
                            const float* b2, const float* ls2, void* out, int64_t M, void* xn_out) {
     const int64_t tiles = (M + F_BM - 1) / F_BM;
-    const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
+    static const int cap = getenv("KASF_MLP_FWD_GRID") ? atoi(getenv("KASF_MLP_FWD_GRID")) : 256;     // measurement switch
+    const unsigned grid = (unsigned)(tiles < cap ? tiles : cap);
     const size_t sh = (size_t)(9 * F_BM * 128) * sizeof(bf16);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_fwd_r), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     hipLaunchKernelGGL(k_mlp_fwd_r, dim3(grid), dim3(F_THR), sh, s, (const bf16*)x, ln_g, ln_b, (const bf16*)W1, b1, (const bf16*)W2, b2, ls2, (bf16*)out, M, (bf16*)xn_out);
