@@ -180,9 +180,11 @@ void build_layout(kasf_model* m) {
             o.p_fc2 = packd(o.fc2w, 128, 512, -1, 0);
             o.p_fc2Ts = packd(o.fc2w, 128, 512, o.ls2, 1);             // (ls2 . W2)^T
         }
-        const std::string p = "layers_with_bone." + std::to_string(l) + ".fusion_three_channel.";
-        lo.fus_w = A.add(p + "weight", {3, 384});
-        lo.fus_b = A.add(p + "bias", {3});
+        if (m->cfg.use_adaptive_fusion) {
+            const std::string p = "layers_with_bone." + std::to_string(l) + ".fusion_three_channel.";
+            lo.fus_w = A.add(p + "weight", {3, 384});
+            lo.fus_b = A.add(p + "bias", {3});
+        }
         lo.end = (A.cur + 3) & ~int64_t(3);
     }
     TopOff& t = m->top;
@@ -218,6 +220,12 @@ void build_layout(kasf_model* m) {
             const std::string p = "layers_with_bone." + std::to_string(l) + "." + BLOCK_NAMES[b] + ".";
             m->layers[l].blk[b].n1lw = A.add(p + "norm1_limb.weight", {128});
             m->layers[l].blk[b].n1lb = A.add(p + "norm1_limb.bias", {128});
+        }
+    if (!m->cfg.use_adaptive_fusion)                 // plain-mean fusion (KASportsFormer.py:284): the gate Linear exists but never receives a gradient
+        for (int l = 0; l < L; ++l) {
+            const std::string p = "layers_with_bone." + std::to_string(l) + ".fusion_three_channel.";
+            m->layers[l].fus_w = A.add(p + "weight", {3, 384});
+            m->layers[l].fus_b = A.add(p + "bias", {3});
         }
     m->n_params = (A.cur + 3) & ~int64_t(3);
     m->n_buffers = (B.cur + 3) & ~int64_t(3);
