@@ -343,7 +343,17 @@ struct Ctx {
 
 void block_forward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void* x_in, const void* x_limb, const Plan& p, const Scratch& sc) {
     const float* P = c.P;
-    if (o.kind == KIND_ATT) {
+    static const bool no_blk = getenv("KASF_NO_ATTN_BLOCK") != nullptr;       // measurement switch: unfused attention forward
+    bool mixer_done = false;     // bf16, groups of <= 32 positions: LN + QKV + attention + proj + residual in one kernel (csrc/k_attn_blk.hip)
+    if (c.dt == KASF_BF16 && !no_blk && o.kind != KIND_GRAPH) {
+        const bool bone = o.kind == KIND_BONE;
+        mixer_done = kasf_launch_attn_block_fwd(c.s, bone ? 1 : 0, x_in, bone ? x_limb : nullptr, P + o.n1w, P + o.n1b, bone ? P + o.n1lw : nullptr,
+                                                bone ? P + o.n1lb : nullptr, c.pk(o.p_mix), bone ? c.pk(o.p_kv) : nullptr, c.pk(o.p_proj), P + o.proj_b,
+                                                P + o.ls1, c.train ? c.w(w.qkv) : nullptr, (c.train && bone) ? c.w(w.kv) : nullptr,
+                                                c.train ? c.w(w.o) : nullptr, c.w(w.x_mid), c.B, c.T, o.mode);
+    }
+    if (mixer_done) {
+    } else if (o.kind == KIND_ATT) {
         kasf_launch_linear(c.dt, c.s, x_in, 128, c.pk(o.p_mix), 128, nullptr, c.w(w.qkv), 384, c.M, 384, P + o.n1w, P + o.n1b, nullptr, 0);
         const char* q = (const char*)c.w(w.qkv);
         kasf_launch_attn_fwd(c.dt, c.s, q, 384, q + 128 * c.es, q + 256 * c.es, 384, c.w(w.o), c.B, c.T, o.mode);
@@ -361,7 +371,7 @@ void block_forward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void* 
                                 count, c.train ? 1 : 0, 0.1f);
         kasf_launch_gcn_apply(c.dt, c.s, x_in, c.w(w.xn), c.w(w.y), (const float*)c.w(w.coef), P + o.ls1, c.w(w.x_mid), c.B, c.T, o.mode);
     }
-    if (o.kind != KIND_GRAPH)
+    if (o.kind != KIND_GRAPH && !mixer_done)
         kasf_launch_linear_res(c.dt, c.s, c.w(w.o), c.pk(o.p_proj), P + o.proj_b, P + o.ls1, x_in, c.w(w.x_mid), c.M);
     kasf_launch_mlp_fwd(c.dt, c.s, c.w(w.x_mid), P + o.n2w, P + o.n2b, c.pk(o.p_fc1), P + o.fc1b, c.pk(o.p_fc2), P + o.fc2b, P + o.ls2, c.w(w.x_out), c.M,
                         w.xn2 >= 0 ? c.w(w.xn2) : nullptr);

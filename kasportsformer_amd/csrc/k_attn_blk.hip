@@ -1,0 +1,262 @@
+// Fused attention block, forward (bf16, groups of at most 32 positions: every spatial block, temporal blocks up to T = 32):
+//     x_mid = x + ls1 * ( proj( softmax(q k^T / 4) v ) + b ),   q|k|v = LN(x) Wqkv^T            (selfattention.py:18-41)
+//     bone:   q = LN(x) Wq^T,  k|v = LN_limb(x_limb) Wkv^T                                       (bone_crossattention.py:19-41)
+// One persistent workgroup (8 waves) walks whole groups -- the 17 joints of a frame, or the T frames of one joint -- so the
+// LayerNorm, the three projections, the 8 heads and the output projection of a group never leave the CU:
+//   * wave w IS head w: in the QKV GEMM it owns exactly the 3 x 16 output features (q_h, k_h, v_h) its own attention core consumes,
+//     so the accumulators reach the core through a wave-private LDS tile without any workgroup barrier;
+//   * the core is the 32x32x16 MFMA formulation of k_attn_mfma.hip (scores transposed, softmax lane-local);
+//   * the output projection + layer-scale + residual reads the 8 heads' outputs from one shared tile;
+//   * weights live in registers for the whole launch (64 VGPRs), groups arrive by LDS-direct loads two groups ahead.
+// HBM traffic per token: 256 B in (512 B for the bone form), 256 B out, plus -- in training only -- q|k|v and the attention output,
+// which the backward pass needs (written once, as full coalesced rows).  The unfused path moved 2.8 KB per token.
+#include "common.h"
+#include "kernels.h"
+#include "tile_ops.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+constexpr int AB_THR = 512, AB_TILE = 32 * 128;
+
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ bf16x8 tok_frag(const bf16* s, int row, int ks) {
+    const int g = (threadIdx.x & 63) >> 4;
+    return *reinterpret_cast<const bf16x8*>(s + Tile<bf16>::chunk_off(row, 4 * ks + g));
+}
+// position held by register `reg` of a 32x32 accumulator in lane half hh (see k_attn_mfma.hip)
+__device__ __forceinline__ int pos_of(int reg, int hh) { return (reg & 3) + 8 * (reg >> 2) + 4 * hh; }
+__device__ __forceinline__ bf16x8 pack8(const f32x16& t, int s) {
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (bf16)t[8 * s + j];
+    return o;
+}
+// transposed fragment of k-step ks out of a row-major [32][16] tile
+__device__ __forceinline__ bf16x8 tr_frag(const bf16* s_tile, int ks) {
+    const int lane = threadIdx.x & 63, u = lane & 15, hh = lane >> 5, q = u >> 2, p = u & 3;
+    typedef __attribute__((address_space(3))) bf16x4 lds_v4;
+    const int k0 = 16 * ks + 4 * hh;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)(s_tile + (k0 + q) * 16 + 4 * p));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)(s_tile + (k0 + 8 + q) * 16 + 4 * p));
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+__device__ __forceinline__ int64_t tok_of(int G, int i, int T, int mode) {
+    return mode == 0 ? (int64_t)G * KASF_J + i : (int64_t)(G / KASF_J) * T * KASF_J + (int64_t)i * KASF_J + (G % KASF_J);
+}
+__device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }   // same-wave LDS write -> read ordering
+
+struct AttnBlkArgs {
+    const bf16* X;            // [M][128] block input (query stream)
+    const bf16* XL;           // bone: [M][128] limb stream
+    const float *ln_g, *ln_b, *lnl_g, *lnl_b;
+    const bf16* Wq;           // self: Wqkv [384][128];  bone: Wq [128][128]
+    const bf16* Wkv;          // bone: [256][128]
+    const bf16* Wproj;        // [128][128]
+    const float *bproj, *ls1;
+    bf16* Qs;                 // training: self qkv [M][384] / bone q [M][128]; nullptr in evaluation
+    bf16* KVs;                // training, bone: [M][256]
+    bf16* Os;                 // training: attention output [M][128]
+    bf16* OUT;                // x_mid [M][128]
+    int L, T, mode, groups;
+};
+
+template <bool BONE>
+__global__ __launch_bounds__(AB_THR) void k_attn_blk_fwd(const AttnBlkArgs a) {
+    constexpr int NS = BONE ? 2 : 1, SLOT = NS * AB_TILE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* sRing = reinterpret_cast<bf16*>(smem);        // [3][x tile (| x_limb tile)]
+    bf16* sA = sRing + 3 * SLOT;                        // [NS][32][128] LN(x) (| LN_limb(x_limb))
+    bf16* sQKV = sA + NS * AB_TILE;                     // [3][32][128] q | k | v of the group (full rows for the training-mode copy-out)
+    bf16* sO = sQKV + 3 * AB_TILE;                      // [32][128] attention output of the 8 heads
+    bf16* sOut = sO + AB_TILE;                          // [32][128] x_mid
+    bf16* sHead = sOut + AB_TILE;                       // [8 waves][q | k | v][32][16] wave-private operand tiles
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4, sub = lane & 15, rl = threadIdx.x >> 4;
+    const int r32 = lane & 31, hh = lane >> 5;
+    const int L = a.L;
+    const int per = (a.groups + gridDim.x - 1) / gridDim.x;
+    const int g0 = blockIdx.x * per;
+    int ng = a.groups - g0;
+    if (ng > per) ng = per;
+    if (ng <= 0) return;
+    bf16* sQh = sHead + w * 3 * 512;
+    bf16* sKh = sQh + 512;
+    bf16* sVh = sKh + 512;
+
+    // ---- weights of this wave: the q / k / v rows of head w, and 16 rows of the output projection ----
+    bf16x8 wq[3][4], wp[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        if (BONE) {
+            wq[0][ks] = *reinterpret_cast<const bf16x8*>(a.Wq + (int64_t)(16 * w + i) * 128 + 32 * ks + 8 * g);
+            wq[1][ks] = *reinterpret_cast<const bf16x8*>(a.Wkv + (int64_t)(16 * w + i) * 128 + 32 * ks + 8 * g);
+            wq[2][ks] = *reinterpret_cast<const bf16x8*>(a.Wkv + (int64_t)(128 + 16 * w + i) * 128 + 32 * ks + 8 * g);
+        } else {
+#pragma unroll
+            for (int nt = 0; nt < 3; ++nt) wq[nt][ks] = *reinterpret_cast<const bf16x8*>(a.Wq + (int64_t)(128 * nt + 16 * w + i) * 128 + 32 * ks + 8 * g);
+        }
+        wp[ks] = *reinterpret_cast<const bf16x8*>(a.Wproj + (int64_t)(16 * w + i) * 128 + 32 * ks + 8 * g);
+    }
+    const f32x4 bpv = *reinterpret_cast<const f32x4*>(a.bproj + 16 * w + 4 * g), lsv = *reinterpret_cast<const f32x4*>(a.ls1 + 16 * w + 4 * g);
+    const int64_t ldrow = a.mode == 0 ? 128 : (int64_t)KASF_J * 128;
+
+    auto nx3 = [](int sl) { return sl == 2 ? 0 : sl + 1; };
+    auto issue = [&](int t, int sl) {                    // exactly NS LDS-direct loads per wave per call
+        const int G = g0 + (t < ng ? t : ng - 1);
+        const int64_t base = tok_of(G, 0, a.T, a.mode) * 128;
+        stage_tile_async<bf16, 32, AB_THR>(sRing + sl * SLOT, a.X + base, ldrow, L);
+        if (BONE) stage_tile_async<bf16, 32, AB_THR>(sRing + sl * SLOT + AB_TILE, a.XL + base, ldrow, L);
+    };
+    auto layernorm = [&](const bf16* raw, bf16* dst, const float* gp, const float* bp) {      // row rl: delivered by this wave's own load
+        float v[8];
+        tile_load8(raw, rl, sub * 8, v);
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[e];
+        const float mean = reduce16(s) * (1.0f / 128.0f);
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { v[e] -= mean; q += v[e] * v[e]; }
+        const float rstd = rsqrtf(reduce16(q) * (1.0f / 128.0f) + KASF_LN_EPS);
+        const f32x4 g0v = *reinterpret_cast<const f32x4*>(gp + sub * 8), g1v = *reinterpret_cast<const f32x4*>(gp + sub * 8 + 4);
+        const f32x4 b0v = *reinterpret_cast<const f32x4*>(bp + sub * 8), b1v = *reinterpret_cast<const f32x4*>(bp + sub * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = v[e] * rstd * g0v[e] + b0v[e]; v[4 + e] = v[4 + e] * rstd * g1v[e] + b1v[e]; }
+        tile_store8(dst, rl, sub * 8, v);
+    };
+    issue(0, 0);
+    issue(1, 1);
+    wait_async_le<NS>();
+    int sl = 0;
+    for (int t = 0; t < ng; ++t, sl = nx3(sl)) {
+        const int G = g0 + t;
+        const bf16* slot = sRing + sl * SLOT;
+        layernorm(slot, sA, a.ln_g, a.ln_b);
+        if (BONE) layernorm(slot + AB_TILE, sA + AB_TILE, a.lnl_g, a.lnl_b);
+        barrier_keep_async();                            // B1: LN tiles complete; every wave finished the copy-out of the previous group
+        {   // ---- q_h, k_h, v_h of the 32 positions: 3 feature tiles x 2 position tiles ----
+            f32x4 acc[3][2];
+            zero_acc(acc);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 f0 = tok_frag(sA, i, ks), f1 = tok_frag(sA, 16 + i, ks);
+                bf16x8 l0 = f0, l1 = f1;
+                if (BONE) { l0 = tok_frag(sA + AB_TILE, i, ks); l1 = tok_frag(sA + AB_TILE, 16 + i, ks); }
+                acc[0][0] = mfma16(wq[0][ks], f0, acc[0][0]);
+                acc[0][1] = mfma16(wq[0][ks], f1, acc[0][1]);
+#pragma unroll
+                for (int nt = 1; nt < 3; ++nt) {
+                    acc[nt][0] = mfma16(wq[nt][ks], l0, acc[nt][0]);
+                    acc[nt][1] = mfma16(wq[nt][ks], l1, acc[nt][1]);
+                }
+            }
+#pragma unroll
+            for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    float v[4] = {acc[nt][mt][0], acc[nt][mt][1], acc[nt][mt][2], acc[nt][mt][3]};
+                    store4(sQh + nt * 512 + (16 * mt + i) * 16 + 4 * g, v);                       // wave-private [pos][16]
+                    if (a.Qs != nullptr) store4(sQKV + nt * AB_TILE + Tile<bf16>::off4(16 * mt + i, 16 * w + 4 * g), v);
+                }
+        }
+        lds_fence();
+        {   // ---- attention core of head w (k_attn_mfma.hip, one 32x32 score tile) ----
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sKh + r32 * 16 + 8 * hh);
+            const bf16x8 qf = *reinterpret_cast<const bf16x8*>(sQh + r32 * 16 + 8 * hh);
+            f32x16 z;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) z[e] = 0.f;
+            f32x16 st = mfma32(kf, qf, z);               // S^T[key][query]
+            float mx = -INFINITY;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float s = pos_of(e, hh) < L ? st[e] * 0.25f : -INFINITY;
+                st[e] = s;
+                mx = fmaxf(mx, s);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            float sum = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { st[e] = __expf(st[e] - mx); sum += st[e]; }
+            sum += __shfl_xor(sum, 32);
+            const float inv = 1.0f / sum;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) st[e] *= inv;
+            f32x16 ot = mfma32(tr_frag(sVh, 0), pack8(st, 0), z);
+            ot = mfma32(tr_frag(sVh, 1), pack8(st, 1), ot);
+            // lane = query r32, registers 0..7 = channels {4hh..4hh+3, 8+4hh..8+4hh+3} of head w
+            float o0[4] = {ot[0], ot[1], ot[2], ot[3]}, o1[4] = {ot[4], ot[5], ot[6], ot[7]};
+            store4(sO + Tile<bf16>::off4(r32, 16 * w + 4 * hh), o0);
+            store4(sO + Tile<bf16>::off4(r32, 16 * w + 8 + 4 * hh), o1);
+        }
+        barrier_keep_async();                            // B2: all heads in sO (and q|k|v in sQKV)
+        {   // ---- output projection + layer-scale + residual: 16 channels x 32 positions per wave ----
+            f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                acc[0] = mfma16(wp[ks], tok_frag(sO, i, ks), acc[0]);
+                acc[1] = mfma16(wp[ks], tok_frag(sO, 16 + i, ks), acc[1]);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                float x[4], v[4];
+                load4(slot + Tile<bf16>::off4(16 * mt + i, 16 * w + 4 * g), x);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = x[r] + lsv[r] * (acc[mt][r] + bpv[r]);
+                store4(sOut + Tile<bf16>::off4(16 * mt + i, 16 * w + 4 * g), v);
+            }
+        }
+        barrier_keep_async();                            // B3: x_mid tile complete; slot (t-1)%3 has no readers left
+        issue(t + 2, nx3(nx3(sl)));
+        wait_async_le<NS>();                             // group t+1 landed (only group t+2 outstanding); this group's stores come after
+        {   // ---- full-row stores: x_mid always; o and q|k|v only when the backward pass will need them ----
+            const int row = threadIdx.x >> 4, ch = threadIdx.x & 15;
+            if (row < L) {
+                const int64_t tok = tok_of(G, row, a.T, a.mode);
+                const int co = Tile<bf16>::chunk_off(row, ch);
+                *reinterpret_cast<f32x4*>(a.OUT + tok * 128 + ch * 8) = *reinterpret_cast<const f32x4*>(sOut + co);
+                if (a.Qs != nullptr) {
+                    *reinterpret_cast<f32x4*>(a.Os + tok * 128 + ch * 8) = *reinterpret_cast<const f32x4*>(sO + co);
+                    if (BONE) {
+                        *reinterpret_cast<f32x4*>(a.Qs + tok * 128 + ch * 8) = *reinterpret_cast<const f32x4*>(sQKV + co);
+                        *reinterpret_cast<f32x4*>(a.KVs + tok * 256 + ch * 8) = *reinterpret_cast<const f32x4*>(sQKV + AB_TILE + co);
+                        *reinterpret_cast<f32x4*>(a.KVs + tok * 256 + 128 + ch * 8) = *reinterpret_cast<const f32x4*>(sQKV + 2 * AB_TILE + co);
+                    } else {
+#pragma unroll
+                        for (int nt = 0; nt < 3; ++nt)
+                            *reinterpret_cast<f32x4*>(a.Qs + tok * 384 + nt * 128 + ch * 8) = *reinterpret_cast<const f32x4*>(sQKV + nt * AB_TILE + co);
+                    }
+                }
+            }
+        }
+    }
+    wait_async();
+}
+
+}  // namespace
+
+// Returns false when the shape is outside the fused kernel's range (groups longer than 32 positions): the caller runs the unfused sequence.
+bool kasf_launch_attn_block_fwd(hipStream_t s, int bone, const void* x, const void* x_limb, const float* ln_g, const float* ln_b, const float* lnl_g,
+                                const float* lnl_b, const void* Wq, const void* Wkv, const void* Wproj, const float* bproj, const float* ls1, void* q_save,
+                                void* kv_save, void* o_save, void* out, int B, int T, int mode) {
+    const int L = mode == 0 ? KASF_J : T;
+    if (L > 32) return false;
+    AttnBlkArgs a;
+    a.X = (const bf16*)x; a.XL = (const bf16*)x_limb; a.ln_g = ln_g; a.ln_b = ln_b; a.lnl_g = lnl_g; a.lnl_b = lnl_b;
+    a.Wq = (const bf16*)Wq; a.Wkv = (const bf16*)Wkv; a.Wproj = (const bf16*)Wproj; a.bproj = bproj; a.ls1 = ls1;
+    a.Qs = (bf16*)q_save; a.KVs = (bf16*)kv_save; a.Os = (bf16*)o_save; a.OUT = (bf16*)out;
+    a.L = L; a.T = T; a.mode = mode; a.groups = mode == 0 ? B * T : B * KASF_J;
+    if (a.groups <= 0) return true;
+    const unsigned grid = (unsigned)(a.groups < 256 ? a.groups : 256);
+    const int ns = bone ? 2 : 1;
+    const size_t sh = (size_t)(3 * ns + ns + 3 + 1 + 1) * AB_TILE * 2 + 8 * 3 * 512 * 2;
+    if (bone) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_blk_fwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        hipLaunchKernelGGL(k_attn_blk_fwd<true>, dim3(grid), dim3(AB_THR), sh, s, a);
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_blk_fwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        hipLaunchKernelGGL(k_attn_blk_fwd<false>, dim3(grid), dim3(AB_THR), sh, s, a);
+    }
+    return true;
+}

@@ -128,3 +128,9 @@ bool kasf_launch_dgrad_r(hipStream_t s, const void* dY, int Kd, const void* Wt, 
 bool kasf_launch_linear_r(hipStream_t s, const void* A, const void* W, const float* bias, void* C, int64_t M, int N, const float* ln_g, const float* ln_b,
                           void* xn_out);
 void kasf_launch_linear_res_r(hipStream_t s, const void* A, const void* W, const float* bias, const float* ls, const void* resid, void* C, int64_t M);
+
+// ---- k_attn_blk.hip (bf16): LN + QKV + 8-head attention + proj + layer-scale + residual of one attention block, forward ----
+// q_save / kv_save / o_save: what the backward pass reads (nullptr in evaluation: nothing but x_mid is written).  false: shape not covered.
+bool kasf_launch_attn_block_fwd(hipStream_t s, int bone, const void* x, const void* x_limb, const float* ln_g, const float* ln_b, const float* lnl_g,
+                                const float* lnl_b, const void* Wq, const void* Wkv, const void* Wproj, const float* bproj, const float* ls1, void* q_save,
+                                void* kv_save, void* o_save, void* out, int B, int T, int mode);
