@@ -9,7 +9,7 @@
 //   * the output projection + layer-scale + residual reads the 8 heads' outputs from one shared tile;
 //   * weights live in registers for the whole launch (64 VGPRs), groups arrive by LDS-direct loads two groups ahead.
 // HBM traffic per token: 256 B in (512 B for the bone form), 256 B out, plus -- in training only -- q|k|v and the attention output,
-// which the backward pass needs (written once, as full coalesced rows).  The unfused path moved 2.8 KB per token.
+// which the backward pass needs (written once).  The unfused path moved 2.8 KB per token.
 #include "common.h"
 #include "kernels.h"
 #include "tile_ops.h"
@@ -42,8 +42,8 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16* s_tile, int ks) {
     const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)(s_tile + (k0 + 8 + q) * 16 + 4 * p));
     return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
-__device__ __forceinline__ int64_t tok_of(int G, int i, int T, int mode) {
-    return mode == 0 ? (int64_t)G * KASF_J + i : (int64_t)(G / KASF_J) * T * KASF_J + (int64_t)i * KASF_J + (G % KASF_J);
+__device__ __forceinline__ int tok_of(int G, int i, int T, int mode) {       // token index (< 2^31: 32-bit keeps address registers short-lived)
+    return mode == 0 ? G * KASF_J + i : (G / KASF_J) * T * KASF_J + i * KASF_J + (G % KASF_J);
 }
 __device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }   // same-wave LDS write -> read ordering
 
@@ -62,16 +62,21 @@ struct AttnBlkArgs {
     int L, T, mode, groups;
 };
 
+// Self-attention form: 72 KB of LDS and <= 128 VGPRs, so TWO workgroups share a CU and one group's barrier / LDS round-trip latencies are
+// covered by the other's work (a group is only 17-32 positions: the per-group dependency chain, not bandwidth, bounds a lone workgroup).
 template <bool BONE>
-__global__ __launch_bounds__(AB_THR) void k_attn_blk_fwd(const AttnBlkArgs a) {
+__global__ __launch_bounds__(AB_THR, BONE ? 2 : 4) void k_attn_blk_fwd(const AttnBlkArgs a) {
     constexpr int NS = BONE ? 2 : 1, SLOT = NS * AB_TILE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* sRing = reinterpret_cast<bf16*>(smem);        // [3][x tile (| x_limb tile)]
     bf16* sA = sRing + 3 * SLOT;                        // [NS][32][128] LN(x) (| LN_limb(x_limb))
-    bf16* sQKV = sA + NS * AB_TILE;                     // [3][32][128] q | k | v of the group (full rows for the training-mode copy-out)
-    bf16* sO = sQKV + 3 * AB_TILE;                      // [32][128] attention output of the 8 heads
+    bf16* sO = sA + NS * AB_TILE;                       // [32][128] attention output of the 8 heads
     bf16* sOut = sO + AB_TILE;                          // [32][128] x_mid
     bf16* sHead = sOut + AB_TILE;                       // [8 waves][q | k | v][32][16] wave-private operand tiles
+    bf16* sQKV = sHead + 8 * 3 * 512 + 6 * 128 * 2;    // bone, training: [3][32][128] q | k | v rows for full-row stores (one workgroup per CU
+                                                        // cannot hide the acknowledgement latency of 32-byte scattered stores)
+    float* sLn = reinterpret_cast<float*>(sHead + 8 * 3 * 512);      // [6][128] gamma, beta, limb gamma, beta, proj bias, ls1: read through LDS so that
+                                                                     // they never sit in the vmcnt queue behind the look-ahead loads
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4, sub = lane & 15, rl = threadIdx.x >> 4;
     const int r32 = lane & 31, hh = lane >> 5;
     const int L = a.L;
@@ -98,17 +103,24 @@ __global__ __launch_bounds__(AB_THR) void k_attn_blk_fwd(const AttnBlkArgs a) {
         }
         wp[ks] = *reinterpret_cast<const bf16x8*>(a.Wproj + (int64_t)(16 * w + i) * 128 + 32 * ks + 8 * g);
     }
-    const f32x4 bpv = *reinterpret_cast<const f32x4*>(a.bproj + 16 * w + 4 * g), lsv = *reinterpret_cast<const f32x4*>(a.ls1 + 16 * w + 4 * g);
+    if (threadIdx.x < 128) {
+        sLn[threadIdx.x] = a.ln_g[threadIdx.x];
+        sLn[128 + threadIdx.x] = a.ln_b[threadIdx.x];
+        if (BONE) { sLn[256 + threadIdx.x] = a.lnl_g[threadIdx.x]; sLn[384 + threadIdx.x] = a.lnl_b[threadIdx.x]; }
+        sLn[512 + threadIdx.x] = a.bproj[threadIdx.x];
+        sLn[640 + threadIdx.x] = a.ls1[threadIdx.x];
+    }
+    __syncthreads();
     const int64_t ldrow = a.mode == 0 ? 128 : (int64_t)KASF_J * 128;
 
     auto nx3 = [](int sl) { return sl == 2 ? 0 : sl + 1; };
     auto issue = [&](int t, int sl) {                    // exactly NS LDS-direct loads per wave per call
         const int G = g0 + (t < ng ? t : ng - 1);
-        const int64_t base = tok_of(G, 0, a.T, a.mode) * 128;
+        const int64_t base = (int64_t)tok_of(G, 0, a.T, a.mode) * 128;
         stage_tile_async<bf16, 32, AB_THR>(sRing + sl * SLOT, a.X + base, ldrow, L);
         if (BONE) stage_tile_async<bf16, 32, AB_THR>(sRing + sl * SLOT + AB_TILE, a.XL + base, ldrow, L);
     };
-    auto layernorm = [&](const bf16* raw, bf16* dst, const float* gp, const float* bp) {      // row rl: delivered by this wave's own load
+    auto layernorm = [&](const bf16* raw, bf16* dst, const float* gp, const float* bp) {      // row rl: delivered by this wave's own load; gp/bp in LDS
         float v[8];
         tile_load8(raw, rl, sub * 8, v);
         float s = 0.f;
@@ -132,8 +144,8 @@ __global__ __launch_bounds__(AB_THR) void k_attn_blk_fwd(const AttnBlkArgs a) {
     for (int t = 0; t < ng; ++t, sl = nx3(sl)) {
         const int G = g0 + t;
         const bf16* slot = sRing + sl * SLOT;
-        layernorm(slot, sA, a.ln_g, a.ln_b);
-        if (BONE) layernorm(slot + AB_TILE, sA + AB_TILE, a.lnl_g, a.lnl_b);
+        layernorm(slot, sA, sLn, sLn + 128);
+        if (BONE) layernorm(slot + AB_TILE, sA + AB_TILE, sLn + 256, sLn + 384);
         barrier_keep_async();                            // B1: LN tiles complete; every wave finished the copy-out of the previous group
         {   // ---- q_h, k_h, v_h of the 32 positions: 3 feature tiles x 2 position tiles ----
             f32x4 acc[3][2];
@@ -157,10 +169,24 @@ __global__ __launch_bounds__(AB_THR) void k_attn_blk_fwd(const AttnBlkArgs a) {
                 for (int mt = 0; mt < 2; ++mt) {
                     float v[4] = {acc[nt][mt][0], acc[nt][mt][1], acc[nt][mt][2], acc[nt][mt][3]};
                     store4(sQh + nt * 512 + (16 * mt + i) * 16 + 4 * g, v);                       // wave-private [pos][16]
-                    if (a.Qs != nullptr) store4(sQKV + nt * AB_TILE + Tile<bf16>::off4(16 * mt + i, 16 * w + 4 * g), v);
+                    if (BONE && a.Qs != nullptr) store4(sQKV + nt * AB_TILE + Tile<bf16>::off4(16 * mt + i, 16 * w + 4 * g), v);
                 }
         }
         lds_fence();
+        if (!BONE && a.Qs != nullptr && r32 < L) {   // training: the backward pass reads q | k | v; each lane stores the 16 bytes it is about to use as an operand
+            const int64_t tok = tok_of(G, r32, a.T, a.mode);
+            const f32x4 vq = *reinterpret_cast<const f32x4*>(sQh + r32 * 16 + 8 * hh), vk = *reinterpret_cast<const f32x4*>(sKh + r32 * 16 + 8 * hh),
+                        vv = *reinterpret_cast<const f32x4*>(sVh + r32 * 16 + 8 * hh);
+            if (BONE) {
+                *reinterpret_cast<f32x4*>(a.Qs + tok * 128 + 16 * w + 8 * hh) = vq;
+                *reinterpret_cast<f32x4*>(a.KVs + tok * 256 + 16 * w + 8 * hh) = vk;
+                *reinterpret_cast<f32x4*>(a.KVs + tok * 256 + 128 + 16 * w + 8 * hh) = vv;
+            } else {
+                *reinterpret_cast<f32x4*>(a.Qs + tok * 384 + 16 * w + 8 * hh) = vq;
+                *reinterpret_cast<f32x4*>(a.Qs + tok * 384 + 128 + 16 * w + 8 * hh) = vk;
+                *reinterpret_cast<f32x4*>(a.Qs + tok * 384 + 256 + 16 * w + 8 * hh) = vv;
+            }
+        }
         {   // ---- attention core of head w (k_attn_mfma.hip, one 32x32 score tile) ----
             const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sKh + r32 * 16 + 8 * hh);
             const bf16x8 qf = *reinterpret_cast<const bf16x8*>(sQh + r32 * 16 + 8 * hh);
@@ -198,6 +224,7 @@ __global__ __launch_bounds__(AB_THR) void k_attn_blk_fwd(const AttnBlkArgs a) {
                 acc[0] = mfma16(wp[ks], tok_frag(sO, i, ks), acc[0]);
                 acc[1] = mfma16(wp[ks], tok_frag(sO, 16 + i, ks), acc[1]);
             }
+            const f32x4 bpv = *reinterpret_cast<const f32x4*>(sLn + 512 + 16 * w + 4 * g), lsv = *reinterpret_cast<const f32x4*>(sLn + 640 + 16 * w + 4 * g);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 float x[4], v[4];
@@ -216,17 +243,11 @@ __global__ __launch_bounds__(AB_THR) void k_attn_blk_fwd(const AttnBlkArgs a) {
                 const int64_t tok = tok_of(G, row, a.T, a.mode);
                 const int co = Tile<bf16>::chunk_off(row, ch);
                 *reinterpret_cast<f32x4*>(a.OUT + tok * 128 + ch * 8) = *reinterpret_cast<const f32x4*>(sOut + co);
-                if (a.Qs != nullptr) {
-                    *reinterpret_cast<f32x4*>(a.Os + tok * 128 + ch * 8) = *reinterpret_cast<const f32x4*>(sO + co);
-                    if (BONE) {
-                        *reinterpret_cast<f32x4*>(a.Qs + tok * 128 + ch * 8) = *reinterpret_cast<const f32x4*>(sQKV + co);
-                        *reinterpret_cast<f32x4*>(a.KVs + tok * 256 + ch * 8) = *reinterpret_cast<const f32x4*>(sQKV + AB_TILE + co);
-                        *reinterpret_cast<f32x4*>(a.KVs + tok * 256 + 128 + ch * 8) = *reinterpret_cast<const f32x4*>(sQKV + 2 * AB_TILE + co);
-                    } else {
-#pragma unroll
-                        for (int nt = 0; nt < 3; ++nt)
-                            *reinterpret_cast<f32x4*>(a.Qs + tok * 384 + nt * 128 + ch * 8) = *reinterpret_cast<const f32x4*>(sQKV + nt * AB_TILE + co);
-                    }
+                if (a.Qs != nullptr) *reinterpret_cast<f32x4*>(a.Os + tok * 128 + ch * 8) = *reinterpret_cast<const f32x4*>(sO + co);
+                if (BONE && a.Qs != nullptr) {
+                    *reinterpret_cast<f32x4*>(a.Qs + tok * 128 + ch * 8) = *reinterpret_cast<const f32x4*>(sQKV + co);
+                    *reinterpret_cast<f32x4*>(a.KVs + tok * 256 + ch * 8) = *reinterpret_cast<const f32x4*>(sQKV + AB_TILE + co);
+                    *reinterpret_cast<f32x4*>(a.KVs + tok * 256 + 128 + ch * 8) = *reinterpret_cast<const f32x4*>(sQKV + 2 * AB_TILE + co);
                 }
             }
         }
@@ -248,9 +269,9 @@ bool kasf_launch_attn_block_fwd(hipStream_t s, int bone, const void* x, const vo
     a.Qs = (bf16*)q_save; a.KVs = (bf16*)kv_save; a.Os = (bf16*)o_save; a.OUT = (bf16*)out;
     a.L = L; a.T = T; a.mode = mode; a.groups = mode == 0 ? B * T : B * KASF_J;
     if (a.groups <= 0) return true;
-    const unsigned grid = (unsigned)(a.groups < 256 ? a.groups : 256);
-    const int ns = bone ? 2 : 1;
-    const size_t sh = (size_t)(3 * ns + ns + 3 + 1 + 1) * AB_TILE * 2 + 8 * 3 * 512 * 2;
+    const int ns = bone ? 2 : 1, cap = bone ? 256 : 512;         // self-attention: two workgroups per CU
+    const unsigned grid = (unsigned)(a.groups < cap ? a.groups : cap);
+    const size_t sh = (size_t)(3 * ns + ns + 1 + 1) * AB_TILE * 2 + 8 * 3 * 512 * 2 + 6 * 128 * 4 + (bone ? 3 * AB_TILE * 2 : 0);
     if (bone) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_blk_fwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
         hipLaunchKernelGGL(k_attn_blk_fwd<true>, dim3(grid), dim3(AB_THR), sh, s, a);
