@@ -8,6 +8,7 @@
 //   k_dgrad_lnbwd   g_in = [resid +] LNbwd( dY . Wt^T [+ add] ) dgrad of an LN-fused linear + LN backward
 //   k_wgrad         dW[N][K] += G^T . LN?(X), db += colsum(G)   split over M, LDS-transpose reads
 //   k_pack          fp32 master weights -> T (optionally transposed / row-scaled) kernel arena
+#include <cstdlib>
 #include "common.h"
 #include "kernels.h"
 #include "tile_ops.h"
@@ -294,12 +295,12 @@ __global__ __launch_bounds__(256) void k_wgrad(const T* __restrict__ G, int64_t 
 
 // ---------------------------------------------------------------------------------------------
 // Streaming variant (bf16, no LayerNorm): the reduction over tokens is an HBM stream of G and X, and a
-// CU needs ~50 KB in flight to hide the ~2 us HBM latency.  64-row tiles go through a 4-stage LDS ring
-// filled by LDS-direct loads issued three tiles ahead; each wave waits only for ITS loads of the
+// CU needs ~50 KB in flight to hide the ~2 us HBM latency.  64-row tiles go through a WR_ST-stage LDS ring
+// filled by LDS-direct loads issued WR_ST-1 tiles ahead (2 stages measured equal to 4 and leave LDS for co-resident kernels); each wave waits only for ITS loads of the
 // current tile (counted vmcnt, 8 loads per tile and wave) and the workgroup meets at a raw s_barrier,
 // so two to three tiles stay in flight across every barrier.  The ragged tail goes through registers.
 // ---------------------------------------------------------------------------------------------
-constexpr int WR_BM = 64, WR_ST = 4, WR_IPT = 8;      // rows per tile, ring stages, LDS-direct loads per tile per wave
+constexpr int WR_BM = 64, WR_ST = 2, WR_IPT = 8;      // rows per tile, ring stages, LDS-direct loads per tile per wave
 
 template <typename T>
 __global__ __launch_bounds__(256) void k_wgrad_ring(const T* __restrict__ G, int64_t ldg, const T* __restrict__ X, int64_t ldx,
@@ -538,7 +539,8 @@ static void wgrad_T(hipStream_t s, const void* G, int64_t ldg, int N, const void
     constexpr int NBUF = GemmCfg<T>::WG_NBUF;
     const int tiles = (N / 128) * (K / 128);
     // one workgroup per CU (the 128 KB of LDS allow only one resident anyway): fewest splits that still fill the chip
-    int splits = (248 + tiles - 1) / tiles;
+    static const int target = getenv("KASF_WGRAD_WGS") ? atoi(getenv("KASF_WGRAD_WGS")) : 248;   // measurement switch (496 = two per CU: slower, the partial tiles double)
+    int splits = (target + tiles - 1) / tiles;
     const int64_t max_splits = (M + WG_BM - 1) / WG_BM;
     if (splits > max_splits) splits = (int)max_splits;
     if (splits < 1) splits = 1;
