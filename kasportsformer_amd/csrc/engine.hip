@@ -413,8 +413,14 @@ void block_backward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void*
     }
     // d_o = g_mid . (ls1 . Wproj);  G_proj = g_mid^T o (unscaled) -> finalize: dWproj, dbproj, dls1
     kasf_launch_linear(c.dt, c.s, g_mid, 128, c.pk(o.p_projTs), 128, nullptr, c.w(sc.d_o), 128, c.M, 128, nullptr, nullptr, nullptr, 0);
-    kasf_launch_wgrad(c.dt, c.s, g_mid, 128, 128, c.w(w.o), 128, 128, nullptr, nullptr, G + o.proj_w, 128, G + o.proj_b, c.M, (float*)c.w(sc.wg_part), WG_PARTIAL_FLOATS);
-    kasf_launch_finalize_ls(c.s, G + o.proj_w, P + o.proj_w, P + o.proj_b, P + o.ls1, G + o.proj_b, G + o.ls1, 128, 128);
+    // bf16: every weight gradient of the block (proj, qkv | q, kv) goes into ONE streaming launch + one finishing launch at the end of the block
+    static const bool no_jobs = getenv("KASF_NO_WGRAD_JOBS") != nullptr;       // measurement switch
+    const bool jobs = c.dt == KASF_BF16 && !no_jobs;
+    float* part = (float*)c.w(sc.wg_part);
+    if (!jobs) {
+        kasf_launch_wgrad(c.dt, c.s, g_mid, 128, 128, c.w(w.o), 128, 128, nullptr, nullptr, G + o.proj_w, 128, G + o.proj_b, c.M, part, WG_PARTIAL_FLOATS);
+        kasf_launch_finalize_ls(c.s, G + o.proj_w, P + o.proj_w, P + o.proj_b, P + o.ls1, G + o.proj_b, G + o.ls1, 128, 128);
+    }
     if (o.kind == KIND_ATT) {
         const char* q = (const char*)c.w(w.qkv);
         char* dq = (char*)c.w(sc.dqkv);
@@ -422,7 +428,22 @@ void block_backward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void*
                              o.mode);
         kasf_launch_dgrad_lnbwd(c.dt, c.s, dq, 384, c.pk(o.p_mixT), nullptr, x_in, P + o.n1w, g_mid, dst, accumulate, G + o.n1w, G + o.n1b, c.M,
                                 c.w(sc.xn_a), P + o.n1b);
-        kasf_launch_wgrad(c.dt, c.s, dq, 384, 384, c.w(sc.xn_a), 128, 128, nullptr, nullptr, G + o.mix_w, 128, nullptr, c.M, (float*)c.w(sc.wg_part), WG_PARTIAL_FLOATS);
+        bool done = false;
+        if (jobs) {
+            const void* Gs[2] = {g_mid, dq};
+            const void* Xs[2] = {c.w(w.o), c.w(sc.xn_a)};
+            const int Ns[2] = {128, 384};
+            float* dWs[2] = {G + o.proj_w, G + o.mix_w};
+            float* dbs[2] = {G + o.proj_b, nullptr};
+            done = kasf_launch_wgrad_jobs(c.s, 2, Gs, Xs, Ns, dWs, dbs, 0, P + o.proj_w, P + o.proj_b, P + o.ls1, G + o.ls1, c.M, part, WG_PARTIAL_FLOATS);
+        }
+        if (!done) {
+            if (jobs) {
+                kasf_launch_wgrad(c.dt, c.s, g_mid, 128, 128, c.w(w.o), 128, 128, nullptr, nullptr, G + o.proj_w, 128, G + o.proj_b, c.M, part, WG_PARTIAL_FLOATS);
+                kasf_launch_finalize_ls(c.s, G + o.proj_w, P + o.proj_w, P + o.proj_b, P + o.ls1, G + o.proj_b, G + o.ls1, 128, 128);
+            }
+            kasf_launch_wgrad(c.dt, c.s, dq, 384, 384, c.w(sc.xn_a), 128, 128, nullptr, nullptr, G + o.mix_w, 128, nullptr, c.M, part, WG_PARTIAL_FLOATS);
+        }
     } else {
         const char* kv = (const char*)c.w(w.kv);
         char* dq = (char*)c.w(sc.dqkv);
@@ -432,8 +453,23 @@ void block_backward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void*
                                 c.w(sc.xn_a), P + o.n1b);
         kasf_launch_dgrad_lnbwd(c.dt, c.s, dkv, 256, c.pk(o.p_kvT), nullptr, x_limb, P + o.n1lw, nullptr, c.w(p.g_limb), 1, G + o.n1lw, G + o.n1lb, c.M,
                                 c.w(sc.xn_b), P + o.n1lb);
-        kasf_launch_wgrad(c.dt, c.s, dq, 128, 128, c.w(sc.xn_a), 128, 128, nullptr, nullptr, G + o.mix_w, 128, nullptr, c.M, (float*)c.w(sc.wg_part), WG_PARTIAL_FLOATS);
-        kasf_launch_wgrad(c.dt, c.s, dkv, 256, 256, c.w(sc.xn_b), 128, 128, nullptr, nullptr, G + o.kv_w, 128, nullptr, c.M, (float*)c.w(sc.wg_part), WG_PARTIAL_FLOATS);
+        bool done = false;
+        if (jobs) {
+            const void* Gs[3] = {g_mid, dq, dkv};
+            const void* Xs[3] = {c.w(w.o), c.w(sc.xn_a), c.w(sc.xn_b)};
+            const int Ns[3] = {128, 128, 256};
+            float* dWs[3] = {G + o.proj_w, G + o.mix_w, G + o.kv_w};
+            float* dbs[3] = {G + o.proj_b, nullptr, nullptr};
+            done = kasf_launch_wgrad_jobs(c.s, 3, Gs, Xs, Ns, dWs, dbs, 0, P + o.proj_w, P + o.proj_b, P + o.ls1, G + o.ls1, c.M, part, WG_PARTIAL_FLOATS);
+        }
+        if (!done) {
+            if (jobs) {
+                kasf_launch_wgrad(c.dt, c.s, g_mid, 128, 128, c.w(w.o), 128, 128, nullptr, nullptr, G + o.proj_w, 128, G + o.proj_b, c.M, part, WG_PARTIAL_FLOATS);
+                kasf_launch_finalize_ls(c.s, G + o.proj_w, P + o.proj_w, P + o.proj_b, P + o.ls1, G + o.proj_b, G + o.ls1, 128, 128);
+            }
+            kasf_launch_wgrad(c.dt, c.s, dq, 128, 128, c.w(sc.xn_a), 128, 128, nullptr, nullptr, G + o.mix_w, 128, nullptr, c.M, part, WG_PARTIAL_FLOATS);
+            kasf_launch_wgrad(c.dt, c.s, dkv, 256, 256, c.w(sc.xn_b), 128, 128, nullptr, nullptr, G + o.kv_w, 128, nullptr, c.M, part, WG_PARTIAL_FLOATS);
+        }
     }
 }
 

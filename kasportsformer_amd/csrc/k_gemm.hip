@@ -302,16 +302,16 @@ __global__ __launch_bounds__(256) void k_wgrad(const T* __restrict__ G, int64_t 
 // ---------------------------------------------------------------------------------------------
 constexpr int WR_BM = 64, WR_ST = 2, WR_IPT = 8;      // rows per tile, ring stages, LDS-direct loads per tile per wave
 
+// One workgroup: the 128 x 128 tile (n0, k0) of split z.  N, K = full dimensions of the weight (partial tiles are laid out [z][N][K]).
 template <typename T>
-__global__ __launch_bounds__(256) void k_wgrad_ring(const T* __restrict__ G, int64_t ldg, const T* __restrict__ X, int64_t ldx,
-                                                    float* __restrict__ out, int64_t ldo, float* __restrict__ dbias, int64_t M, int64_t slice,
-                                                    float* __restrict__ partial) {
+__device__ __forceinline__ void wgrad_ring_body(const T* __restrict__ G, int64_t ldg, const T* __restrict__ X, int64_t ldx, float* __restrict__ out,
+                                                int64_t ldo, float* __restrict__ dbias, int64_t M, int64_t slice, float* __restrict__ partial, int N, int K,
+                                                int n0, int k0, int z) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* ring = reinterpret_cast<T*>(smem);               // [WR_ST][2][64][128]  (G tile, X tile)
-    const int n0 = blockIdx.x * 128, k0 = blockIdx.y * 128;
-    const int64_t m_begin = (int64_t)blockIdx.z * slice, m_end = (m_begin + slice < M) ? m_begin + slice : M;
+    const int64_t m_begin = (int64_t)z * slice, m_end = (m_begin + slice < M) ? m_begin + slice : M;
     const int sub = threadIdx.x & 15, rl = threadIdx.x >> 4;
-    const bool want_bias = dbias != nullptr && blockIdx.y == 0;
+    const bool want_bias = dbias != nullptr && k0 == 0;
     float bsum[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) bsum[i] = 0.f;
@@ -366,8 +366,8 @@ __global__ __launch_bounds__(256) void k_wgrad_ring(const T* __restrict__ G, int
     }
     {
         const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
-        float* dst = partial != nullptr ? partial + (int64_t)blockIdx.z * (gridDim.x * 128) * (gridDim.y * 128) : out;
-        const int64_t ld = partial != nullptr ? (int64_t)gridDim.y * 128 : ldo;
+        float* dst = partial != nullptr ? partial + (int64_t)z * N * K : out;
+        const int64_t ld = partial != nullptr ? (int64_t)K : ldo;
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -391,6 +391,102 @@ __global__ __launch_bounds__(256) void k_wgrad_ring(const T* __restrict__ G, int
             for (int k = 0; k < 16; ++k) s += red[k * 128 + threadIdx.x];
             atomicAdd(dbias + n0 + threadIdx.x, s);
         }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_wgrad_ring(const T* __restrict__ G, int64_t ldg, const T* __restrict__ X, int64_t ldx,
+                                                    float* __restrict__ out, int64_t ldo, float* __restrict__ dbias, int64_t M, int64_t slice,
+                                                    float* __restrict__ partial) {
+    wgrad_ring_body<T>(G, ldg, X, ldx, out, ldo, dbias, M, slice, partial, gridDim.x * 128, gridDim.y * 128, blockIdx.x * 128, blockIdx.y * 128, blockIdx.z);
+}
+
+// Several weight gradients of one block in ONE launch (bf16): the launch / ramp-up / partial-write overhead of these short streaming kernels
+// is paid once, and one k_wgrad_finish_jobs launch sums every job's partial tiles (and applies the layer-scale algebra of the proj weight).
+struct WgJob {
+    const bf16 *G, *X;
+    int64_t ldg, ldx;
+    float *partial, *dbias;
+    int N, K, first;          // first workgroup of this job; it owns (N/128)(K/128) tiles x splits workgroups
+};
+struct WgJobs {
+    int n, splits;
+    int64_t slice, M;
+    WgJob j[3];
+};
+__global__ __launch_bounds__(256) void k_wgrad_ring_jobs(const WgJobs js) {
+    int ji = 0;
+#pragma unroll
+    for (int q = 1; q < 3; ++q)
+        if (q < js.n && (int)blockIdx.x >= js.j[q].first) ji = q;
+    const WgJob& jb = js.j[ji];
+    const int tiles_k = jb.K / 128, tiles = (jb.N / 128) * tiles_k, rel = blockIdx.x - jb.first, tile = rel % tiles, z = rel / tiles;
+    wgrad_ring_body<bf16>(jb.G, jb.ldg, jb.X, jb.ldx, nullptr, 0, jb.dbias, js.M, js.slice, jb.partial, jb.N, jb.K, (tile / tiles_k) * 128,
+                          (tile % tiles_k) * 128, z);
+}
+struct FinJob {
+    const float* partial;
+    float* out;               // [N][K] dense, accumulated into
+    int N, K, first;          // first workgroup; N*K/256 workgroups
+    const float *W, *bias, *ls;   // W != nullptr (K == 128): out += ls[n] * G, dls[n] += <W[n], G[n]> + bias[n] * db[n], db[n] *= ls[n]
+    float *db, *dls;
+};
+struct FinJobs {
+    int n, splits;
+    FinJob j[3];
+};
+__global__ __launch_bounds__(256) void k_wgrad_finish_jobs(const FinJobs js) {
+    __shared__ f32x4 sPart[4][64];
+    int ji = 0;
+#pragma unroll
+    for (int q = 1; q < 3; ++q)
+        if (q < js.n && (int)blockIdx.x >= js.j[q].first) ji = q;
+    const FinJob& jb = js.j[ji];
+    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int64_t e = ((int64_t)(blockIdx.x - jb.first) * 64 + lane) * 4, stride = (int64_t)jb.N * jb.K;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+    int z = part;
+    for (; z + 4 < js.splits; z += 8) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(jb.partial + (int64_t)z * stride + e);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(jb.partial + (int64_t)(z + 4) * stride + e);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { s0[q] += a[q]; s1[q] += b[q]; }
+    }
+    if (z < js.splits) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(jb.partial + (int64_t)z * stride + e);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s0[q] += a[q];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s0[q] += s1[q];
+    sPart[part][lane] = s0;
+    __syncthreads();
+    if (part == 0) {
+        const f32x4 a = sPart[0][lane], b = sPart[1][lane], c = sPart[2][lane], d = sPart[3][lane];
+        f32x4 gsum;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) gsum[q] = (a[q] + b[q]) + (c[q] + d[q]);
+        f32x4* o = reinterpret_cast<f32x4*>(jb.out + e);
+        f32x4 cur = *o;
+        if (jb.W != nullptr) {                           // K == 128: lanes 0..31 hold row 2b, lanes 32..63 row 2b+1
+            const int n = (int)(e / 128);
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(jb.W + e);
+            float dot = wv[0] * gsum[0] + wv[1] * gsum[1] + wv[2] * gsum[2] + wv[3] * gsum[3];
+#pragma unroll
+            for (int m = 16; m >= 1; m >>= 1) dot += __shfl_xor(dot, m);
+            const float l = jb.ls[n];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cur[q] += l * gsum[q];
+            if ((lane & 31) == 0) {
+                const float gs = jb.db[n];
+                jb.dls[n] += dot + jb.bias[n] * gs;
+                jb.db[n] = gs * l;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cur[q] += gsum[q];
+        }
+        *o = cur;
     }
 }
 
@@ -582,4 +678,43 @@ void kasf_launch_pack(int dt, hipStream_t s, const float* params, void* arena, c
     if (total_tiles <= 0) return;
     if (dt == KASF_F32) hipLaunchKernelGGL(k_pack<float>, dim3(total_tiles), dim3(256), 0, s, params, (float*)arena, desc, tile_start, ndesc);
     else hipLaunchKernelGGL(k_pack<bf16>, dim3(total_tiles), dim3(256), 0, s, params, (bf16*)arena, desc, tile_start, ndesc);
+}
+
+// Up to three bf16 weight gradients  dW_j[N_j][128] += G_j^T X_j  (dense operands: ldg = N_j, ldx = 128) in one streaming launch plus one
+// finishing launch.  fin_* of job j (optional): the layer-scale algebra of k_finalize_ls applied to that job (the proj weight).
+// Returns false (nothing launched) when the scratch is too small.
+bool kasf_launch_wgrad_jobs(hipStream_t s, int njobs, const void* const* G, const void* const* X, const int* N, float* const* dW, float* const* dbias,
+                            int fin_job, const float* fin_W, const float* fin_bias, const float* fin_ls, float* fin_dls, int64_t M, float* partial,
+                            int64_t partial_floats) {
+    if (njobs < 1 || njobs > 3 || M <= 0) return false;
+    int tiles = 0;
+    for (int j = 0; j < njobs; ++j) tiles += N[j] / 128;
+    static const int target = getenv("KASF_WGRAD_WGS") ? atoi(getenv("KASF_WGRAD_WGS")) : 248;
+    int splits = (target + tiles - 1) / tiles;
+    const int64_t max_splits = (M + WG_BM - 1) / WG_BM;
+    if (splits > max_splits) splits = (int)max_splits;
+    int64_t slice = (M + splits - 1) / splits;
+    slice = (slice + WG_BM - 1) / WG_BM * WG_BM;
+    splits = (int)((M + slice - 1) / slice);
+    int64_t need = 0;
+    for (int j = 0; j < njobs; ++j) need += (int64_t)splits * N[j] * 128;
+    if (partial == nullptr || need > partial_floats) return false;
+    WgJobs js;
+    FinJobs fj;
+    js.n = fj.n = njobs; js.splits = fj.splits = splits; js.slice = slice; js.M = M;
+    int first = 0, ffirst = 0;
+    float* pp = partial;
+    for (int j = 0; j < njobs; ++j) {
+        js.j[j] = WgJob{(const bf16*)G[j], (const bf16*)X[j], N[j], 128, pp, dbias[j], N[j], 128, first};
+        const bool fin = j == fin_job;
+        fj.j[j] = FinJob{pp, dW[j], N[j], 128, ffirst, fin ? fin_W : nullptr, fin_bias, fin_ls, dbias[j], fin_dls};
+        first += (N[j] / 128) * splits;
+        ffirst += N[j] * 128 / 256;
+        pp += (int64_t)splits * N[j] * 128;
+    }
+    const size_t shr = (size_t)WR_ST * 2 * WR_BM * 128 * sizeof(bf16);
+    set_smem(k_wgrad_ring_jobs, shr);
+    hipLaunchKernelGGL(k_wgrad_ring_jobs, dim3(first), dim3(256), shr, s, js);
+    hipLaunchKernelGGL(k_wgrad_finish_jobs, dim3(ffirst), dim3(256), 0, s, fj);
+    return true;
 }

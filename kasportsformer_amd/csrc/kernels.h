@@ -134,3 +134,8 @@ void kasf_launch_linear_res_r(hipStream_t s, const void* A, const void* W, const
 bool kasf_launch_attn_block_fwd(hipStream_t s, int bone, const void* x, const void* x_limb, const float* ln_g, const float* ln_b, const float* lnl_g,
                                 const float* lnl_b, const void* Wq, const void* Wkv, const void* Wproj, const float* bproj, const float* ls1, void* q_save,
                                 void* kv_save, void* o_save, void* out, int B, int T, int mode);
+
+// ---- k_gemm.hip: several bf16 weight gradients dW_j[N_j][128] += G_j^T X_j in one streaming launch + one finishing launch ----
+bool kasf_launch_wgrad_jobs(hipStream_t s, int njobs, const void* const* G, const void* const* X, const int* N, float* const* dW, float* const* dbias,
+                            int fin_job, const float* fin_W, const float* fin_bias, const float* fin_ls, float* fin_dls, int64_t M, float* partial,
+                            int64_t partial_floats);
