@@ -367,9 +367,8 @@ void block_forward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void* 
         kasf_launch_gcn_agg_fwd(c.dt, c.s, c.w(sc.uv), c.w(w.xn), c.w(w.y), w.mask >= 0 ? (uint32_t*)c.w(w.mask) : nullptr, (double*)c.w(w.stats), c.B,
                                 c.T, o.mode);
         const double count = o.mode == 0 ? (double)c.B * c.T * 128 : (double)c.B * 17 * 128;
-        kasf_launch_bn_finalize(c.s, (const double*)c.w(w.stats), P + o.bn_w, P + o.bn_b, c.buf + o.bn_rm, c.buf + o.bn_rv, (float*)c.w(w.coef), o.nodes,
-                                count, c.train ? 1 : 0, 0.1f);
-        kasf_launch_gcn_apply(c.dt, c.s, x_in, c.w(w.xn), c.w(w.y), (const float*)c.w(w.coef), P + o.ls1, c.w(w.x_mid), c.B, c.T, o.mode);
+        kasf_launch_gcn_apply(c.dt, c.s, x_in, c.w(w.xn), c.w(w.y), (const double*)c.w(w.stats), P + o.bn_w, P + o.bn_b, c.buf + o.bn_rm, c.buf + o.bn_rv,
+                              (float*)c.w(w.coef), P + o.ls1, c.w(w.x_mid), c.B, c.T, o.mode, count, c.train ? 1 : 0, 0.1f);
     }
     if (o.kind != KIND_GRAPH && !mixer_done)
         kasf_launch_linear_res(c.dt, c.s, c.w(w.o), c.pk(o.p_proj), P + o.proj_b, P + o.ls1, x_in, c.w(w.x_mid), c.M);
@@ -403,9 +402,8 @@ void block_backward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void*
         kasf_launch_gcn_bwd1(c.dt, c.s, g_mid, c.w(w.xn), c.w(w.y), (const float*)c.w(w.coef), P + o.ls1, c.w(sc.rbuf), G + o.ls1, (double*)c.w(w.bstats),
                              c.B, c.T, o.mode);
         const double count = o.mode == 0 ? (double)c.B * c.T * 128 : (double)c.B * 17 * 128;
-        kasf_launch_gcn_bwd_finalize(c.s, (const double*)c.w(w.bstats), (float*)c.w(w.coef), G + o.bn_w, G + o.bn_b, o.nodes, count);
         kasf_launch_gcn_bwd2(c.dt, c.s, c.w(sc.rbuf), c.w(w.y), (const float*)c.w(w.coef), w.mask >= 0 ? (const uint32_t*)c.w(w.mask) : nullptr, c.w(sc.duv),
-                             c.B, c.T, o.mode);
+                             c.B, c.T, o.mode, (const double*)c.w(w.bstats), G + o.bn_w, G + o.bn_b, count);
         kasf_launch_dgrad_lnbwd(c.dt, c.s, c.w(sc.duv), 256, c.pk(o.p_mixT), c.w(sc.rbuf), x_in, P + o.n1w, g_mid, dst, accumulate, G + o.n1w, G + o.n1b,
                                 c.M);
         kasf_launch_wgrad(c.dt, c.s, c.w(sc.duv), 256, 256, c.w(w.xn), 128, 128, nullptr, nullptr, G + o.mix_w, 128, G + o.uv_b, c.M, (float*)c.w(sc.wg_part), WG_PARTIAL_FLOATS);

@@ -161,36 +161,56 @@ __global__ __launch_bounds__(256) void k_gcn_agg_temporal(const T* __restrict__ 
     if (threadIdx.x < 2 * L) atomicAdd(stats + threadIdx.x, (double)sStat[threadIdx.x]);
 }
 
-// ------------------------------------------------------------------ BatchNorm1d(num_nodes) statistics -> affine coefficients
-__global__ void k_bn_finalize(const double* __restrict__ stats, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ run_mean,
-                              float* __restrict__ run_var, float* __restrict__ coef, int nodes, double count, int training, float momentum) {
-    const int n = threadIdx.x;
-    if (n >= nodes) return;
-    float mean, var;
+// ------------------------------------------------------------------ BatchNorm1d(num_nodes) + ReLU + layer-scale + residual
+// BatchNorm coefficients of one node from the batch sums (training) or the running statistics (evaluation): graph.py:37
+__device__ __forceinline__ void bn_node_coef(const double* stats, const float* w, const float* bias, const float* run_mean, const float* run_var, int n,
+                                             double count, int training, float& scale, float& shift, float& mean, float& rstd, float& var_unbiased) {
+    float var;
     if (training) {
         const double m = stats[2 * n] / count;
         double v = stats[2 * n + 1] / count - m * m;
         if (v < 0) v = 0;
         mean = (float)m;
         var = (float)v;
-        run_mean[n] = (1.0f - momentum) * run_mean[n] + momentum * mean;
-        run_var[n] = (1.0f - momentum) * run_var[n] + momentum * (float)(v * count / (count - 1.0));
+        var_unbiased = (float)(v * count / (count - 1.0));
     } else {
         mean = run_mean[n];
         var = run_var[n];
+        var_unbiased = var;
     }
-    const float rstd = 1.0f / sqrtf(var + 1e-5f);
-    const float scale = w[n] * rstd;
-    coef[n * COEF_LD + 0] = scale;
-    coef[n * COEF_LD + 1] = bias[n] - mean * scale;
-    coef[n * COEF_LD + 2] = mean;
-    coef[n * COEF_LD + 3] = rstd;
+    rstd = 1.0f / sqrtf(var + 1e-5f);
+    scale = w[n] * rstd;
+    shift = bias[n] - mean * scale;
 }
 
+// out = x + ls1 * relu(xn + BN(y)).  Every workgroup derives the per-node affine itself from the (complete) batch sums -- 17 to 81 nodes --
+// instead of waiting for a one-workgroup finalize launch; workgroup 0 also publishes the coefficients for the backward pass and updates
+// the running statistics.
 template <typename T>
 __global__ __launch_bounds__(256) void k_gcn_apply(const T* __restrict__ x_in, const T* __restrict__ xn, const T* __restrict__ y,
-                                                   const float* __restrict__ coef, const float* __restrict__ ls1, T* __restrict__ out, int64_t M, int Tn,
-                                                   int mode) {
+                                                   const double* __restrict__ stats, const float* __restrict__ bn_w, const float* __restrict__ bn_b,
+                                                   float* __restrict__ run_mean, float* __restrict__ run_var, float* __restrict__ coef,
+                                                   const float* __restrict__ ls1, T* __restrict__ out, int64_t M, int Tn, int mode, int nodes, double count,
+                                                   int training, float momentum) {
+    __shared__ float sC[96][2];
+    if ((int)threadIdx.x < nodes) {
+        const int n = threadIdx.x;
+        float scale, shift, mean, rstd, varu;
+        bn_node_coef(stats, bn_w, bn_b, run_mean, run_var, n, count, training, scale, shift, mean, rstd, varu);
+        sC[n][0] = scale;
+        sC[n][1] = shift;
+        if (blockIdx.x == 0) {
+            coef[n * COEF_LD + 0] = scale;
+            coef[n * COEF_LD + 1] = shift;
+            coef[n * COEF_LD + 2] = mean;
+            coef[n * COEF_LD + 3] = rstd;
+            if (training) {
+                run_mean[n] = (1.0f - momentum) * run_mean[n] + momentum * mean;
+                run_var[n] = (1.0f - momentum) * run_var[n] + momentum * varu;
+            }
+        }
+    }
+    __syncthreads();
     const int sub = threadIdx.x & 15;
     float ls[8];
 #pragma unroll
@@ -198,7 +218,7 @@ __global__ __launch_bounds__(256) void k_gcn_apply(const T* __restrict__ x_in, c
     for (int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x; item < M * 16; item += (int64_t)gridDim.x * 256) {
         const int64_t tok = item >> 4;
         const int node = node_of(tok, Tn, mode);
-        const float sc = coef[node * COEF_LD], sh = coef[node * COEF_LD + 1];
+        const float sc = sC[node][0], sh = sC[node][1];
         float a[8], b[8], c[8];
         load8(x_in + tok * 128 + sub * 8, a);
         load8(xn + tok * 128 + sub * 8, b);
@@ -256,21 +276,13 @@ __global__ __launch_bounds__(256) void k_gcn_bwd1(const T* __restrict__ g, const
     if (threadIdx.x < 2 * nodes) atomicAdd(bstats + threadIdx.x, (double)sStat[threadIdx.x]);
 }
 
-__global__ void k_gcn_bwd_finalize(const double* __restrict__ bstats, float* __restrict__ coef, float* __restrict__ d_w, float* __restrict__ d_b, int nodes,
-                                   double count) {
-    const int n = threadIdx.x;
-    if (n >= nodes) return;
-    d_b[n] += (float)bstats[2 * n];
-    d_w[n] += (float)bstats[2 * n + 1];
-    coef[n * COEF_LD + 4] = (float)(bstats[2 * n] / count);
-    coef[n * COEF_LD + 5] = (float)(bstats[2 * n + 1] / count);
-}
-
 // dy of one 8-channel chunk: BN backward with the finalised per-node means
+// sC: per-node {scale, mean, rstd, c1, c2} in LDS (c1, c2 = the BatchNorm-backward means, derived per workgroup by bwd2_prologue)
+constexpr int C2_LD = 5;
 template <typename T>
-__device__ __forceinline__ void dy_chunk(const T* rbuf, const T* y, const float* coef, int64_t tok, int node, int sub, float (&dy)[8]) {
-    const float sc = coef[node * COEF_LD], mean = coef[node * COEF_LD + 2], rstd = coef[node * COEF_LD + 3];
-    const float c1 = coef[node * COEF_LD + 4], c2 = coef[node * COEF_LD + 5];
+__device__ __forceinline__ void dy_chunk(const T* rbuf, const T* y, const float* sC, int64_t tok, int node, int sub, float (&dy)[8]) {
+    const float sc = sC[node * C2_LD], mean = sC[node * C2_LD + 1], rstd = sC[node * C2_LD + 2];
+    const float c1 = sC[node * C2_LD + 3], c2 = sC[node * C2_LD + 4];
     float r[8], c[8];
     load8(rbuf + tok * 128 + sub * 8, r);
     load8(y + tok * 128 + sub * 8, c);
@@ -278,9 +290,29 @@ __device__ __forceinline__ void dy_chunk(const T* rbuf, const T* y, const float*
     for (int e = 0; e < 8; ++e) dy[e] = sc * (r[e] - c1 - (c[e] - mean) * rstd * c2);
 }
 
+// what k_gcn_bwd_finalize did in a one-workgroup launch: every workgroup derives the node table itself; workgroup 0 accumulates d(bn weight / bias)
+__device__ __forceinline__ void bwd2_prologue(float* sC, const float* coef, const double* bstats, float* d_w, float* d_b, int nodes, double count) {
+    if ((int)threadIdx.x < nodes) {
+        const int n = threadIdx.x;
+        sC[n * C2_LD + 0] = coef[n * COEF_LD];
+        sC[n * C2_LD + 1] = coef[n * COEF_LD + 2];
+        sC[n * C2_LD + 2] = coef[n * COEF_LD + 3];
+        sC[n * C2_LD + 3] = (float)(bstats[2 * n] / count);
+        sC[n * C2_LD + 4] = (float)(bstats[2 * n + 1] / count);
+        if (blockIdx.x == 0) {
+            d_b[n] += (float)bstats[2 * n];
+            d_w[n] += (float)bstats[2 * n + 1];
+        }
+    }
+    __syncthreads();
+}
+
 template <typename T>
-__global__ __launch_bounds__(256) void k_gcn_bwd2_spatial(const T* __restrict__ rbuf, const T* __restrict__ y, const float* __restrict__ coef,
-                                                          T* __restrict__ duv, int64_t M) {
+__global__ __launch_bounds__(256) void k_gcn_bwd2_spatial(const T* __restrict__ rbuf, const T* __restrict__ y, const float* __restrict__ coefg,
+                                                          T* __restrict__ duv, int64_t M, const double* __restrict__ bstats, float* __restrict__ d_w,
+                                                          float* __restrict__ d_b, int nodes, double count) {
+    __shared__ float coef[96 * C2_LD];
+    bwd2_prologue(coef, coefg, bstats, d_w, d_b, nodes, count);
     const int sub = threadIdx.x & 15;
     for (int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x; item < M * 16; item += (int64_t)gridDim.x * 256) {
         const int64_t tok = item >> 4, frame0 = (tok / KASF_J) * KASF_J;
@@ -306,8 +338,11 @@ __global__ __launch_bounds__(256) void k_gcn_bwd2_spatial(const T* __restrict__ 
 }
 
 template <typename T, int L>
-__global__ __launch_bounds__(256) void k_gcn_bwd2_temporal(const T* __restrict__ rbuf, const T* __restrict__ y, const float* __restrict__ coef,
-                                                           const uint32_t* __restrict__ mask, T* __restrict__ duv, int Tn) {
+__global__ __launch_bounds__(256) void k_gcn_bwd2_temporal(const T* __restrict__ rbuf, const T* __restrict__ y, const float* __restrict__ coefg,
+                                                           const uint32_t* __restrict__ mask, T* __restrict__ duv, int Tn, const double* __restrict__ bstats,
+                                                           float* __restrict__ d_w, float* __restrict__ d_b, int nodes, double count) {
+    __shared__ float coef[96 * C2_LD];
+    bwd2_prologue(coef, coefg, bstats, d_w, d_b, nodes, count);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sDy = reinterpret_cast<float*>(smem);        // [L][SX_LD]
     float* sDinv = sDy + L * SX_LD;
@@ -366,9 +401,11 @@ void agg_temporal_TL(hipStream_t s, const void* uv, const void* xn, void* y, uin
                        stats, Tn, 4, tracks);
 }
 template <typename T, int L>
-void bwd2_temporal_TL(hipStream_t s, const void* r, const void* y, const float* coef, const uint32_t* mask, void* duv, int B, int Tn) {
+void bwd2_temporal_TL(hipStream_t s, const void* r, const void* y, const float* coef, const uint32_t* mask, void* duv, int B, int Tn, const double* bstats,
+                      float* d_w, float* d_b, double count) {
     set_smem(k_gcn_bwd2_temporal<T, L>, bwd2_smem<L>());
-    hipLaunchKernelGGL((k_gcn_bwd2_temporal<T, L>), dim3(B * KASF_J), dim3(256), bwd2_smem<L>(), s, (const T*)r, (const T*)y, coef, mask, (T*)duv, Tn);
+    hipLaunchKernelGGL((k_gcn_bwd2_temporal<T, L>), dim3(B * KASF_J), dim3(256), bwd2_smem<L>(), s, (const T*)r, (const T*)y, coef, mask, (T*)duv, Tn, bstats,
+                       d_w, d_b, Tn, count);
 }
 
 template <typename T>
@@ -384,12 +421,14 @@ void agg_fwd_T(hipStream_t s, const void* uv, const void* xn, void* y, uint32_t*
     else kasf_set_error(3, "temporal GCN: n_frames must be one of 9, 27, 81");
 }
 template <typename T>
-void bwd2_T(hipStream_t s, const void* r, const void* y, const float* coef, const uint32_t* mask, void* duv, int B, int Tn, int mode) {
+void bwd2_T(hipStream_t s, const void* r, const void* y, const float* coef, const uint32_t* mask, void* duv, int B, int Tn, int mode, const double* bstats,
+            float* d_w, float* d_b, double count) {
     const int64_t M = (int64_t)B * Tn * KASF_J;
-    if (mode == 0) hipLaunchKernelGGL(k_gcn_bwd2_spatial<T>, dim3(ew_grid(M)), dim3(256), 0, s, (const T*)r, (const T*)y, coef, (T*)duv, M);
-    else if (Tn == 27) bwd2_temporal_TL<T, 27>(s, r, y, coef, mask, duv, B, Tn);
-    else if (Tn == 81) bwd2_temporal_TL<T, 81>(s, r, y, coef, mask, duv, B, Tn);
-    else if (Tn == 9) bwd2_temporal_TL<T, 9>(s, r, y, coef, mask, duv, B, Tn);
+    if (mode == 0) hipLaunchKernelGGL(k_gcn_bwd2_spatial<T>, dim3(ew_grid(M)), dim3(256), 0, s, (const T*)r, (const T*)y, coef, (T*)duv, M, bstats, d_w, d_b,
+                                      KASF_J, count);
+    else if (Tn == 27) bwd2_temporal_TL<T, 27>(s, r, y, coef, mask, duv, B, Tn, bstats, d_w, d_b, count);
+    else if (Tn == 81) bwd2_temporal_TL<T, 81>(s, r, y, coef, mask, duv, B, Tn, bstats, d_w, d_b, count);
+    else if (Tn == 9) bwd2_temporal_TL<T, 9>(s, r, y, coef, mask, duv, B, Tn, bstats, d_w, d_b, count);
     else kasf_set_error(3, "temporal GCN: n_frames must be one of 9, 27, 81");
 }
 
@@ -419,15 +458,13 @@ void kasf_launch_gcn_agg_fwd(int dt, hipStream_t s, const void* uv, const void* 
     if (dt == KASF_F32) agg_fwd_T<float>(s, uv, xn, y, mask, stats, B, T, mode);
     else agg_fwd_T<bf16>(s, uv, xn, y, mask, stats, B, T, mode);
 }
-void kasf_launch_bn_finalize(hipStream_t s, const double* stats, const float* bn_w, const float* bn_b, float* run_mean, float* run_var, float* coef,
-                             int nodes, double count, int training, float momentum) {
-    hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(128), 0, s, stats, bn_w, bn_b, run_mean, run_var, coef, nodes, count, training, momentum);
-}
-void kasf_launch_gcn_apply(int dt, hipStream_t s, const void* x_in, const void* xn, const void* y, const float* coef, const float* ls1, void* out, int B,
-                           int T, int mode) {
+void kasf_launch_gcn_apply(int dt, hipStream_t s, const void* x_in, const void* xn, const void* y, const double* stats, const float* bn_w, const float* bn_b,
+                           float* run_mean, float* run_var, float* coef, const float* ls1, void* out, int B, int T, int mode, double count, int training,
+                           float momentum) {
     const int64_t M = (int64_t)B * T * KASF_J;
-    if (dt == KASF_F32) hipLaunchKernelGGL(k_gcn_apply<float>, dim3(ew_grid(M)), dim3(256), 0, s, (const float*)x_in, (const float*)xn, (const float*)y, coef, ls1, (float*)out, M, T, mode);
-    else hipLaunchKernelGGL(k_gcn_apply<bf16>, dim3(ew_grid(M)), dim3(256), 0, s, (const bf16*)x_in, (const bf16*)xn, (const bf16*)y, coef, ls1, (bf16*)out, M, T, mode);
+    const int nodes = mode == 0 ? KASF_J : T;
+    if (dt == KASF_F32) hipLaunchKernelGGL(k_gcn_apply<float>, dim3(ew_grid(M)), dim3(256), 0, s, (const float*)x_in, (const float*)xn, (const float*)y, stats, bn_w, bn_b, run_mean, run_var, coef, ls1, (float*)out, M, T, mode, nodes, count, training, momentum);
+    else hipLaunchKernelGGL(k_gcn_apply<bf16>, dim3(ew_grid(M)), dim3(256), 0, s, (const bf16*)x_in, (const bf16*)xn, (const bf16*)y, stats, bn_w, bn_b, run_mean, run_var, coef, ls1, (bf16*)out, M, T, mode, nodes, count, training, momentum);
 }
 void kasf_launch_gcn_bwd1(int dt, hipStream_t s, const void* g, const void* xn, const void* y, const float* coef, const float* ls1, void* r,
                           float* dls1, double* bstats, int B, int T, int mode) {
@@ -438,12 +475,9 @@ void kasf_launch_gcn_bwd1(int dt, hipStream_t s, const void* g, const void* xn, 
     if (dt == KASF_F32) hipLaunchKernelGGL(k_gcn_bwd1<float>, dim3(grid), dim3(256), 0, s, (const float*)g, (const float*)xn, (const float*)y, coef, ls1, (float*)r, dls1, bstats, M, T, mode, nodes);
     else hipLaunchKernelGGL(k_gcn_bwd1<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)g, (const bf16*)xn, (const bf16*)y, coef, ls1, (bf16*)r, dls1, bstats, M, T, mode, nodes);
 }
-void kasf_launch_gcn_bwd_finalize(hipStream_t s, const double* bstats, float* coef, float* d_bn_w, float* d_bn_b, int nodes, double count) {
-    hipLaunchKernelGGL(k_gcn_bwd_finalize, dim3(1), dim3(128), 0, s, bstats, coef, d_bn_w, d_bn_b, nodes, count);
-}
 void kasf_launch_gcn_bwd2(int dt, hipStream_t s, const void* r, const void* y, const float* coef, const uint32_t* mask, void* duv, int B, int T,
-                          int mode) {
+                          int mode, const double* bstats, float* d_bn_w, float* d_bn_b, double count) {
     kasf_gcn_init();
-    if (dt == KASF_F32) bwd2_T<float>(s, r, y, coef, mask, duv, B, T, mode);
-    else bwd2_T<bf16>(s, r, y, coef, mask, duv, B, T, mode);
+    if (dt == KASF_F32) bwd2_T<float>(s, r, y, coef, mask, duv, B, T, mode, bstats, d_bn_w, d_bn_b, count);
+    else bwd2_T<bf16>(s, r, y, coef, mask, duv, B, T, mode, bstats, d_bn_w, d_bn_b, count);
 }

@@ -79,15 +79,15 @@ bool kasf_launch_attn_bwd_mfma(hipStream_t s, const void* q, int64_t ldq, const 
 // ---- k_gcn.hip ----
 void kasf_gcn_init();   // uploads the skeleton table to constant memory (blocking; call once per process before capture)
 void kasf_launch_gcn_agg_fwd(int dt, hipStream_t s, const void* uv, const void* xn, void* y, uint32_t* mask, double* stats, int B, int T, int mode);
-void kasf_launch_bn_finalize(hipStream_t s, const double* stats, const float* bn_w, const float* bn_b, float* run_mean, float* run_var, float* coef,
-                             int nodes, double count, int training, float momentum);
-void kasf_launch_gcn_apply(int dt, hipStream_t s, const void* x_in, const void* xn, const void* y, const float* coef, const float* ls1, void* out, int B,
-                           int T, int mode);
+// BatchNorm finalisation (batch sums or running statistics -> per-node affine `coef`, running-statistics update) is part of the apply kernel
+void kasf_launch_gcn_apply(int dt, hipStream_t s, const void* x_in, const void* xn, const void* y, const double* stats, const float* bn_w, const float* bn_b,
+                           float* run_mean, float* run_var, float* coef, const float* ls1, void* out, int B, int T, int mode, double count, int training,
+                           float momentum);
 void kasf_launch_gcn_bwd1(int dt, hipStream_t s, const void* g, const void* xn, const void* y, const float* coef, const float* ls1, void* r,
                           float* dls1, double* bstats, int B, int T, int mode);
-void kasf_launch_gcn_bwd_finalize(hipStream_t s, const double* bstats, float* coef, float* d_bn_w, float* d_bn_b, int nodes, double count);
+// BatchNorm-backward finalisation (means of the backward sums, d(bn weight / bias)) is part of bwd2
 void kasf_launch_gcn_bwd2(int dt, hipStream_t s, const void* r, const void* y, const float* coef, const uint32_t* mask, void* duv, int B, int T,
-                          int mode);
+                          int mode, const double* bstats, float* d_bn_w, float* d_bn_b, double count);
 
 // ---- k_misc.hip ----
 void kasf_launch_prologue_fwd(int dt, hipStream_t s, const float* x, const float* params, const KasfProOff* off, void* xj, void* xb, void* xl,
