@@ -723,10 +723,19 @@ int kasf_backward(const kasf_model* m, const float* params, const void* packed, 
             const KasfProOff& po = m->pro;
             const float* src[3] = {(const float*)c.w(p.x3), (const float*)c.w(p.bone3), (const float*)c.w(p.limb3)};
             const void* gs[3] = {g_x, c.w(p.g_bone), c.w(p.g_limb)};
-            for (int sidx = 0; sidx < 3; ++sidx)
-                kasf_launch_embed_bwd(c.dt, c.s, gs[sidx], src[sidx], params + po.embed_w[sidx], grads + po.embed_w[sidx], grads + po.embed_b[sidx],
+            // the three embedding backward passes are independent: joints and bone on the side streams, limb (+ the limb-refusion MLPs that
+            // consume its input gradient) on the caller's stream
+            if (!single_stream()) HIPCHK(hipEventRecord(m->ev_fork, c.s));
+            for (int sidx = 0; sidx < 3; ++sidx) {
+                hipStream_t st = (sidx == 2 || single_stream()) ? c.s : m->side[sidx];
+                if (st != c.s) HIPCHK(hipStreamWaitEvent(st, m->ev_fork, 0));
+                kasf_launch_embed_bwd(c.dt, st, gs[sidx], src[sidx], params + po.embed_w[sidx], grads + po.embed_w[sidx], grads + po.embed_b[sidx],
                                       grads + po.pos[sidx], sidx == 2 ? (float*)c.w(p.dlimb3) : nullptr, frames);
+                if (st != c.s) HIPCHK(hipEventRecord(m->ev_join[sidx], st));
+            }
             kasf_launch_refusion_bwd(c.s, (const float*)c.w(p.x3), (const float*)c.w(p.dlimb3), params, grads, m->d_pro, frames);
+            if (!single_stream())
+                for (int sidx = 0; sidx < 2; ++sidx) HIPCHK(hipStreamWaitEvent(c.s, m->ev_join[sidx], 0));
         }
     }
     HIPCHK(hipGetLastError());
