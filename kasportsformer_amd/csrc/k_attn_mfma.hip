@@ -55,6 +55,16 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16* s_tile, int ks) {
     const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)(s_tile + (k0 + 8 + q) * 16 + 4 * p));
     return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
+// same, out of a row-major [32 rows][32 columns] tile: element j of lane (column = lane & 31, half hh) = tile[kappa(ks,hh,j)][lane & 31].
+// Turns a tile written with lane = row into the operand of a product whose lanes are the columns (the 32 x 32 transpose of P / dS).
+__device__ __forceinline__ bf16x8 tr_frag32(const bf16* s_tile, int ks) {
+    const int lane = threadIdx.x & 63, u = lane & 15, hh = lane >> 5, q = u >> 2, p = u & 3, c0 = 16 * ((lane >> 4) & 1);
+    typedef __attribute__((address_space(3))) bf16x4 lds_v4;
+    const int k0 = 16 * ks + 4 * hh;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)(s_tile + (k0 + q) * 32 + c0 + 4 * p));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)(s_tile + (k0 + 8 + q) * 32 + c0 + 4 * p));
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
 // registers 8s..8s+7 of an accumulator tile -> bf16 operand fragment of k-step s
 __device__ __forceinline__ bf16x8 pack8(const f32x16& t, int s) {
     bf16x8 o;
@@ -127,7 +137,8 @@ __global__ __launch_bounds__(256) void k_attn_bwd_mfma(const bf16* __restrict__ 
                                                        bf16* __restrict__ dK, bf16* __restrict__ dV, int64_t lddkv, int L, int Tn, int mode, int units) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TILE = NKT * 32 * 16;                           // bf16 elements of one [positions][16] tile
-    constexpr int WAVE_BYTES = 3 * TILE * 2 + NKT * 32 * 16;      // K, Q, dO tiles + [positions][4] fp32 statistics
+    constexpr int WAVE_BYTES = 3 * TILE * 2 + NKT * 32 * 16 + (NKT == 1 ? 2 * 32 * 32 * 2 : 0);   // K, Q, dO tiles + [positions][4] fp32 statistics
+                                                                                               // (+ P and dS tiles, one-tile groups)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
     const int unit = blockIdx.x * 4 + wave;
     if (unit >= units) return;
@@ -136,6 +147,8 @@ __global__ __launch_bounds__(256) void k_attn_bwd_mfma(const bf16* __restrict__ 
     bf16* sQ = sK + TILE;
     bf16* sD = sQ + TILE;
     f32x4* sStat = reinterpret_cast<f32x4*>(sD + TILE);
+    bf16* sP = reinterpret_cast<bf16*>(sStat + NKT * 32);             // NKT == 1: P[query][key] and dS[query][key] of pass 1, bf16
+    bf16* sdS = sP + 32 * 32;
     bf16x8 kf[NKT], vf[NKT], qf[NKT], df[NKT];
 #pragma unroll
     for (int t = 0; t < NKT; ++t) {
@@ -178,6 +191,14 @@ __global__ __launch_bounds__(256) void k_attn_bwd_mfma(const bf16* __restrict__ 
             for (int g = 0; g < 16; ++g) { st[kt][g] *= inv; delta += st[kt][g] * dp[kt][g]; }
         delta += __shfl_xor(delta, 32);
         f32x16 dq = zero16();
+        if (NKT == 1) {   // one-tile groups: hand P to pass 2 through LDS instead of recomputing the softmax there (lane = query -> row of the tile;
+                          // registers 4a..4a+3 are the consecutive keys 8a + 4hh ..)
+#pragma unroll
+            for (int a4 = 0; a4 < 4; ++a4) {
+                float v4[4] = {st[0][4 * a4], st[0][4 * a4 + 1], st[0][4 * a4 + 2], st[0][4 * a4 + 3]};
+                store4(sP + r * 32 + 8 * a4 + 4 * hh, v4);
+            }
+        }
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
@@ -186,7 +207,29 @@ __global__ __launch_bounds__(256) void k_attn_bwd_mfma(const bf16* __restrict__ 
             dq = mfma32(tr_frag(sK, 2 * kt + 1), pack8(st[kt], 1), dq);
         }
         if (i < L) store_t(dQ + tok_of(G, i, Tn, mode) * lddq + h * 16, dq, hh);
-        if (hh == 0) sStat[i] = f32x4{mx, inv, delta, 0.f};
+        if (NKT == 1) {
+#pragma unroll
+            for (int a4 = 0; a4 < 4; ++a4) {
+                float v4[4] = {st[0][4 * a4], st[0][4 * a4 + 1], st[0][4 * a4 + 2], st[0][4 * a4 + 3]};
+                store4(sdS + r * 32 + 8 * a4 + 4 * hh, v4);
+            }
+        } else if (hh == 0) sStat[i] = f32x4{mx, inv, delta, 0.f};
+    }
+    if (NKT == 1) {   // ---------------- pass 2, one-tile groups: dV^T = dO^T . P, dK^T = Q^T . dS with P / dS read back transposed ----------------
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the tiles were written by other lanes of this wave (LDS is in order per wave)
+        const int j = r;
+        f32x16 dv = zero16(), dk = zero16();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            dv = mfma32(tr_frag(sD, ks), tr_frag32(sP, ks), dv);
+            dk = mfma32(tr_frag(sQ, ks), tr_frag32(sdS, ks), dk);
+        }
+        if (j < L) {
+            const int64_t tok = tok_of(G, j, Tn, mode);
+            store_t(dV + tok * lddkv + h * 16, dv, hh);
+            store_t(dK + tok * lddkv + h * 16, dk, hh);
+        }
+        return;
     }
     // ---------------- pass 2: lane = key ----------------
 #pragma unroll
@@ -247,7 +290,7 @@ bool kasf_launch_attn_bwd_mfma(hipStream_t s, const void* q, int64_t ldq, const 
     if (L > 96) return false;
     const dim3 grid((units + 3) / 4);
     if (L <= 32) {
-        const size_t sh = 4 * (3 * 32 * 16 * 2 + 32 * 16);
+        const size_t sh = 4 * (3 * 32 * 16 * 2 + 32 * 16 + 2 * 32 * 32 * 2);
         hipLaunchKernelGGL(k_attn_bwd_mfma<1>, grid, dim3(256), sh, s, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldkv, (const bf16*)d_o, (bf16*)dq,
                            lddq, (bf16*)dk, (bf16*)dv, lddkv, L, Tn, mode, units);
     } else {
