@@ -57,6 +57,14 @@ def test_layout_covers_reference_state_dict(golden_dir):
     assert ranges[0][0] == 0 and ranges[-1][1] == live and all(a[1] == c[0] for a, c in zip(ranges, ranges[1:]))
     assert lib.kasf_workspace_bytes(h, 256, 1) > lib.kasf_workspace_bytes(h, 256, 0) > 0
     lib.kasf_model_destroy(h)
+    # plain-mean fusion (use_adaptive_fusion=False, KASportsFormer.py:284): the gate Linear never gets a gradient either -> never-updated region
+    cfg2 = _lib.KasfConfig(26, 27, 8, 4, 0, 1)
+    _lib.check(lib.kasf_model_create_layout_only(C.byref(cfg2), C.byref(h)))
+    params2 = {n: (o, s) for n, o, s in _lib.param_entries(h)}
+    live2 = lib.kasf_param_live_count(h)
+    dead2 = {n for n, (o, _) in params2.items() if o >= live2}
+    assert set(params2) == set(params) and dead2 == dead | {n for n in params if ".fusion_three_channel." in n} and len(dead2) == 208 + 52
+    lib.kasf_model_destroy(h)
 
 
 def test_host_module_contract(golden_dir):
