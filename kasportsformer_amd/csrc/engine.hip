@@ -410,7 +410,9 @@ void block_backward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void*
         return;
     }
     // d_o = g_mid . (ls1 . Wproj);  G_proj = g_mid^T o (unscaled) -> finalize: dWproj, dbproj, dls1
-    kasf_launch_linear(c.dt, c.s, g_mid, 128, c.pk(o.p_projTs), 128, nullptr, c.w(sc.d_o), 128, c.M, 128, nullptr, nullptr, nullptr, 0);
+    static const bool no_fdo = getenv("KASF_NO_FUSED_DO") != nullptr;          // measurement switch
+    const bool fdo = c.dt == KASF_BF16 && !no_fdo && (o.mode == 0 ? 17 : c.T) <= 32;   // d_o formed inside the attention backward kernel
+    if (!fdo) kasf_launch_linear(c.dt, c.s, g_mid, 128, c.pk(o.p_projTs), 128, nullptr, c.w(sc.d_o), 128, c.M, 128, nullptr, nullptr, nullptr, 0);
     // bf16: every weight gradient of the block (proj, qkv | q, kv) goes into ONE streaming launch + one finishing launch at the end of the block
     static const bool no_jobs = getenv("KASF_NO_WGRAD_JOBS") != nullptr;       // measurement switch
     const bool jobs = c.dt == KASF_BF16 && !no_jobs;
@@ -422,8 +424,10 @@ void block_backward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void*
     if (o.kind == KIND_ATT) {
         const char* q = (const char*)c.w(w.qkv);
         char* dq = (char*)c.w(sc.dqkv);
-        kasf_launch_attn_bwd(c.dt, c.s, q, 384, q + 128 * c.es, q + 256 * c.es, 384, c.w(sc.d_o), dq, 384, dq + 128 * c.es, dq + 256 * c.es, 384, c.B, c.T,
-                             o.mode);
+        if (fdo) kasf_launch_attn_bwd_fused_do(c.s, q, 384, q + 128 * c.es, q + 256 * c.es, 384, g_mid, c.pk(o.p_projTs), dq, 384, dq + 128 * c.es,
+                                               dq + 256 * c.es, 384, c.B, c.T, o.mode);
+        else kasf_launch_attn_bwd(c.dt, c.s, q, 384, q + 128 * c.es, q + 256 * c.es, 384, c.w(sc.d_o), dq, 384, dq + 128 * c.es, dq + 256 * c.es, 384, c.B,
+                                  c.T, o.mode);
         kasf_launch_dgrad_lnbwd(c.dt, c.s, dq, 384, c.pk(o.p_mixT), nullptr, x_in, P + o.n1w, g_mid, dst, accumulate, G + o.n1w, G + o.n1b, c.M,
                                 c.w(sc.xn_a), P + o.n1b);
         bool done = false;
@@ -446,7 +450,9 @@ void block_backward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void*
         const char* kv = (const char*)c.w(w.kv);
         char* dq = (char*)c.w(sc.dqkv);
         char* dkv = dq + c.M * 128 * c.es;
-        kasf_launch_attn_bwd(c.dt, c.s, c.w(w.qkv), 128, kv, kv + 128 * c.es, 256, c.w(sc.d_o), dq, 128, dkv, dkv + 128 * c.es, 256, c.B, c.T, o.mode);
+        if (fdo) kasf_launch_attn_bwd_fused_do(c.s, c.w(w.qkv), 128, kv, kv + 128 * c.es, 256, g_mid, c.pk(o.p_projTs), dq, 128, dkv, dkv + 128 * c.es, 256, c.B,
+                                               c.T, o.mode);
+        else kasf_launch_attn_bwd(c.dt, c.s, c.w(w.qkv), 128, kv, kv + 128 * c.es, 256, c.w(sc.d_o), dq, 128, dkv, dkv + 128 * c.es, 256, c.B, c.T, o.mode);
         kasf_launch_dgrad_lnbwd(c.dt, c.s, dq, 128, c.pk(o.p_mixT), nullptr, x_in, P + o.n1w, g_mid, dst, accumulate, G + o.n1w, G + o.n1b, c.M,
                                 c.w(sc.xn_a), P + o.n1b);
         kasf_launch_dgrad_lnbwd(c.dt, c.s, dkv, 256, c.pk(o.p_kvT), nullptr, x_limb, P + o.n1lw, nullptr, c.w(p.g_limb), 1, G + o.n1lw, G + o.n1lb, c.M,

@@ -131,17 +131,24 @@ __global__ __launch_bounds__(256) void k_attn_fwd_mfma(const bf16* __restrict__ 
     }
 }
 
-template <int NKT>
-__global__ __launch_bounds__(256) void k_attn_bwd_mfma(const bf16* __restrict__ Q, int64_t ldq, const bf16* __restrict__ K, const bf16* __restrict__ V,
-                                                       int64_t ldkv, const bf16* __restrict__ dO, bf16* __restrict__ dQ, int64_t lddq,
-                                                       bf16* __restrict__ dK, bf16* __restrict__ dV, int64_t lddkv, int L, int Tn, int mode, int units) {
+// FDO (one-tile groups only): the gradient of the attention output is not read from memory but formed here, d_o = g_mid . (ls1 . Wproj)
+// restricted to this head's 16 channels: the workgroup is the 8 heads of ONE group, g_mid's rows are staged once (LDS-direct) and each wave
+// runs 8 MFMAs against its 16 rows of the packed weight.  Saves the d_o round trip (60 MB) and a launch per attention block.
+template <int NKT, bool FDO>
+__global__ __launch_bounds__(FDO ? 512 : 256) void k_attn_bwd_mfma(const bf16* __restrict__ Q, int64_t ldq, const bf16* __restrict__ K,
+                                                                   const bf16* __restrict__ V, int64_t ldkv, const bf16* __restrict__ dO,
+                                                                   bf16* __restrict__ dQ, int64_t lddq, bf16* __restrict__ dK, bf16* __restrict__ dV,
+                                                                   int64_t lddkv, int L, int Tn, int mode, int units, const bf16* __restrict__ Gmid,
+                                                                   const bf16* __restrict__ Wp) {
+    static_assert(!FDO || NKT == 1, "fused d_o: one-tile groups");
+    constexpr int NWAVE = FDO ? 8 : 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TILE = NKT * 32 * 16;                           // bf16 elements of one [positions][16] tile
     constexpr int WAVE_BYTES = 3 * TILE * 2 + NKT * 32 * 16 + (NKT == 1 ? 2 * 32 * 32 * 2 : 0);   // K, Q, dO tiles + [positions][4] fp32 statistics
                                                                                                // (+ P and dS tiles, one-tile groups)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
-    const int unit = blockIdx.x * 4 + wave;
-    if (unit >= units) return;
+    const int unit = blockIdx.x * NWAVE + wave;
+    if (!FDO && unit >= units) return;                                  // (FDO: the grid is exactly one workgroup per group)
     const int G = unit >> 3, h = unit & 7;
     bf16* sK = reinterpret_cast<bf16*>(smem + wave * WAVE_BYTES);
     bf16* sQ = sK + TILE;
@@ -150,13 +157,40 @@ __global__ __launch_bounds__(256) void k_attn_bwd_mfma(const bf16* __restrict__ 
     bf16* sP = reinterpret_cast<bf16*>(sStat + NKT * 32);             // NKT == 1: P[query][key] and dS[query][key] of pass 1, bf16
     bf16* sdS = sP + 32 * 32;
     bf16x8 kf[NKT], vf[NKT], qf[NKT], df[NKT];
+    if (FDO) {
+        bf16* sG = reinterpret_cast<bf16*>(smem + NWAVE * WAVE_BYTES);           // [32][128] g_mid rows of the group (swizzled tile)
+        stage_tile_async<bf16, 32, 512>(sG, Gmid + tok_of(G, 0, Tn, mode) * 128, mode == 0 ? 128 : (int64_t)KASF_J * 128, L);
+    }
 #pragma unroll
     for (int t = 0; t < NKT; ++t) {
         const int pos = 32 * t + r;
         kf[t] = row_frag(K, ldkv, G, pos, L, Tn, mode, h, hh, sK);
         vf[t] = row_frag(V, ldkv, G, pos, L, Tn, mode, h, hh, nullptr);
         qf[t] = row_frag(Q, ldq, G, pos, L, Tn, mode, h, hh, sQ);
-        df[t] = row_frag(dO, 128, G, pos, L, Tn, mode, h, hh, sD);
+        if (!FDO) df[t] = row_frag(dO, 128, G, pos, L, Tn, mode, h, hh, sD);
+    }
+    if (FDO) {
+        const bf16* sG = reinterpret_cast<const bf16*>(smem + NWAVE * WAVE_BYTES);
+        const int li = lane & 15, lg = lane >> 4;
+        bf16x8 wp[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) wp[ks] = *reinterpret_cast<const bf16x8*>(Wp + (int64_t)(16 * h + li) * 128 + 32 * ks + 8 * lg);
+        wait_async();
+        __syncthreads();
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[ks], *reinterpret_cast<const bf16x8*>(sG + Tile<bf16>::chunk_off(li, 4 * ks + lg)), acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[ks], *reinterpret_cast<const bf16x8*>(sG + Tile<bf16>::chunk_off(16 + li, 4 * ks + lg)), acc[1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {             // d_o[pos = 16 mt + li][channel 4 lg .. 4 lg + 3] of this head; rows past L are zero like row_frag's
+            const float live = 16 * mt + li < L ? 1.0f : 0.0f;
+            float v[4] = {acc[mt][0] * live, acc[mt][1] * live, acc[mt][2] * live, acc[mt][3] * live};
+            store4(sD + (16 * mt + li) * 16 + 4 * lg, v);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        df[0] = *reinterpret_cast<const bf16x8*>(sD + r * 16 + 8 * hh);
     }
     // ---------------- pass 1: lane = query ----------------
 #pragma unroll
@@ -291,12 +325,26 @@ bool kasf_launch_attn_bwd_mfma(hipStream_t s, const void* q, int64_t ldq, const 
     const dim3 grid((units + 3) / 4);
     if (L <= 32) {
         const size_t sh = 4 * (3 * 32 * 16 * 2 + 32 * 16 + 2 * 32 * 32 * 2);
-        hipLaunchKernelGGL(k_attn_bwd_mfma<1>, grid, dim3(256), sh, s, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldkv, (const bf16*)d_o, (bf16*)dq,
-                           lddq, (bf16*)dk, (bf16*)dv, lddkv, L, Tn, mode, units);
+        hipLaunchKernelGGL((k_attn_bwd_mfma<1, false>), grid, dim3(256), sh, s, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldkv, (const bf16*)d_o,
+                           (bf16*)dq, lddq, (bf16*)dk, (bf16*)dv, lddkv, L, Tn, mode, units, (const bf16*)nullptr, (const bf16*)nullptr);
     } else {
         const size_t sh = 4 * (3 * 96 * 16 * 2 + 96 * 16);
-        hipLaunchKernelGGL(k_attn_bwd_mfma<3>, grid, dim3(256), sh, s, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldkv, (const bf16*)d_o, (bf16*)dq,
-                           lddq, (bf16*)dk, (bf16*)dv, lddkv, L, Tn, mode, units);
+        hipLaunchKernelGGL((k_attn_bwd_mfma<3, false>), grid, dim3(256), sh, s, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldkv, (const bf16*)d_o,
+                           (bf16*)dq, lddq, (bf16*)dk, (bf16*)dv, lddkv, L, Tn, mode, units, (const bf16*)nullptr, (const bf16*)nullptr);
     }
+    return true;
+}
+
+// Attention backward with the projection's data gradient fused in (bf16, groups of <= 32 positions): d_o = g_mid . WprojTs^T is formed per head
+// inside the kernel.  false: shape not covered (the caller computes d_o with a linear and calls kasf_launch_attn_bwd).
+bool kasf_launch_attn_bwd_fused_do(hipStream_t s, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, const void* g_mid,
+                                   const void* WprojTs, void* dq, int64_t lddq, void* dk, void* dv, int64_t lddkv, int B, int Tn, int mode) {
+    const int L = mode == 0 ? KASF_J : Tn, groups = mode == 0 ? B * Tn : B * KASF_J;
+    if (L > 32) return false;
+    if (groups <= 0) return true;
+    const size_t sh = 8 * (3 * 32 * 16 * 2 + 32 * 16 + 2 * 32 * 32 * 2) + 32 * 128 * 2;
+    set_smem(k_attn_bwd_mfma<1, true>, sh);
+    hipLaunchKernelGGL((k_attn_bwd_mfma<1, true>), dim3(groups), dim3(512), sh, s, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldkv,
+                       (const bf16*)nullptr, (bf16*)dq, lddq, (bf16*)dk, (bf16*)dv, lddkv, L, Tn, mode, groups * 8, (const bf16*)g_mid, (const bf16*)WprojTs);
     return true;
 }
