@@ -9,6 +9,7 @@ Public surface mirrors the reference's interface for this path:
   clip_metrics, Evaluator, evaluate_one_epoch
   pack_clip_directory, PackedClips,     data/preprocessor/clip_generate_sp.py:28-79 (file format), data/reader/sp_dataset.py:45-92
   DeviceClipLoader
+  train_one_epoch                       train_and_evaluate_sp.py:201-243
   warmup_lr, ReduceLROnPlateau          train_and_evaluate_sp.py:273,325-329,393-397
   checkpoint_save, checkpoint_load      utils/utilities.py:110-118, train_and_evaluate_sp.py:171-176,285-301
 """
@@ -18,9 +19,10 @@ from .optim import FusedAdamW
 from .parallel import DataParallel
 from .data import PackedClips, DeviceClipLoader, pack_clip_directory, read_clip_file, shard_indices
 from .checkpoint import checkpoint_save, checkpoint_load, strip_module_prefix, adamw_state_dict, load_adamw_state_dict
+from .loop import train_one_epoch
 from .schedule import warmup_lr, apply_warmup, ReduceLROnPlateau
 from .evaluate import joint_flip, predict_flip_tta, clip_metrics, Evaluator, evaluate_one_epoch
 
 __all__ = ["KASportsFormer", "load_model", "loss3", "FusedAdamW", "DataParallel", "joint_flip", "predict_flip_tta", "clip_metrics", "Evaluator",
            "evaluate_one_epoch", "PackedClips", "DeviceClipLoader", "pack_clip_directory", "read_clip_file", "shard_indices",
-           "checkpoint_save", "checkpoint_load", "strip_module_prefix", "adamw_state_dict", "load_adamw_state_dict", "warmup_lr", "apply_warmup", "ReduceLROnPlateau"]
+           "checkpoint_save", "checkpoint_load", "strip_module_prefix", "adamw_state_dict", "load_adamw_state_dict", "warmup_lr", "apply_warmup", "ReduceLROnPlateau", "train_one_epoch"]

@@ -90,3 +90,33 @@ def test_gather_out_of_range_index_yields_zero_clip():
     _lib.check(lib.kasf_gather_clips(xa.data_ptr(), None, idx.data_ptr(), None, 3, 4, 9, out.data_ptr(), None,
                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)))
     assert torch.equal(out[0], xa[2]) and torch.equal(out[3], xa[0]) and float(out[1].abs().max()) == 0 and float(out[2].abs().max()) == 0
+
+
+def test_train_one_epoch_over_device_loader_matches_oracle_loop():
+    """Loader -> model -> loss -> fused optimizer through K.train_one_epoch against the reference's loop restated with the oracle (sp:201-243)."""
+    import kasportsformer_amd as K
+    from gpu_util import make_pair
+    clips = K.pack_clip_directory(os.path.join(CLIPS, "SPgt-9", "train"))
+    oracle, model = make_pair(1, 9, "fp32")
+    opt = K.FusedAdamW(model, lr=5e-4, weight_decay=0.01)
+    topt = torch.optim.AdamW(oracle.parameters(), lr=5e-4, weight_decay=0.01)
+    loader = K.DeviceClipLoader(clips, batch_size=2, shuffle=True, flip=True, seed=5)
+    loader.set_epoch(0)
+    batches = [(x.cpu(), y.cpu()) for x, y in loader]
+    loader.set_epoch(0)                                               # same epoch -> same order and the same flips
+    got = K.train_one_epoch(model, loader, opt)
+    oracle.train()
+    sums, n = [0.0, 0.0, 0.0, 0.0], 0
+    for x, y in batches:
+        pred = oracle(x)
+        topt.zero_grad()
+        total, (l1, l2, l3) = O.loss_total(pred, y)
+        for k, v in enumerate((total, l1, l2, l3)):
+            sums[k] += float(v) * x.shape[0]
+        n += x.shape[0]
+        total.backward()
+        topt.step()
+    for k, name in enumerate(("loss_total", "loss_mpjpe", "loss_n_mpjpe", "loss_velocity")):
+        assert abs(got[name] - sums[k] / n) < 2e-3 * abs(sums[k] / n), (name, got[name], sums[k] / n)
+    worst = max(float((p.detach().cpu() - q.detach()).abs().max()) for p, q in zip(model.parameters(), oracle.parameters()))
+    assert worst < 3 * 5e-4                                           # three AdamW steps at lr 5e-4
