@@ -113,3 +113,30 @@ def test_stacked_tta_forward_equals_two_forwards_and_train_mode_is_kept_separate
         b = (model(x) + K.joint_flip(model(K.joint_flip(x)))) / 2
         b[:, :, 0] = 0
     assert torch.equal(a, b)                                          # eval-mode rows are independent: stacking changes nothing, bit for bit
+
+
+def test_full_size_properties_at_baseline_config():
+    """BASELINE.json configs[1] size (26 layers, T=27, B=256, bf16), through properties that need no oracle run:
+    (1) a clip's evaluation-mode prediction does not depend on its batch (bit-exact), (2) flip-TTA commutes with the flip:
+    tta(flip(x)) == flip(tta(x)) bit for bit, root joint exactly zero, (3) the metric kernel is invariant to the same symmetry."""
+    import kasportsformer_amd as K
+    torch.manual_seed(114514)
+    model = K.KASportsFormer(n_layers=26, num_heads=8, n_frames=27, compute_dtype="bf16").cuda().eval()
+    x, y = O.synthetic_clips(256, 27, seed=1234)
+    x = x.cuda()
+    with torch.no_grad():
+        full = model(x)
+        for i in (0, 101, 255):
+            assert torch.equal(full[i:i + 1], model(x[i:i + 1])), i
+        a = K.predict_flip_tta(model, x)
+        b = K.predict_flip_tta(model, K.joint_flip(x))
+    assert torch.isfinite(a).all() and float(a[:, :, 0].abs().max()) == 0.0
+    assert torch.equal(K.joint_flip(a), b)
+    label_scaled, factor, res, _ = O.synthetic_test_extras(y, seed=7)
+    m1 = K.clip_metrics(a, label_scaled, factor, res)
+    m2 = K.clip_metrics(b, K.joint_flip(label_scaled.cuda()), factor, res)          # mirrored prediction vs mirrored ground truth
+    perm = torch.tensor([0, 4, 5, 6, 1, 2, 3, 7, 8, 9, 10, 14, 15, 16, 11, 12, 13], device="cuda")
+    assert torch.allclose(m1[0], m2[0], rtol=1e-5, atol=1e-4)                         # MPJPE
+    assert torch.allclose(m1[1][:, :, perm], m2[1], rtol=1e-5, atol=1e-4)             # per-joint errors, left/right swapped
+    assert torch.allclose(m1[2], m2[2], rtol=1e-5, atol=1e-4)                         # acceleration error
+    assert torch.allclose(m1[3], m2[3], rtol=1e-4, atol=1e-3)                         # P-MPJPE: a reflection is undone by ... the reflection fix
