@@ -17,6 +17,12 @@ import os
 import sys
 import time
 
+# The engine runs the three branches of a layer on three HIP streams.  RCCL adds streams of its own, and with the runtime's default of 4
+# hardware queues per process the branch streams then share queues and serialise (measured: -6 % with a process group merely alive).
+# Must be set before the HIP runtime loads, i.e. before `import torch`.
+if int(os.environ.get("WORLD_SIZE", "1")) > 1 or "--force-dp" in sys.argv:
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -139,13 +145,24 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="clips per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-roofline", action="store_true")
+    ap.add_argument("--force-dp", action="store_true", help="testing: take the data-parallel code path (stage-sliced backward, RCCL all-reduce) with one rank")
     args = ap.parse_args()
+    # stdout carries exactly ONE line (the JSON): everything else any library prints there (RCCL's version banner on communicator
+    # creation, for instance) is sent to stderr by pointing file descriptor 1 at it for the duration of the run.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     torch.cuda.set_device(local)
     import torch.distributed as dist
-    if world > 1:
+    if world > 1 or args.force_dp:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     import kasportsformer_amd as K
     from oracle import kasf_oracle as O      # synthetic input generator only (checker-side data recipe)
@@ -155,9 +172,12 @@ def main():
     model.attach_param_grads = False
     opt = K.FusedAdamW(model, lr=5e-4, weight_decay=0.01)
     dp = None
-    if world > 1:
-        dp = K.DataParallel(model)
+    if world > 1 or args.force_dp:
+        dp = K.DataParallel(model, overlap=os.environ.get("KASF_DP_OVERLAP", "1") != "0")
         opt.grad_scale = 1.0 / world
+        if os.environ.get("KASF_DP_SKIP_ALLREDUCE") == "1":          # diagnosis only: process group alive, no collective in the step
+            model.grad_stage_hook = None
+            dp.finish_gradients = lambda: None
     x, y = O.synthetic_clips(args.batch, T, seed=1234 + rank)
     x, y = x.cuda(), y.cuda()
 
@@ -251,8 +271,9 @@ def main():
             out["kernels"] = {k: {"ms": v["seconds"] * 1e3, "tflops": v["achieved_tflops"]} for k, v in ks.items()}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out))
-    if world > 1:
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    if world > 1 or args.force_dp:
         dist.destroy_process_group()
 
 

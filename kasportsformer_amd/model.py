@@ -273,12 +273,25 @@ class KASportsFormer(nn.Module):
         if self.grad_stage_hook is None:
             _lib.check(self._lib.kasf_backward(*args, 0, stages, self._stream()))
         else:
+            # `grad_stage_group` consecutive stages per call: the gradient ranges of consecutive layers are adjacent, so each call finalises one
+            # contiguous bucket (two for the last group: layers + top level) that the hook hands to the all-reduce while the next group runs
             b, e = C.c_int64(), C.c_int64()
-            for st in range(stages):
-                _lib.check(self._lib.kasf_backward(*args, st, st + 1, self._stream()))
-                _lib.check(self._lib.kasf_stage_grad_range(h, st, C.byref(b), C.byref(e)))
-                if e.value > b.value:
-                    self.grad_stage_hook(st, g[b.value:e.value])
+            group = max(1, int(getattr(self, "grad_stage_group", 1)))
+            for st in range(0, stages, group):
+                end = min(st + group, stages)
+                _lib.check(self._lib.kasf_backward(*args, st, end, self._stream()))
+                spans = []                                           # adjacent stage ranges merge; the top-level range stays on its own
+                for k in range(st, end):
+                    _lib.check(self._lib.kasf_stage_grad_range(h, k, C.byref(b), C.byref(e)))
+                    if e.value > b.value:
+                        if spans and spans[-1][0] == e.value:
+                            spans[-1][0] = b.value
+                        elif spans and spans[-1][1] == b.value:
+                            spans[-1][1] = e.value
+                        else:
+                            spans.append([b.value, e.value])
+                for lo, hi in spans:
+                    self.grad_stage_hook(st, g[lo:hi])
         self.flat_grad = g
         if self.attach_param_grads:
             for p, off, n, shape in self._live:
