@@ -274,6 +274,7 @@ def main():
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if world > 1 or args.force_dp:
+        dist.barrier()                       # rank 0 may still be in its kernel micro-benchmark: leave together
         dist.destroy_process_group()
 
 
