@@ -61,6 +61,6 @@ def test_rccl_single_rank_matches_plain_run(tmp_path):
     script = tmp_path / "dp_worker.py"
     script.write_text(WORKER)
     env = dict(os.environ, KASF_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
-               HSA_ENABLE_IPC_MODE_LEGACY="0")
+               HSA_ENABLE_IPC_MODE_LEGACY="0", GPU_MAX_HW_QUEUES="8")
     out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "DP_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
