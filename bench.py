@@ -20,8 +20,7 @@ import time
 # The engine runs the three branches of a layer on three HIP streams.  RCCL adds streams of its own, and with the runtime's default of 4
 # hardware queues per process the branch streams then share queues and serialise (measured: -6 % with a process group merely alive).
 # Must be set before the HIP runtime loads, i.e. before `import torch`.
-if int(os.environ.get("WORLD_SIZE", "1")) > 1 or "--force-dp" in sys.argv:
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")          # no effect on the single-process run (measured), needed as soon as RCCL is alive
 
 import torch
 
