@@ -13,6 +13,7 @@
 // and the transposed LDS reads fetch the other operand in exactly that key order.
 // Backward runs two passes per (group, head): pass 1 with lane = query (softmax statistics, delta, dQ), pass 2
 // with lane = key (S and dP recomputed un-transposed; dK, dV), exchanging only 3 floats per query through LDS.
+#include <cstdlib>
 #include "common.h"
 #include "kernels.h"
 
@@ -298,6 +299,118 @@ __global__ __launch_bounds__(FDO ? 512 : 256) void k_attn_bwd_mfma(const bf16* _
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Backward for groups of 33..96 positions (temporal attention at T = 81), one wave per (group, head), built to fit TWO waves per SIMD
+// (<= 256 VGPRs, 16 KB of LDS per wave): the two-pass kernel above needs 296 VGPRs, runs one wave per SIMD and spends most of its time
+// waiting on MFMA -> VALU -> LDS dependencies it cannot hide.  Here every query tile is visited once: its softmax statistics, delta and dQ
+// are formed with lane = query; each 32 x 32 block of P and dS then goes through a 2 KB LDS tile and is read back transposed
+// (ds_read_b64_tr_b16) as the operand of the dV / dK products (lane = key), which accumulate in registers across the query tiles.
+// K and V fragments are re-read from LDS instead of living in registers.
+// ---------------------------------------------------------------------------------------------------------------
+template <int NKT>
+__global__ __launch_bounds__(256, 2) void k_attn_bwd_long(const bf16* __restrict__ Q, int64_t ldq, const bf16* __restrict__ K, const bf16* __restrict__ V,
+                                                          int64_t ldkv, const bf16* __restrict__ dO, bf16* __restrict__ dQ, int64_t lddq,
+                                                          bf16* __restrict__ dK, bf16* __restrict__ dV, int64_t lddkv, int L, int Tn, int mode, int units) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TILE = NKT * 32 * 16;                           // [positions][16] operand tile
+    constexpr int WAVE_BYTES = (4 * TILE + 2 * 32 * 32) * 2;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
+    const int unit = blockIdx.x * 4 + wave;
+    if (unit >= units) return;                                    // wave-uniform; no workgroup barrier below
+    const int G = unit >> 3, h = unit & 7;
+    bf16* sK = reinterpret_cast<bf16*>(smem + wave * WAVE_BYTES);
+    bf16* sV = sK + TILE;
+    bf16* sQ = sV + TILE;
+    bf16* sD = sQ + TILE;
+    bf16* sP = sD + TILE;                                         // [32 queries][32 keys] block of P
+    bf16* sdS = sP + 32 * 32;                                     // ... and of dS
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) {
+        const int pos = 32 * t + r;
+        row_frag(K, ldkv, G, pos, L, Tn, mode, h, hh, sK);
+        row_frag(V, ldkv, G, pos, L, Tn, mode, h, hh, sV);
+        row_frag(Q, ldq, G, pos, L, Tn, mode, h, hh, sQ);
+        row_frag(dO, 128, G, pos, L, Tn, mode, h, hh, sD);
+    }
+    f32x16 dv[NKT], dk[NKT];
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) { dv[t] = zero16(); dk[t] = zero16(); }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    auto rowf = [&](const bf16* tile, int t) { return *reinterpret_cast<const bf16x8*>(tile + (32 * t + r) * 16 + 8 * hh); };
+#pragma unroll
+    for (int qt = 0; qt < NKT; ++qt) {
+        if (32 * qt >= L) break;
+        const int i = 32 * qt + r;
+        const bf16x8 qf = rowf(sQ, qt), dfq = rowf(sD, qt);
+        f32x16 st[NKT];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            st[kt] = mfma32(rowf(sK, kt), qf, zero16());          // S^T[key][query]
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const float sv = (32 * kt + pos_of(g, hh) < L) ? st[kt][g] * 0.25f : -INFINITY;
+                st[kt][g] = sv;
+                mx = fmaxf(mx, sv);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) { st[kt][g] = __expf(st[kt][g] - mx); sum += st[kt][g]; }
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.0f / sum;
+        float delta = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            const f32x16 dp = mfma32(rowf(sV, kt), dfq, zero16());       // dP^T[key][query]
+#pragma unroll
+            for (int g = 0; g < 16; ++g) { st[kt][g] *= inv; delta += st[kt][g] * dp[g]; }
+        }
+        delta += __shfl_xor(delta, 32);
+        f32x16 dq = zero16();
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            if (32 * kt >= L) break;
+#pragma unroll
+            for (int a4 = 0; a4 < 4; ++a4) {                      // P block: registers 4a..4a+3 = keys 8a + 4hh .. of this key tile
+                float v4[4] = {st[kt][4 * a4], st[kt][4 * a4 + 1], st[kt][4 * a4 + 2], st[kt][4 * a4 + 3]};
+                store4(sP + r * 32 + 8 * a4 + 4 * hh, v4);
+            }
+            const f32x16 dp = mfma32(rowf(sV, kt), dfq, zero16());       // one more MFMA instead of 16 live registers per key tile
+#pragma unroll
+            for (int g = 0; g < 16; ++g) st[kt][g] = st[kt][g] * (dp[g] - delta) * 0.25f;          // dS^T (scale folded)
+            dq = mfma32(tr_frag(sK, 2 * kt), pack8(st[kt], 0), dq);
+            dq = mfma32(tr_frag(sK, 2 * kt + 1), pack8(st[kt], 1), dq);
+#pragma unroll
+            for (int a4 = 0; a4 < 4; ++a4) {
+                float v4[4] = {st[kt][4 * a4], st[kt][4 * a4 + 1], st[kt][4 * a4 + 2], st[kt][4 * a4 + 3]};
+                store4(sdS + r * 32 + 8 * a4 + 4 * hh, v4);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the blocks were written by other lanes of this wave
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {                      // lane = key: dV^T += dO^T . P,  dK^T += Q^T . dS over the 32 queries of this tile
+                dv[kt] = mfma32(tr_frag(sD, 2 * qt + ks), tr_frag32(sP, ks), dv[kt]);
+                dk[kt] = mfma32(tr_frag(sQ, 2 * qt + ks), tr_frag32(sdS, ks), dk[kt]);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the next key tile overwrites the blocks
+        }
+        if (i < L) store_t(dQ + tok_of(G, i, Tn, mode) * lddq + h * 16, dq, hh);
+    }
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+        const int j = 32 * kt + r;
+        if (j < L) {
+            const int64_t tok = tok_of(G, j, Tn, mode);
+            store_t(dV + tok * lddkv + h * 16, dv[kt], hh);
+            store_t(dK + tok * lddkv + h * 16, dk[kt], hh);
+        }
+    }
+}
+
 template <typename K> void set_smem(K k, size_t bytes) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
@@ -328,6 +441,14 @@ bool kasf_launch_attn_bwd_mfma(hipStream_t s, const void* q, int64_t ldq, const 
         hipLaunchKernelGGL((k_attn_bwd_mfma<1, false>), grid, dim3(256), sh, s, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldkv, (const bf16*)d_o,
                            (bf16*)dq, lddq, (bf16*)dk, (bf16*)dv, lddkv, L, Tn, mode, units, (const bf16*)nullptr, (const bf16*)nullptr);
     } else {
+        static const bool two_pass = getenv("KASF_ATTN_BWD_TWO_PASS") != nullptr;     // measurement switch: the recomputing two-pass form
+        if (!two_pass) {
+            const size_t shl = 4 * (size_t)(4 * 96 * 16 + 2 * 32 * 32) * 2;
+            set_smem(k_attn_bwd_long<3>, shl);
+            hipLaunchKernelGGL(k_attn_bwd_long<3>, grid, dim3(256), shl, s, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldkv, (const bf16*)d_o,
+                               (bf16*)dq, lddq, (bf16*)dk, (bf16*)dv, lddkv, L, Tn, mode, units);
+            return true;
+        }
         const size_t sh = 4 * (3 * 96 * 16 * 2 + 96 * 16);
         hipLaunchKernelGGL((k_attn_bwd_mfma<3, false>), grid, dim3(256), sh, s, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldkv, (const bf16*)d_o,
                            (bf16*)dq, lddq, (bf16*)dk, (bf16*)dv, lddkv, L, Tn, mode, units, (const bf16*)nullptr, (const bf16*)nullptr);
