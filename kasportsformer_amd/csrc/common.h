@@ -116,6 +116,39 @@ template <typename T = float> __device__ __forceinline__ float gelu_f(float x) {
     gelu_tail<GeluMode<T>::FAST>(x, s, e);
     return fmaf(-fabsf(x), s, fmaxf(x, 0.0f));
 }
+// Two bf16-mode GELUs at once in packed fp32 (v_pk_fma_f32 / v_pk_mul_f32): 15 instructions per pair instead of 2 x 12.
+//   GELU(x) = x/2 + |x| (1/2 - s),  s = e . G(|x|) as in gelu_tail<true>.  No clamp of |x|: e underflows to 0 long before G overflows
+//   (|x| > 8e6), so the product stays finite for every activation a LayerNorm'd input can produce.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int N> __device__ __forceinline__ void gelu_pairs_fast(f32x2 (&x)[N]) {      // in place; the N Horner chains advance together: a dependent
+    auto C = [](float v) { return f32x2{v, v}; };                                        // v_pk_fma_f32 issued back to back costs a wait state
+    auto fma2 = [](f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); };
+    f32x2 a[N], e[N], G[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        a[k][0] = __builtin_fabsf(x[k][0]);
+        a[k][1] = __builtin_fabsf(x[k][1]);
+        const f32x2 u = x[k] * x[k] * C(-0.72134752044448170f);
+        e[k][0] = __builtin_amdgcn_exp2f(u[0]);
+        e[k][1] = __builtin_amdgcn_exp2f(u[1]);
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) G[k] = fma2(a[k], C(7.042173346e-04f), C(-8.041790507e-03f));
+#pragma unroll
+    for (int k = 0; k < N; ++k) G[k] = fma2(a[k], G[k], C(3.967198035e-02f));
+#pragma unroll
+    for (int k = 0; k < N; ++k) G[k] = fma2(a[k], G[k], C(-1.169407755e-01f));
+#pragma unroll
+    for (int k = 0; k < N; ++k) G[k] = fma2(a[k], G[k], C(2.444233516e-01f));
+#pragma unroll
+    for (int k = 0; k < N; ++k) G[k] = fma2(a[k], G[k], C(-3.982094769e-01f));
+#pragma unroll
+    for (int k = 0; k < N; ++k) G[k] = fma2(a[k], G[k], C(4.999843037e-01f));
+#pragma unroll
+    for (int k = 0; k < N; ++k) G[k] = fma2(-G[k], e[k], C(0.5f));
+#pragma unroll
+    for (int k = 0; k < N; ++k) x[k] = fma2(a[k], G[k], x[k] * C(0.5f));
+}
 template <typename T = float> __device__ __forceinline__ void gelu_and_grad(float x, float& y, float& dy) {
     float s, e;
     gelu_tail<GeluMode<T>::FAST>(x, s, e);

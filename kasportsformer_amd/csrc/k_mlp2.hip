@@ -559,6 +559,11 @@ void kasf_launch_mlp_fwd_r(hipStream_t s, const void* x, const float* ln_g, cons
     const int64_t tiles = (M + F_BM - 1) / F_BM;
     static const int cap = getenv("KASF_MLP_FWD_GRID") ? atoi(getenv("KASF_MLP_FWD_GRID")) : 256;     // measurement switch
     const unsigned grid = (unsigned)(tiles < cap ? tiles : cap);
+    static const bool lockstep = getenv("KASF_MLP_FWD_LOCKSTEP") != nullptr;                          // measurement switch: the symmetric kernel
+    if (!lockstep) {
+        kasf_launch_mlp_fwd_s(s, x, ln_g, ln_b, W1, b1, W2, b2, ls2, out, M, xn_out, grid);
+        return;
+    }
     const size_t sh = (size_t)(9 * F_BM * 128) * sizeof(bf16);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_fwd_r), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     hipLaunchKernelGGL(k_mlp_fwd_r, dim3(grid), dim3(F_THR), sh, s, (const bf16*)x, ln_g, ln_b, (const bf16*)W1, b1, (const bf16*)W2, b2, ls2, (bf16*)out, M, (bf16*)xn_out);

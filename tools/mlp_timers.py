@@ -1,0 +1,30 @@
+"""Reads the clock64 segment timers of a -DKASF_PROBE_TIMERS build of k_mlp3.hip (workgroup 7, lane 0 of a producer and a consumer wave)."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from kasportsformer_amd import _lib
+lib = _lib.load()
+raw = C.CDLL(_lib.LIB_PATH)
+buf = (C.c_longlong * 32)()
+M = 256 * 27 * 17
+dev, bf = "cuda", torch.bfloat16
+x = torch.randn(M, 128, device=dev).to(bf); out = torch.empty_like(x); xn = torch.empty_like(x)
+w1 = (torch.randn(512, 128, device=dev) * 0.05).to(bf); w2 = (torch.randn(128, 512, device=dev) * 0.05).to(bf)
+b1 = torch.zeros(512, device=dev); b2 = torch.zeros(128, device=dev); ls = torch.ones(128, device=dev); gam = torch.ones(128, device=dev); bet = torch.zeros(128, device=dev)
+p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
+names = {0: "P frag+gemm1(0)", 1: "P slices", 2: "P barrier", 8: "C issue", 9: "C gemm2", 10: "C wait vmcnt", 11: "C layernorm", 12: "C epilogue", 13: "C barrier"}
+for label, xo in (("with xn store", xn), ("no xn store", None)):
+    lib.kasf_op_mlp_fwd(1, p(x), p(gam), p(bet), p(w1), p(b1), p(w2), p(b2), p(ls), p(out), M, p(xo), st())
+    raw.kasf_debug_read_prof(buf, 1)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        lib.kasf_op_mlp_fwd(1, p(x), p(gam), p(bet), p(w1), p(b1), p(w2), p(b2), p(ls), p(out), M, p(xo), st())
+    e1.record(); torch.cuda.synchronize()
+    raw.kasf_debug_read_prof(buf, 0)
+    v = list(buf)
+    tiles = 10 * ((M + 31) // 32 + 255) // 256
+    print(label, "us/launch", e0.elapsed_time(e1) * 100)
+    for k, n in names.items():
+        print(f"   {n:20s} {v[k] / tiles:9.0f} cycles/tile")
