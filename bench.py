@@ -79,7 +79,7 @@ def kernel_rooflines(M):
     wg2 = lambda: lib.kasf_op_wgrad(1, p(gout), 128, p(H), 512, None, None, p(dW2), p(gs), M, p(part), part.numel(), st())
     res = {}
     # algorithmic FLOP: forward 2 GEMMs; fused backward = dgrad (2 GEMMs) + wgrad (2 GEMMs) = 2x forward (the Z recompute is not counted)
-    for name, fn, flop in (("k_mlp_fwd_r", fwd, MLP_FLOP_PER_TOKEN_FWD * M), ("k_mlp_bwd_q(+lnbwd_sum4+wfinish)", bwd, 2 * MLP_FLOP_PER_TOKEN_FWD * M),
+    for name, fn, flop in (("k_mlp_fwd_s", fwd, MLP_FLOP_PER_TOKEN_FWD * M), ("k_mlp_bwd_q(+lnbwd_sum4+wfinish)", bwd, 2 * MLP_FLOP_PER_TOKEN_FWD * M),
                            ("k_wgrad_ring[512x128]", wg1, MLP_FLOP_PER_TOKEN_FWD // 2 * M), ("k_wgrad_ring[128x512]", wg2, MLP_FLOP_PER_TOKEN_FWD // 2 * M)):
         t = time_kernel(fn)
         res[name] = {"seconds": t, "achieved_tflops": flop / t / 1e12, "algorithmic_flop": flop}
@@ -87,7 +87,7 @@ def kernel_rooflines(M):
 
 
 TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_traffic.json")
-TRAFFIC_PARTS = {"k_mlp_fwd_r": {"k_mlp_fwd_r": 1}, "k_mlp_bwd_q(+lnbwd_sum4+wfinish)": {"k_mlp_bwd_q": 1, "k_lnbwd_sum4": 1, "k_mlp_wfinish": 1}}
+TRAFFIC_PARTS = {"k_mlp_fwd_s": {"k_mlp_fwd_s": 1}, "k_mlp_bwd_q(+lnbwd_sum4+wfinish)": {"k_mlp_bwd_q": 1, "k_lnbwd_sum4": 1, "k_mlp_wfinish": 1}}
 
 
 def pmc_traffic(entry, M):

@@ -149,6 +149,42 @@ template <int N> __device__ __forceinline__ void gelu_pairs_fast(f32x2 (&x)[N]) 
 #pragma unroll
     for (int k = 0; k < N; ++k) x[k] = fma2(a[k], G[k], x[k] * C(0.5f));
 }
+// ... and GELU with its derivative for N pairs:  GELU'(x) = Phi + x phi = 1/2 + copysign(1/2 - s, x) + x e / sqrt(2 pi)
+template <int N> __device__ __forceinline__ void gelu_grad_pairs_fast(f32x2 (&x)[N], f32x2 (&dy)[N]) {
+    auto C = [](float v) { return f32x2{v, v}; };
+    auto fma2 = [](f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); };
+    f32x2 a[N], e[N], G[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        a[k][0] = __builtin_fabsf(x[k][0]);
+        a[k][1] = __builtin_fabsf(x[k][1]);
+        const f32x2 u = x[k] * x[k] * C(-0.72134752044448170f);
+        e[k][0] = __builtin_amdgcn_exp2f(u[0]);
+        e[k][1] = __builtin_amdgcn_exp2f(u[1]);
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) G[k] = fma2(a[k], C(7.042173346e-04f), C(-8.041790507e-03f));
+#pragma unroll
+    for (int k = 0; k < N; ++k) G[k] = fma2(a[k], G[k], C(3.967198035e-02f));
+#pragma unroll
+    for (int k = 0; k < N; ++k) G[k] = fma2(a[k], G[k], C(-1.169407755e-01f));
+#pragma unroll
+    for (int k = 0; k < N; ++k) G[k] = fma2(a[k], G[k], C(2.444233516e-01f));
+#pragma unroll
+    for (int k = 0; k < N; ++k) G[k] = fma2(a[k], G[k], C(-3.982094769e-01f));
+#pragma unroll
+    for (int k = 0; k < N; ++k) G[k] = fma2(a[k], G[k], C(4.999843037e-01f));
+#pragma unroll
+    for (int k = 0; k < N; ++k) G[k] = fma2(-G[k], e[k], C(0.5f));              // 1/2 - s
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        f32x2 cs;
+        cs[0] = __builtin_copysignf(G[k][0], x[k][0]);
+        cs[1] = __builtin_copysignf(G[k][1], x[k][1]);
+        dy[k] = fma2(x[k] * C(0.3989422804014327f), e[k], cs + C(0.5f));
+        x[k] = fma2(a[k], G[k], x[k] * C(0.5f));
+    }
+}
 template <typename T = float> __device__ __forceinline__ void gelu_and_grad(float x, float& y, float& dy) {
     float s, e;
     gelu_tail<GeluMode<T>::FAST>(x, s, e);

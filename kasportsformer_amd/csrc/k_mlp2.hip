@@ -143,6 +143,16 @@ __global__ __launch_bounds__(NW * 64) void k_mlp_bwd_q(const bf16* __restrict__ 
             // rows past M (only the last tile of the last range has any) must not leak GELU(b1) into anything: masked variant there only
             auto epilogue = [&](auto MASKED) {
                 constexpr bool masked = decltype(MASKED)::value;
+                constexpr int NP = NTW * Q_MT * 2;           // all pairs of the wave advance together (dependent packed FMAs back to back cost wait states)
+                f32x2 z[NP], dg[NP];
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < Q_MT; ++mt)
+#pragma unroll
+                        for (int hp = 0; hp < 2; ++hp)
+                            z[(nt * Q_MT + mt) * 2 + hp] = f32x2{accZ[nt][mt][2 * hp] + bias4[nt][2 * hp], accZ[nt][mt][2 * hp + 1] + bias4[nt][2 * hp + 1]};
+                gelu_grad_pairs_fast(z, dg);
 #pragma unroll
                 for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
@@ -151,9 +161,8 @@ __global__ __launch_bounds__(NW * 64) void k_mlp_bwd_q(const bf16* __restrict__ 
                         const float live = (!masked || mt * 16 + i < nvalid) ? 1.0f : 0.0f;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            float dg;
-                            gelu_and_grad<bf16>(accZ[nt][mt][r] + bias4[nt][r], h[r], dg);
-                            dz[r] = accH[nt][mt][r] * dg;
+                            h[r] = z[(nt * Q_MT + mt) * 2 + (r >> 1)][r & 1];
+                            dz[r] = accH[nt][mt][r] * dg[(nt * Q_MT + mt) * 2 + (r >> 1)][r & 1];
                             if (masked) { h[r] *= live; dz[r] *= live; }
                             db1acc[nt][r] += dz[r];
                         }

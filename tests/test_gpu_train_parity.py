@@ -73,7 +73,10 @@ def test_training_then_evaluation_tracks_oracle(init, cd, tol_mm):
     osd, msd = oracle.state_dict(), model.state_dict()
     for n in osd:      # BatchNorm running statistics drive the evaluation-mode forward (a missed or mis-weighted update would be an O(1) error)
         if n.endswith("running_var") or n.endswith("running_mean"):
-            assert torch.allclose(msd[n].cpu(), osd[n], rtol=0.1 if cd == "bf16" else 5e-2, atol=0.1 if cd == "bf16" else 5e-3), n
+            # seeded weights: a flipped top-4 neighbour (see above) shifts the statistics of that layer's temporal mixer by ~10 %; run-to-run noise of
+            # the fp32 atomics decides whether it happens, so that case gets the bf16 room
+            loose = cd == "bf16" or init == "seeded"
+            assert torch.allclose(msd[n].cpu(), osd[n], rtol=0.1 if loose else 5e-2, atol=0.1 if loose else 5e-3), n
         if n.endswith("num_batches_tracked"):
             assert int(msd[n]) == int(osd[n]) == STEPS
 
