@@ -551,10 +551,15 @@ void kasf_launch_mlp_bwd_q(hipStream_t s, const void* x, const void* xn, const v
     const int used = (int)((tiles + tpr - 1) / tpr);             // ranges that own at least one tile
     float* p1 = partial;
     float* p2 = partial + (int64_t)used * 512 * 128;
-    const size_t sh = (size_t)(8 * Q_BM * 128) * sizeof(bf16);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_bwd_q<Q_NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    hipLaunchKernelGGL(k_mlp_bwd_q<Q_NW>, dim3(4 * used), dim3(Q_NW * 64), sh, s, (const bf16*)xn, (const bf16*)g, (const bf16*)W1, b1, (const bf16*)W2ts,
-                       (const bf16*)W1t, (bf16*)dApart, p1, p2, db1, M, tpr);
+    static const bool lockstep = getenv("KASF_MLP_BWD_LOCKSTEP") != nullptr;                          // measurement switch: the symmetric kernel
+    if (!lockstep) {
+        kasf_launch_mlp_bwd_s(s, xn, g, W1, b1, W2ts, W1t, dApart, p1, p2, db1, M, tpr, used);
+    } else {
+        const size_t sh = (size_t)(8 * Q_BM * 128) * sizeof(bf16);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_bwd_q<Q_NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        hipLaunchKernelGGL(k_mlp_bwd_q<Q_NW>, dim3(4 * used), dim3(Q_NW * 64), sh, s, (const bf16*)xn, (const bf16*)g, (const bf16*)W1, b1, (const bf16*)W2ts,
+                           (const bf16*)W1t, (bf16*)dApart, p1, p2, db1, M, tpr);
+    }
     int64_t blocks = (M + 15) / 16;
     if (blocks > 512) blocks = 512;                     // few blocks: every block ends with 384 same-address atomics (contended atomics serialise)
     hipLaunchKernelGGL(k_lnbwd_sum4, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16*)dApart, (const bf16*)x, (const bf16*)g, ln_g, (bf16*)g_in, dgamma,

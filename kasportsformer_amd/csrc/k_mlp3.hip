@@ -17,6 +17,7 @@
 // LDS: sA 2 x 8 KB, sH 2 x 32 KB, raw x ring 4 x 8 KB (tiles t-1, t, t+1 in use, t+2 in flight), parameters 4 KB.
 #include "common.h"
 #include "kernels.h"
+#include "tile_ops.h"
 #include <type_traits>
 
 #ifdef KASF_PROBE_TIMERS
@@ -254,6 +255,262 @@ __global__ __launch_bounds__(S_THR) void k_mlp_fwd_s(const bf16* __restrict__ X,
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Fused MLP backward with specialised waves: the same hidden-quarter ownership, grid mapping, inputs and outputs as k_mlp_bwd_q
+// (k_mlp2.hip, where the algorithm is described), but waves 0-3 (one per SIMD) are producers and waves 4-7 consumers:
+//     iteration t:   producers  Z_q(t), dH_q(t), GELU / GELU' -> sH[t & 1], sD[t & 1]                       (wave p: hidden units [32p, 32p + 32) of the quarter)
+//                    consumers  loads of tile t+2;  dA_q(t-1) = W1_q^T dZ_q  (wave c: channels [32c, 32c + 32)),
+//                               dW1_q += dZ_q^T LN(x),  dW2_q += g^T H_q  of tile t-1  (wave c: a 64 x 64 block of each 128 x 128 quarter)
+// One barrier per 32-token tile.  Against the symmetric kernel every B fragment feeds twice as many MFMAs (LDS reads per tile: 176 KB, was
+// 288 KB), the per-wave loop overheads exist once per role instead of eight times, and a SIMD holds a vector-heavy and a matrix-heavy
+// wave.  LDS: LN(x) and g rings 5 x (8 + 8) KB (tile t-1 still feeds the weight gradients while t is in use and t+1 .. t+3 land), H / dZ
+// double-buffered 2 x (8 + 8) KB.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(S_THR) void k_mlp_bwd_s(const bf16* __restrict__ XN, const bf16* __restrict__ G, const bf16* __restrict__ W1,
+                                                     const float* __restrict__ b1, const bf16* __restrict__ W2ts, const bf16* __restrict__ W1t,
+                                                     bf16* __restrict__ dApart, float* __restrict__ dW1part, float* __restrict__ dW2part,
+                                                     float* __restrict__ db1, int64_t M, int tiles_per_range) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* sA = reinterpret_cast<bf16*>(smem);            // [5][32][128] LN(x) ring
+    bf16* sG = sA + 5 * TL;                              // [5][32][128] upstream gradient ring
+    bf16* sH = sG + 5 * TL;                              // [2][32][128] H of this quarter
+    bf16* sD = sH + 2 * TL;                              // [2][32][128] dZ of this quarter
+    int q, range;
+    {   // the four hidden quarters of one token range sit on one XCD (see k_mlp_bwd_q)
+        const int used = gridDim.x >> 2, full = used & ~7, b = blockIdx.x;
+        if (b < 4 * full) { q = (b >> 3) & 3; range = (b & 7) + 8 * (b >> 5); }
+        else { q = (b - 4 * full) & 3; range = full + ((b - 4 * full) >> 2); }
+    }
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+    const int64_t tile0 = (int64_t)range * tiles_per_range;
+    const int64_t ntiles_total = (M + S_BM - 1) / S_BM;
+    int64_t ntiles = ntiles_total - tile0;
+    if (ntiles > tiles_per_range) ntiles = tiles_per_range;
+
+    if (w < 4) {
+        // ------------------------------------------------ producer: hidden units [32w, 32w + 32) of the quarter ------------------------------------------------
+        const int h0 = 32 * w;
+        bf16x8 w1f[2][4], w2f[2][4];
+        f32x4 bias4[2], db1acc[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                w1f[nt][ks] = *reinterpret_cast<const bf16x8*>(W1 + (int64_t)(q * 128 + h0 + 16 * nt + i) * 128 + 32 * ks + 8 * g);
+                w2f[nt][ks] = *reinterpret_cast<const bf16x8*>(W2ts + (int64_t)(q * 128 + h0 + 16 * nt + i) * 128 + 32 * ks + 8 * g);
+            }
+            bias4[nt] = *reinterpret_cast<const f32x4*>(b1 + q * 128 + h0 + 16 * nt + 4 * g);
+            db1acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        barrier_keep_async();                            // tile 0 has landed
+        TSTART();
+        int sp = 0;                                      // ring slot of tile t (t mod 5, rolling)
+        for (int64_t t = 0; t <= ntiles; ++t, sp = sp == 4 ? 0 : sp + 1) {
+            if (t < ntiles) {
+                const bf16* cA = sA + sp * TL;
+                const bf16* cG = sG + sp * TL;
+                bf16* cH = sH + (int)(t & 1) * TL;
+                bf16* cD = sD + (int)(t & 1) * TL;
+                const int64_t row0 = (tile0 + t) * S_BM;
+                const int nvalid = (int)((M - row0) < S_BM ? (M - row0) : S_BM);
+                // all 16 operand fragments first (64 VGPRs), then the MFMAs of hidden slice 1 are issued BEFORE the GELU of slice 0 so that the matrix pipe
+                // works through them while the vector ALU does the GELU
+                bf16x8 fa[4][2], fg[4][2];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) { fa[ks][mt] = tok_frag(cA, mt * 16 + i, ks); fg[ks][mt] = tok_frag(cG, mt * 16 + i, ks); }
+                f32x4 accZ[2][2], accH[2][2];
+                zero_acc(accZ);
+                zero_acc(accH);
+                auto gemm = [&](int nt) {
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt) {
+                            accZ[nt][mt] = mfma16(w1f[nt][ks], fa[ks][mt], accZ[nt][mt]);
+                            accH[nt][mt] = mfma16(w2f[nt][ks], fg[ks][mt], accH[nt][mt]);
+                        }
+                };
+                const bool ragged = nvalid != S_BM;      // rows past M (only the last tile of the last range has any) must not leak GELU(b1) into anything
+                auto act = [&](int nt) {
+                    f32x2 z[4], dg[4];
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int hp = 0; hp < 2; ++hp)
+                            z[2 * mt + hp] = f32x2{accZ[nt][mt][2 * hp] + bias4[nt][2 * hp], accZ[nt][mt][2 * hp + 1] + bias4[nt][2 * hp + 1]};
+                    gelu_grad_pairs_fast(z, dg);
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        float h[4], dz[4];
+                        const float live = (!ragged || mt * 16 + i < nvalid) ? 1.0f : 0.0f;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            h[r] = z[2 * mt + (r >> 1)][r & 1] * live;
+                            dz[r] = accH[nt][mt][r] * dg[2 * mt + (r >> 1)][r & 1] * live;
+                            db1acc[nt][r] += dz[r];
+                        }
+                        store4(cH + Tile<bf16>::off4(mt * 16 + i, h0 + 16 * nt + 4 * g), h);
+                        store4(cD + Tile<bf16>::off4(mt * 16 + i, h0 + 16 * nt + 4 * g), dz);
+                    }
+                };
+                gemm(0);
+                __builtin_amdgcn_sched_barrier(0);
+                TMARK(16);
+                gemm(1);
+                act(0);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {           // one MFMA of slice 1 to five vector instructions of slice 0
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                act(1);
+                TMARK(17);
+            }
+            barrier_keep_async();
+            TMARK(18);
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = db1acc[nt][r];                 // sum over the 16 token lanes that share (g, r)
+                v += __shfl_xor(v, 1);
+                v += __shfl_xor(v, 2);
+                v += __shfl_xor(v, 4);
+                v += __shfl_xor(v, 8);
+                if (i == 0) atomicAdd(db1 + q * 128 + h0 + 16 * nt + 4 * g + r, v);
+            }
+    } else {
+        // ------------------------------------------------ consumer: channels [32c, 32c + 32) of dA, a 64 x 64 block of each weight-gradient quarter ------------------------------------------------
+        const int c = w - 4, ch0 = 32 * c, tr0 = 64 * (c >> 1), tc0 = 64 * (c & 1);
+        bf16x8 wtf[2][4];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) wtf[nt][ks] = *reinterpret_cast<const bf16x8*>(W1t + (int64_t)(ch0 + 16 * nt + i) * 512 + q * 128 + 32 * ks + 8 * g);
+        f32x4 accW1[4][4], accW2[4][4];
+        zero_acc(accW1);
+        zero_acc(accW2);
+        auto issue = [&](int64_t t, int slot) {          // four LDS-direct loads per consumer wave: rows [8c, 8c + 8) of g and LN(x) of tile t
+            const int64_t tt = t < ntiles ? t : 0;       // past the range: harmless re-read that keeps the per-issue load count constant
+            const int64_t row0 = (tile0 + tt) * S_BM;
+            const int nvalid = t < ntiles ? (int)((M - row0) < S_BM ? (M - row0) : S_BM) : 1;
+            const unsigned baseG = __builtin_amdgcn_readfirstlane(lds_addr(sG + slot * TL));
+            const unsigned baseA = __builtin_amdgcn_readfirstlane(lds_addr(sA + slot * TL));
+            const void* ug = uniform_ptr(G + row0 * 128);
+            const void* ua = uniform_ptr(XN + row0 * 128);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int inst = 2 * c + k, row = inst * 4 + (lane >> 4), pc = lane & 15, chn = pc ^ (row & 15);
+                const int srow = row < nvalid ? row : nvalid - 1;
+                const unsigned off = (unsigned)srow * 256u + (unsigned)chn * 16u;
+                glds16_s(ug, off, baseG + (unsigned)inst * 1024u);
+                glds16_s(ua, off, baseA + (unsigned)inst * 1024u);
+            }
+        };
+        issue(0, 0);
+        issue(1, 1);
+        issue(2, 2);
+        wait_async_le<8>();                              // tile 0 has landed (tiles 1 and 2 may still be in flight)
+        barrier_keep_async();
+        TSTART();
+        int si = 3, sc = 4;                              // ring slots of tile t+3 (issued) and tile t-1 (consumed), rolling mod 5
+        for (int64_t t = 0; t <= ntiles; ++t, si = si == 4 ? 0 : si + 1, sc = sc == 4 ? 0 : sc + 1) {
+            issue(t + 3, si);                            // into the slot of tile t-2: three tiles of HBM latency cover
+            TMARK(24);
+            f32x4 accA[2][2];
+            if (t >= 1) {
+                const bf16* cA = sA + sc * TL;
+                const bf16* cG = sG + sc * TL;
+                const bf16* cH = sH + (int)((t - 1) & 1) * TL;
+                const bf16* cD = sD + (int)((t - 1) & 1) * TL;
+                {   // ---- dA_q partial: 32 channels x 32 tokens over the 128 hidden units of the quarter ----
+                    zero_acc(accA);
+                    bf16x8 fd[2][2];
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) fd[0][mt] = tok_frag(cD, mt * 16 + i, 0);
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        if (ks + 1 < 4) {
+#pragma unroll
+                            for (int mt = 0; mt < 2; ++mt) fd[(ks + 1) & 1][mt] = tok_frag(cD, mt * 16 + i, ks + 1);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                            for (int nt = 0; nt < 2; ++nt) accA[nt][mt] = mfma16(wtf[nt][ks], fd[ks & 1][mt], accA[nt][mt]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                TMARK(25);
+                {   // ---- weight gradients: reduction over the 32 tokens of the tile (one k-step) ----
+                    bf16x8 ra[4], cb[4];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) ra[a] = frag_tr(cD, 8 * g, tr0 + 16 * a);
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) cb[b] = frag_tr(cA, 8 * g, tc0 + 16 * b);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) accW1[a][b] = mfma16(ra[a], cb[b], accW1[a][b]);             // dW1[hq][k] += dZ^T LN(x)
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) ra[a] = frag_tr(cG, 8 * g, tr0 + 16 * a);
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) cb[b] = frag_tr(cH, 8 * g, tc0 + 16 * b);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) accW2[a][b] = mfma16(ra[a], cb[b], accW2[a][b]);             // dW2[c][hq] += g^T H
+                }
+            }
+            TMARK(26);
+            // tile t+1 must have landed.  In issue order this wave has, youngest first: loads(t+3) 4, stores(t-2) 4, loads(t+2) 4, stores(t-3) 4, loads(t+1) ...
+            // (every full tile stores exactly 4 times per wave; only the last tile of the last range can store less, and no wait follows it).  The first
+            // iterations have fewer stores in the sequence, so they wait for all but the two youngest load groups instead.
+            if (t >= 3) wait_async_le<16>(); else wait_async_le<8>();
+            TMARK(27);
+            if (t >= 1) {
+                const int64_t row0 = (tile0 + t - 1) * S_BM;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const int64_t row = row0 + mt * 16 + i;
+                    if (row < M) {
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) {
+                            const float v[4] = {accA[nt][mt][0], accA[nt][mt][1], accA[nt][mt][2], accA[nt][mt][3]};
+                            store4(dApart + ((int64_t)q * M + row) * 128 + ch0 + 16 * nt + 4 * g, v);
+                        }
+                    }
+                }
+            }
+            TMARK(28);
+            barrier_keep_async();
+            TMARK(29);
+        }
+        wait_async();                                    // drain the look-ahead requests before the wave retires
+        float* p1 = dW1part + (int64_t)range * 512 * 128;        // [512][128]
+        float* p2 = dW2part + (int64_t)range * 128 * 512;        // [128][512]
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rr = tr0 + 16 * a + 4 * g + r, cc = tc0 + 16 * b + i;
+                    p1[(int64_t)(q * 128 + rr) * 128 + cc] = accW1[a][b][r];
+                    p2[(int64_t)rr * 512 + q * 128 + cc] = accW2[a][b][r];
+                }
+    }
+}
+
 }  // namespace
 
 void kasf_launch_mlp_fwd_s(hipStream_t s, const void* x, const float* ln_g, const float* ln_b, const void* W1, const float* b1, const void* W2,
@@ -271,3 +528,11 @@ extern "C" void kasf_debug_read_prof(long long* dst, int reset) {
     if (reset) { long long z[32] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)); }
 }
 #endif
+
+void kasf_launch_mlp_bwd_s(hipStream_t s, const void* xn, const void* g, const void* W1, const float* b1, const void* W2ts, const void* W1t, void* dApart,
+                           float* p1, float* p2, float* db1, int64_t M, int tiles_per_range, int used) {
+    const size_t sh = (size_t)(14 * TL) * sizeof(bf16);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_bwd_s), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    hipLaunchKernelGGL(k_mlp_bwd_s, dim3(4 * used), dim3(S_THR), sh, s, (const bf16*)xn, (const bf16*)g, (const bf16*)W1, b1, (const bf16*)W2ts, (const bf16*)W1t,
+                       (bf16*)dApart, p1, p2, db1, M, tiles_per_range);
+}

@@ -65,6 +65,9 @@ void kasf_launch_mlp_fwd_r(hipStream_t s, const void* x, const float* ln_g, cons
 // producer / consumer form of the same kernel (k_mlp3.hip); kasf_launch_mlp_fwd_r forwards to it unless KASF_MLP_FWD_LOCKSTEP is set
 void kasf_launch_mlp_fwd_s(hipStream_t s, const void* x, const float* ln_g, const float* ln_b, const void* W1, const float* b1, const void* W2,
                            const float* b2, const float* ls2, void* out, int64_t M, void* xn_out, unsigned grid);
+// producer / consumer form of k_mlp_bwd_q (k_mlp3.hip): same inputs, partial-tile layout and grid mapping
+void kasf_launch_mlp_bwd_s(hipStream_t s, const void* xn, const void* g, const void* W1, const float* b1, const void* W2ts, const void* W1t, void* dApart,
+                           float* p1, float* p2, float* db1, int64_t M, int tiles_per_range, int used);
 void kasf_launch_wgrad_reduce(hipStream_t s, const float* partial, float* out, int64_t ldo, int N, int K, int splits);
 
 // ---- k_attn.hip ----

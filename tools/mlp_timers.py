@@ -13,6 +13,7 @@ w1 = (torch.randn(512, 128, device=dev) * 0.05).to(bf); w2 = (torch.randn(128, 5
 b1 = torch.zeros(512, device=dev); b2 = torch.zeros(128, device=dev); ls = torch.ones(128, device=dev); gam = torch.ones(128, device=dev); bet = torch.zeros(128, device=dev)
 p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
 st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
+bnames = {16: "P Z/dH mfma", 17: "P gelu+store", 18: "P barrier", 24: "C issue", 25: "C dA", 26: "C wgrad", 27: "C wait vmcnt", 28: "C dA stores", 29: "C barrier"}
 names = {0: "P frag+gemm1(0)", 1: "P slices", 2: "P barrier", 8: "C issue", 9: "C gemm2", 10: "C wait vmcnt", 11: "C layernorm", 12: "C epilogue", 13: "C barrier"}
 for label, xo in (("with xn store", xn), ("no xn store", None)):
     lib.kasf_op_mlp_fwd(1, p(x), p(gam), p(bet), p(w1), p(b1), p(w2), p(b2), p(ls), p(out), M, p(xo), st())
@@ -28,3 +29,18 @@ for label, xo in (("with xn store", xn), ("no xn store", None)):
     print(label, "us/launch", e0.elapsed_time(e1) * 100)
     for k, n in names.items():
         print(f"   {n:20s} {v[k] / tiles:9.0f} cycles/tile")
+
+# fused backward (k_mlp_bwd_s): same timers, indices 16..29
+g = torch.randn(M, 128, device=dev).to(bf); w2ts = (torch.randn(512, 128, device=dev) * 0.05).to(bf); w1t = w1.t().contiguous()
+dap = torch.empty(4 * M * 128, device=dev, dtype=bf); part2 = torch.empty(2 * 64 * 65536, device=dev)
+dW1 = torch.zeros(512, 128, device=dev); dW2 = torch.zeros(128, 512, device=dev); db1 = torch.zeros(512, device=dev); gs = torch.zeros(128, device=dev)
+gin = torch.empty_like(x); dg_ = torch.zeros(128, device=dev); db_ = torch.zeros(128, device=dev)
+bwd = lambda: lib.kasf_op_mlp_bwd_fused(p(x), p(xn), p(g), p(gam), p(w1), p(b1), p(w2ts), p(w1t), p(dap), p(part2), p(dW1), p(dW2), p(db1), p(gs), p(gin), p(dg_), p(db_), M, st())
+bwd(); raw.kasf_debug_read_prof(buf, 1)
+for _ in range(10): bwd()
+raw.kasf_debug_read_prof(buf, 0)
+v = list(buf)
+tiles = 10 * 58          # 3,672 tiles / 64 ranges = 57.4 per workgroup
+print("fused backward, cycles per tile (workgroup 7)")
+for k, n in bnames.items():
+    print(f"   {n:20s} {v[k] / tiles:9.0f}")
