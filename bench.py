@@ -72,14 +72,14 @@ def kernel_rooflines(M):
     fwd = lambda: lib.kasf_op_mlp_fwd(1, p(x), p(gam), p(bet), p(w1), p(b1), p(w2), p(b2), p(ls), p(out), M, p(xn), st())    # training-mode forward: also stores LN(x)
     dap = torch.empty(4 * M * 128, device=dev, dtype=bf)
     part2 = torch.empty(2 * 64 * 65536, device=dev)
-    # the engine's bf16 backward: data gradient + both weight gradients + LayerNorm backward in k_mlp_bwd_q / k_lnbwd_sum4 / k_mlp_wfinish
+    # the engine's bf16 backward: data gradient + both weight gradients + LayerNorm backward in k_mlp_bwd_s / k_lnbwd_sum4 / k_mlp_wfinish
     bwd = lambda: lib.kasf_op_mlp_bwd_fused(p(x), p(xn), p(gout), p(gam), p(w1), p(b1), p(w2ts), p(w1t), p(dap), p(part2), p(dW1), p(dW2), p(db1),
                                             p(gs), p(gin), p(dg), p(db), M, st())
     wg1 = lambda: lib.kasf_op_wgrad(1, p(dZ), 512, p(x), 128, None, None, p(dW1), p(db1), M, p(part), part.numel(), st())   # engine path: X = LN(x) emitted by k_mlp_bwd
     wg2 = lambda: lib.kasf_op_wgrad(1, p(gout), 128, p(H), 512, None, None, p(dW2), p(gs), M, p(part), part.numel(), st())
     res = {}
     # algorithmic FLOP: forward 2 GEMMs; fused backward = dgrad (2 GEMMs) + wgrad (2 GEMMs) = 2x forward (the Z recompute is not counted)
-    for name, fn, flop in (("k_mlp_fwd_s", fwd, MLP_FLOP_PER_TOKEN_FWD * M), ("k_mlp_bwd_q(+lnbwd_sum4+wfinish)", bwd, 2 * MLP_FLOP_PER_TOKEN_FWD * M),
+    for name, fn, flop in (("k_mlp_fwd_s", fwd, MLP_FLOP_PER_TOKEN_FWD * M), ("k_mlp_bwd_s(+lnbwd_sum4+wfinish)", bwd, 2 * MLP_FLOP_PER_TOKEN_FWD * M),
                            ("k_wgrad_ring[512x128]", wg1, MLP_FLOP_PER_TOKEN_FWD // 2 * M), ("k_wgrad_ring[128x512]", wg2, MLP_FLOP_PER_TOKEN_FWD // 2 * M)):
         t = time_kernel(fn)
         res[name] = {"seconds": t, "achieved_tflops": flop / t / 1e12, "algorithmic_flop": flop}
@@ -87,7 +87,7 @@ def kernel_rooflines(M):
 
 
 TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_traffic.json")
-TRAFFIC_PARTS = {"k_mlp_fwd_s": {"k_mlp_fwd_s": 1}, "k_mlp_bwd_q(+lnbwd_sum4+wfinish)": {"k_mlp_bwd_q": 1, "k_lnbwd_sum4": 1, "k_mlp_wfinish": 1}}
+TRAFFIC_PARTS = {"k_mlp_fwd_s": {"k_mlp_fwd_s": 1}, "k_mlp_bwd_s(+lnbwd_sum4+wfinish)": {"k_mlp_bwd_s": 1, "k_lnbwd_sum4": 1, "k_mlp_wfinish": 1}}
 
 
 def pmc_traffic(entry, M):
