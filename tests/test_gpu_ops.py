@@ -90,7 +90,7 @@ def _mlp_ref(x, p):
 
 
 @pytest.mark.parametrize("cd", ["fp32", "bf16"])
-@pytest.mark.parametrize("M", [459, 1000])
+@pytest.mark.parametrize("M", [459, 1000, 50001])      # 50001: six 32-token tiles per persistent workgroup + a ragged tail (ring reuse, look-ahead waits)
 def test_mlp_forward(lib, cd, M):
     from kasportsformer_amd import _lib
     p = _mlp_params()
@@ -146,9 +146,9 @@ def test_mlp_backward_and_wgrad(lib, cd):
     assert rel_err(_back(gsum), gr.sum(0)) < tol
 
 
-@pytest.mark.parametrize("M", [459, 3000])
+@pytest.mark.parametrize("M", [459, 3000, 20011])     # 20011: ten tiles per token range (steady-state ring slots and vmcnt accounting) + a ragged tail
 def test_mlp_backward_fused_bf16(lib, M):
-    """k_mlp_bwd_q + k_lnbwd_sum4 + k_wgrad_reduce (the bf16 engine path) against autograd."""
+    """k_mlp_bwd_s (or k_mlp_bwd_q under KASF_MLP_BWD_LOCKSTEP) + k_lnbwd_sum4 + k_mlp_wfinish (the bf16 engine path) against autograd."""
     from kasportsformer_amd import _lib
     cd = "bf16"
     p = _mlp_params(seed=30)
