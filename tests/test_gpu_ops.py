@@ -58,9 +58,9 @@ def _ln(x, g, b):
 
 @pytest.mark.parametrize("cd", ["fp32", "bf16"])
 @pytest.mark.parametrize("use_ln,act,N", [(True, 0, 384), (False, 0, 128), (True, 1, 512)])
-def test_linear(lib, cd, use_ln, act, N):
+@pytest.mark.parametrize("M", [300, 40003])       # 40003: five 32-token tiles per persistent workgroup (3-slot ring reuse) + a ragged tail
+def test_linear(lib, cd, use_ln, act, N, M):
     from kasportsformer_amd import _lib
-    M = 300
     a, w, bias = _rand(M, 128, seed=1), _rand(N, 128, seed=2, scale=1 / math.sqrt(128)), _rand(N, seed=3, scale=0.1)
     g, b = torch.rand(128) + 0.5, _rand(128, seed=4, scale=0.1)
     ad, wd = _dev(a, cd), _dev(w, cd)
@@ -188,7 +188,7 @@ DGRAD_CASES = [(384, False, True, False, True), (128, False, True, False, True),
 
 
 @pytest.mark.parametrize("cd", ["fp32", "bf16"])
-@pytest.mark.parametrize("M", [333, 8200])
+@pytest.mark.parametrize("M", [333, 8200, 40003])
 @pytest.mark.parametrize("Kd,use_add,use_resid,accumulate,want_xn", DGRAD_CASES)
 def test_dgrad_lnbwd(lib, cd, M, Kd, use_add, use_resid, accumulate, want_xn):
     from kasportsformer_amd import _lib
