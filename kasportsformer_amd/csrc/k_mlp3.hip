@@ -146,10 +146,6 @@ __global__ __launch_bounds__(S_THR) void k_mlp_fwd_s(const bf16* __restrict__ X,
         __builtin_amdgcn_s_setprio(3);                   // short latency-bound sections: win the issue arbitration against the producer on the same SIMD
 #endif
         bf16x8 w2f[2][16];
-#pragma unroll
-        for (int n2 = 0; n2 < 2; ++n2)
-#pragma unroll
-            for (int ks = 0; ks < 16; ++ks) w2f[n2][ks] = *reinterpret_cast<const bf16x8*>(W2 + (int64_t)(32 * c + 16 * n2 + i) * 512 + 32 * ks + 8 * g);
 
         auto issue = [&](int64_t t) {                    // two LDS-direct loads per consumer wave: rows [8c, 8c + 8) of tile t, the rows it will normalise
             const int64_t tt = t < ntiles ? t : ntiles - 1;
@@ -189,9 +185,13 @@ __global__ __launch_bounds__(S_THR) void k_mlp_fwd_s(const bf16* __restrict__ X,
                 }
             }
         };
-        issue(0);
+        issue(0);                                        // the first tiles are in flight while the weights arrive from L2
         issue(1);
-        wait_async_le<2>();
+#pragma unroll
+        for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) w2f[n2][ks] = *reinterpret_cast<const bf16x8*>(W2 + (int64_t)(32 * c + 16 * n2 + i) * 512 + 32 * ks + 8 * g);
+        wait_async();                                    // tiles 0, 1 and the weights
         layernorm(0);
         barrier_keep_async();
         TSTART();
@@ -388,10 +388,6 @@ __global__ __launch_bounds__(S_THR) void k_mlp_bwd_s(const bf16* __restrict__ XN
         // ------------------------------------------------ consumer: channels [32c, 32c + 32) of dA, a 64 x 64 block of each weight-gradient quarter ------------------------------------------------
         const int c = w - 4, ch0 = 32 * c, tr0 = 64 * (c >> 1), tc0 = 64 * (c & 1);
         bf16x8 wtf[2][4];
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) wtf[nt][ks] = *reinterpret_cast<const bf16x8*>(W1t + (int64_t)(ch0 + 16 * nt + i) * 512 + q * 128 + 32 * ks + 8 * g);
         f32x4 accW1[4][4], accW2[4][4];
         zero_acc(accW1);
         zero_acc(accW2);
@@ -412,10 +408,14 @@ __global__ __launch_bounds__(S_THR) void k_mlp_bwd_s(const bf16* __restrict__ XN
                 glds16_s(ua, off, baseA + (unsigned)inst * 1024u);
             }
         };
-        issue(0, 0);
+        issue(0, 0);                                     // the first tiles are in flight while the weights arrive from L2
         issue(1, 1);
         issue(2, 2);
-        wait_async_le<8>();                              // tile 0 has landed (tiles 1 and 2 may still be in flight)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) wtf[nt][ks] = *reinterpret_cast<const bf16x8*>(W1t + (int64_t)(ch0 + 16 * nt + i) * 512 + q * 128 + 32 * ks + 8 * g);
+        wait_async_le<16>();                             // tile 0 has landed: at most the 8 weight loads and the loads of tiles 1 and 2 are behind it
         barrier_keep_async();
         TSTART();
         int si = 3, sc = 4;                              // ring slots of tile t+3 (issued) and tile t-1 (consumed), rolling mod 5
