@@ -415,7 +415,8 @@ __global__ __launch_bounds__(S_THR) void k_mlp_bwd_s(const bf16* __restrict__ XN
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) wtf[nt][ks] = *reinterpret_cast<const bf16x8*>(W1t + (int64_t)(ch0 + 16 * nt + i) * 512 + q * 128 + 32 * ks + 8 * g);
-        wait_async_le<16>();                             // tile 0 has landed: at most the 8 weight loads and the loads of tiles 1 and 2 are behind it
+        wait_async();                                    // tiles 0..2 and the weights.  NOT a counted wait: hipcc is free to sink the (const, restrict) weight
+                                                         // loads below this point, and a count that assumes them would then let tile 0 through unfinished
         barrier_keep_async();
         TSTART();
         int si = 3, sc = 4;                              // ring slots of tile t+3 (issued) and tile t-1 (consumed), rolling mod 5

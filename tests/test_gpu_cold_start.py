@@ -1,0 +1,49 @@
+"""The very first launch of every kernel in a fresh process (code objects not loaded, caches cold, workspace memory never written) against the
+second one.  Counted-vmcnt prologues are timing-sensitive exactly there: a look-ahead tile that is consumed before it has landed shows up as
+NaN or as a difference between the first and the second identical step -- and never again once the process is warm, so the in-process tests
+cannot see it."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys, torch
+sys.path.insert(0, os.environ["KASF_ROOT"])
+import kasportsformer_amd as K
+from oracle import kasf_oracle as O
+torch.manual_seed(114514)
+m = K.KASportsFormer(n_layers=26, num_heads=8, n_frames=27, compute_dtype=os.environ["KASF_CD"]).cuda().train()
+m.attach_param_grads = False
+B = int(os.environ["KASF_B"])
+x, y = (t.cuda() for t in O.synthetic_clips(B, 27, seed=5))
+torch.empty(3 << 28, dtype=torch.float32, device="cuda").fill_(float("nan"))      # whatever the allocator hands out next has NaN in it
+torch.cuda.synchronize()
+grads, losses = [], []
+for rep in range(2):
+    if m.flat_grad is not None:
+        m.flat_grad.zero_()
+    loss, _ = K.loss3(m(x), y)
+    loss.backward()
+    torch.cuda.synchronize()
+    grads.append(m.flat_grad[:m.n_live].clone()); losses.append(float(loss))
+g0, g1 = grads
+assert torch.isfinite(g0).all(), f"first step: {int((~torch.isfinite(g0)).sum())} non-finite gradient entries"
+scale = float(g1.abs().max())
+diff = float((g0 - g1).abs().max())
+print("cold vs warm: max |dg| / |g|max =", diff / scale, " losses", losses)
+assert diff <= 2e-5 * scale, (diff, scale)          # run-to-run noise of the fp32 atomics is ~1e-6 of the scale
+'''
+
+
+@pytest.mark.parametrize("cd,B", [("bf16", 64), ("fp32", 8)])
+def test_first_step_in_a_fresh_process_equals_the_second(cd, B, tmp_path):
+    script = tmp_path / "cold.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, KASF_ROOT=ROOT, KASF_CD=cd, KASF_B=str(B))
+    out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]

@@ -7,11 +7,11 @@ m = K.KASportsFormer(n_layers=26, num_heads=8, n_frames=27, compute_dtype="bf16"
 m.attach_param_grads = False
 opt = K.FusedAdamW(m, lr=5e-4, weight_decay=0.01)
 x, y = (t.cuda() for t in O.synthetic_clips(64, 27, seed=5))
-for step in range(301):
+for step in range(int(os.environ.get("STEPS", "301"))):
     opt.zero_grad()
     loss, parts = K.loss3(m(x), y)
     loss.backward()
     opt.step()
-    if step % 50 == 0:
+    if step % int(os.environ.get("EVERY", "50")) == 0:
         print(step, [round(float(v), 4) for v in parts], flush=True)
 print("finite params:", bool(torch.isfinite(m._flat).all()))
