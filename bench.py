@@ -13,6 +13,7 @@ Prints ONE JSON line on rank 0.
 import argparse
 import ctypes as C
 import json
+import math
 import os
 import sys
 import time
@@ -211,6 +212,9 @@ def main():
         parts = step()
     fence()
     dt = time.perf_counter() - t0
+    # a step that produced NaN / inf is not a measurement (checked after the clock has stopped: .item() synchronises)
+    if not all(math.isfinite(float(v)) for v in parts) or not bool(torch.isfinite(model._flat[:model.n_live]).all()):
+        raise RuntimeError(f"bench: non-finite loss terms or parameters after the timed steps: {[float(v) for v in parts]}")
     if world > 1:
         tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
