@@ -3,7 +3,7 @@
 // k_mlp_fwd_r (k_mlp2.hip) gives every wave the same program: GEMM1 (32 MFMAs), GELU (~370 vector instructions), barrier, GEMM2 (32 MFMAs),
 // epilogue.  The two waves that share a SIMD belong to the same workgroup and move in lockstep between the barriers, so the matrix pipe idles
 // during GELU and the vector ALU idles during the GEMMs: measured 18.6 % MFMA busy, 42 % VALU busy, and a tile time equal to the SUM of the
-// phases plus the stalls (SQ counters in profiles/r1_mlp_sq_counters.md).  Software-pipelining the symmetric program did not help.
+// phases plus the stalls (SQ counters in profiles/r1_mlp_sq_counters.json).  Software-pipelining the symmetric program did not help.
 //
 // Here waves 0-3 (one per SIMD) are PRODUCERS: wave p keeps W1 rows [128p, 128p+128) in 128 VGPRs and does GEMM1 + GELU for its quarter of the
 // hidden units.  Waves 4-7 (again one per SIMD) are CONSUMERS: wave c keeps W2 rows [32c, 32c+32) in 128 VGPRs and does GEMM2 of the PREVIOUS
@@ -12,8 +12,9 @@
 // barrier per tile:
 //     iteration t:   producers  GEMM1(t) + GELU(t) -> sH[t & 1]        consumers  GEMM2(t-1) <- sH[(t-1) & 1], epilogue(t-1), LN(t+1) -> sA[(t+1) & 1]
 // Packed fp32 instructions (v_pk_fma_f32 ...) do not overlap with MFMAs of another wave on gfx950 (tools/valu_probe.hip: an MFMA wave and a
-// v_pk_fma_f32 wave on one SIMD take the sum of their times, an MFMA wave and a v_fma_f32 wave the maximum), so this file is compiled with
-// -fno-slp-vectorize.
+// v_pk_fma_f32 wave on one SIMD take the sum of their times, an MFMA wave and a v_fma_f32 wave the maximum), but one wave issues at most one
+// vector instruction per ~5.3 cycles whatever it is, so the producers' GELU is written in packed form anyway (half the instructions; building this
+// file with and without -fno-slp-vectorize measured the same, the explicit packed GELU 6 % faster than either).
 // LDS: sA 2 x 8 KB, sH 2 x 32 KB, raw x ring 4 x 8 KB (tiles t-1, t, t+1 in use, t+2 in flight), parameters 4 KB.
 #include "common.h"
 #include "kernels.h"
