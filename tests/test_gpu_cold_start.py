@@ -47,3 +47,28 @@ def test_first_step_in_a_fresh_process_equals_the_second(cd, B, tmp_path):
     env = dict(os.environ, KASF_ROOT=ROOT, KASF_CD=cd, KASF_B=str(B))
     out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+def test_short_full_depth_training_run_stays_finite_and_learns():
+    """Sixty AdamW steps of the 26-layer bf16 model on one batch: every loss term finite, parameters finite, loss lower than at the start
+    (a NaN anywhere in the 156-block backward poisons all of this within a step or two)."""
+    import torch
+    import kasportsformer_amd as K
+    from oracle import kasf_oracle as O
+    torch.manual_seed(114514)
+    m = K.KASportsFormer(n_layers=26, num_heads=8, n_frames=27, compute_dtype="bf16").cuda().train()
+    m.attach_param_grads = False
+    opt = K.FusedAdamW(m, lr=5e-4, weight_decay=0.01)
+    x, y = (t.cuda() for t in O.synthetic_clips(64, 27, seed=5))
+    first = last = None
+    for step in range(60):
+        opt.zero_grad()
+        loss, parts = K.loss3(m(x), y)
+        loss.backward()
+        opt.step()
+        vals = [float(v) for v in parts]
+        assert all(v == v and abs(v) < 1e6 for v in vals), (step, vals)
+        first = vals[0] if first is None else first
+        last = vals[0]
+    assert bool(torch.isfinite(m._flat).all())
+    assert last < first, (first, last)
