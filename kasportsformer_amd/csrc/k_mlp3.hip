@@ -86,9 +86,9 @@ __global__ __launch_bounds__(S_THR) void k_mlp_fwd_s(const bf16* __restrict__ X,
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) { fa[ks][0] = tok_frag(cA, i, ks); fa[ks][1] = tok_frag(cA, 16 + i, ks); }
                 f32x4 acc[2][2];
-                auto gemm1 = [&](f32x4 (&a)[2], int nt) {
-                    a[0] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    a[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                auto gemm1 = [&](f32x4 (&a)[2], int nt) {      // accumulators start from the bias (the lane's 4 rows = 4 hidden units): no add afterwards
+                    a[0] = b1v[nt];
+                    a[1] = b1v[nt];
 #pragma unroll
 #ifdef KASF_PROBE_NO_MFMA1
                     for (int ks = 0; ks < 1; ++ks) {
@@ -105,12 +105,11 @@ __global__ __launch_bounds__(S_THR) void k_mlp_fwd_s(const bf16* __restrict__ X,
                 auto slice = [&](auto NT) {              // MFMAs of slice nt+1 spread over the GELU of slice nt
                     constexpr int nt = decltype(NT)::value;
                     if (nt < 7) gemm1(acc[(nt + 1) & 1], nt + 1);
-                    const f32x4 bv = b1v[nt];
                     f32x2 y[4];
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt) {
-                        y[2 * mt] = f32x2{acc[nt & 1][mt][0] + bv[0], acc[nt & 1][mt][1] + bv[1]};
-                        y[2 * mt + 1] = f32x2{acc[nt & 1][mt][2] + bv[2], acc[nt & 1][mt][3] + bv[3]};
+                        y[2 * mt] = f32x2{acc[nt & 1][mt][0], acc[nt & 1][mt][1]};
+                        y[2 * mt + 1] = f32x2{acc[nt & 1][mt][2], acc[nt & 1][mt][3]};
                     }
                     gelu_pairs_fast(y);
 #pragma unroll
@@ -203,7 +202,7 @@ __global__ __launch_bounds__(S_THR) void k_mlp_fwd_s(const bf16* __restrict__ X,
             if (t >= 1) {                                // GEMM2 of tile t-1 over all 512 hidden units
                 const bf16* cH = sH + (int)((t - 1) & 1) * 4 * TL;
 #pragma unroll
-                for (int n2 = 0; n2 < 2; ++n2) { acc2[n2][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[n2][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                for (int n2 = 0; n2 < 2; ++n2) acc2[n2][0] = acc2[n2][1] = *reinterpret_cast<const f32x4*>(sPar + 512 + 32 * c + 16 * n2 + 4 * g);   // starts from b2
                 bf16x8 fh[3][2];                          // fragment ring, two k-steps ahead: LDS latency under load exceeds the 64 cycles of one step's MFMAs
                 auto frag = [&](int ks, int slot) {
                     const bf16* hT = cH + (ks >> 2) * TL;
@@ -234,7 +233,7 @@ __global__ __launch_bounds__(S_THR) void k_mlp_fwd_s(const bf16* __restrict__ X,
 #pragma unroll
                 for (int n2 = 0; n2 < 2; ++n2) {
                     const int col = 32 * c + 16 * n2 + 4 * g;
-                    const f32x4 b2v = *reinterpret_cast<const f32x4*>(sPar + 512 + col), lsv = *reinterpret_cast<const f32x4*>(sPar + 640 + col);
+                    const f32x4 lsv = *reinterpret_cast<const f32x4*>(sPar + 640 + col);
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt) {
                         const int64_t row = row0 + mt * 16 + i;
@@ -242,7 +241,7 @@ __global__ __launch_bounds__(S_THR) void k_mlp_fwd_s(const bf16* __restrict__ X,
                             float x[4], y[4];
                             load4(cX + Tile<bf16>::off4(mt * 16 + i, col), x);      // residual from the raw tile still in LDS
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) y[r] = x[r] + lsv[r] * (acc2[n2][mt][r] + b2v[r]);
+                            for (int r = 0; r < 4; ++r) y[r] = x[r] + lsv[r] * acc2[n2][mt][r];
                             store4(out + row * 128 + col, y);
                         }
                     }
@@ -323,7 +322,8 @@ __global__ __launch_bounds__(S_THR) void k_mlp_bwd_s(const bf16* __restrict__ XN
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt) { fa[ks][mt] = tok_frag(cA, mt * 16 + i, ks); fg[ks][mt] = tok_frag(cG, mt * 16 + i, ks); }
                 f32x4 accZ[2][2], accH[2][2];
-                zero_acc(accZ);
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) { accZ[nt][0] = bias4[nt]; accZ[nt][1] = bias4[nt]; }      // Z accumulates on top of the bias
                 zero_acc(accH);
                 auto gemm = [&](int nt) {
 #pragma unroll
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(S_THR) void k_mlp_bwd_s(const bf16* __restrict__ XN
                     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                         for (int hp = 0; hp < 2; ++hp)
-                            z[2 * mt + hp] = f32x2{accZ[nt][mt][2 * hp] + bias4[nt][2 * hp], accZ[nt][mt][2 * hp + 1] + bias4[nt][2 * hp + 1]};
+                            z[2 * mt + hp] = f32x2{accZ[nt][mt][2 * hp], accZ[nt][mt][2 * hp + 1]};
                     gelu_grad_pairs_fast(z, dg);
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt) {
