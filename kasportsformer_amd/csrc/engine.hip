@@ -260,11 +260,11 @@ void build_plan(const kasf_model* m, int B, bool train, bool names, Plan& p) {
     p.layers.resize(nl);
     p.stats_begin = cur;
     for (int l = 0; l < nl; ++l)
-        for (int b = 2; b < 4; ++b) p.layers[l].b[b].stats = take(96 * 2, 2, "bn_stats", l, b);
+        for (int b = 2; b < 4; ++b) p.layers[l].b[b].stats = take((int64_t)KASF_STAT_LD * KASF_STAT_SLOTS, 2, "bn_stats", l, b);
     p.stats_bytes = cur - p.stats_begin;
     p.bstats_begin = cur;
     for (int l = 0; l < nl; ++l)
-        for (int b = 2; b < 4; ++b) p.layers[l].b[b].bstats = take(96 * 2, 2, "bn_bwd_stats", l, b);
+        for (int b = 2; b < 4; ++b) p.layers[l].b[b].bstats = take((int64_t)KASF_STAT_LD * KASF_STAT_SLOTS, 2, "bn_bwd_stats", l, b);
     p.bstats_bytes = cur - p.bstats_begin;
     p.x3 = take(M * 3, 1, "x_input");
     p.bone3 = take(M * 3, 1, "bone3");

@@ -20,6 +20,17 @@ constexpr int COEF_LD = 8;      // per node: scale, shift, mean, rstd, c1, c2, -
 constexpr int MASK_W = 3;       // 32-bit words per adjacency row (T <= 96)
 constexpr int SX_LD = 132;      // padded fp32 row of the temporal tiles
 
+// Batch statistics are accumulated in KASF_STAT_SLOTS copies ([slot][96 nodes][2] doubles, slot = workgroup index mod slots): a thousand
+// workgroups each ending in fp64 atomics on the same 34..162 addresses serialise at the memory side (44 us for the spatial aggregate with one
+// copy, 24 us without the atomics); readers add the copies up.
+__device__ __forceinline__ double stat_sum(const double* stats, int idx) {
+    double v = 0.0;
+#pragma unroll
+    for (int sl = 0; sl < KASF_STAT_SLOTS; ++sl) v += stats[sl * KASF_STAT_LD + idx];
+    return v;
+}
+__device__ __forceinline__ double* stat_slot(double* stats) { return stats + (blockIdx.x % KASF_STAT_SLOTS) * KASF_STAT_LD; }
+
 __device__ __forceinline__ int node_of(int64_t tok, int T, int mode) { return mode == 0 ? (int)(tok % KASF_J) : (int)((tok / KASF_J) % T); }
 
 // ------------------------------------------------------------------ spatial aggregate (elementwise + 4-neighbour gather)
@@ -54,7 +65,7 @@ __global__ __launch_bounds__(256) void k_gcn_agg_spatial(const T* __restrict__ u
         if (sub == 0) { atomicAdd(&sStat[i * 2], s1); atomicAdd(&sStat[i * 2 + 1], s2); }
     }
     __syncthreads();
-    if (threadIdx.x < KASF_J * 2) atomicAdd(stats + threadIdx.x, (double)sStat[threadIdx.x]);
+    if (threadIdx.x < KASF_J * 2) atomicAdd(stat_slot(stats) + threadIdx.x, (double)sStat[threadIdx.x]);
 }
 
 // ------------------------------------------------------------------ temporal aggregate: persistent workgroups, one (b, joint) track at a time
@@ -158,7 +169,7 @@ __global__ __launch_bounds__(256) void k_gcn_agg_temporal(const T* __restrict__ 
         }
     }
     __syncthreads();
-    if (threadIdx.x < 2 * L) atomicAdd(stats + threadIdx.x, (double)sStat[threadIdx.x]);
+    if (threadIdx.x < 2 * L) atomicAdd(stat_slot(stats) + threadIdx.x, (double)sStat[threadIdx.x]);
 }
 
 // ------------------------------------------------------------------ BatchNorm1d(num_nodes) + ReLU + layer-scale + residual
@@ -167,8 +178,8 @@ __device__ __forceinline__ void bn_node_coef(const double* stats, const float* w
                                              double count, int training, float& scale, float& shift, float& mean, float& rstd, float& var_unbiased) {
     float var;
     if (training) {
-        const double m = stats[2 * n] / count;
-        double v = stats[2 * n + 1] / count - m * m;
+        const double m = stat_sum(stats, 2 * n) / count;
+        double v = stat_sum(stats, 2 * n + 1) / count - m * m;
         if (v < 0) v = 0;
         mean = (float)m;
         var = (float)v;
@@ -273,7 +284,7 @@ __global__ __launch_bounds__(256) void k_gcn_bwd1(const T* __restrict__ g, const
         for (int k = 0; k < 16; ++k) s += sRed[k * 128 + threadIdx.x];
         atomicAdd(dls1 + threadIdx.x, s);
     }
-    if (threadIdx.x < 2 * nodes) atomicAdd(bstats + threadIdx.x, (double)sStat[threadIdx.x]);
+    if (threadIdx.x < 2 * nodes) atomicAdd(stat_slot(bstats) + threadIdx.x, (double)sStat[threadIdx.x]);
 }
 
 // dy of one 8-channel chunk: BN backward with the finalised per-node means
@@ -297,11 +308,12 @@ __device__ __forceinline__ void bwd2_prologue(float* sC, const float* coef, cons
         sC[n * C2_LD + 0] = coef[n * COEF_LD];
         sC[n * C2_LD + 1] = coef[n * COEF_LD + 2];
         sC[n * C2_LD + 2] = coef[n * COEF_LD + 3];
-        sC[n * C2_LD + 3] = (float)(bstats[2 * n] / count);
-        sC[n * C2_LD + 4] = (float)(bstats[2 * n + 1] / count);
+        const double s0 = stat_sum(bstats, 2 * n), s1 = stat_sum(bstats, 2 * n + 1);
+        sC[n * C2_LD + 3] = (float)(s0 / count);
+        sC[n * C2_LD + 4] = (float)(s1 / count);
         if (blockIdx.x == 0) {
-            d_b[n] += (float)bstats[2 * n];
-            d_w[n] += (float)bstats[2 * n + 1];
+            d_b[n] += (float)s0;
+            d_w[n] += (float)s1;
         }
     }
     __syncthreads();
