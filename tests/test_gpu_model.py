@@ -123,6 +123,35 @@ def test_backward_matches_oracle(cd, tol, L, T, B):
     assert not bad, f"{len(bad)} gradients above {tol}; worst (err, name, |g|max/gmax): {bad[:12]}"
 
 
+@pytest.mark.parametrize("cd,tol", [("fp32", 2e-3), ("bf16", 0.35)])
+def test_detected_keypoints_confidence_channel(cd, tol):
+    """SURVEY config 3 ("WorldPose-det"): the third input channel is a detector confidence ~U(0,1) instead of the constant 1 of ground-truth 2-D
+    input, so the confidence-channel limb MLPs and the third embedding column see real data: forward and every gradient against the oracle."""
+    oracle, model = make_pair(2, 27, cd)
+    x, y = O.synthetic_clips(3, 27, seed=77, res=(1920, 1080), det_conf=True)
+    oracle.train()
+    loss_ref, _ = O.loss_total(oracle(x), y)
+    loss_ref.backward()
+    model.train()
+    pred = model(x.cuda())
+    loss, _ = O.loss_total(pred, y.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - loss_ref.item()) < (1e-4 if cd == "fp32" else 5e-2) * max(1.0, abs(loss_ref.item()))
+    ref_grads = dict(oracle.named_parameters())
+    gmax = max(float(q.grad.abs().max()) for q in ref_grads.values() if q.grad is not None)
+    bad = []
+    for n, p in model.named_parameters():
+        r = ref_grads[n].grad
+        assert (r is None) == (p.grad is None), n
+        if r is None:
+            continue
+        err = float((p.grad.detach().double().cpu() - r.double()).abs().max() / max(float(r.abs().max()), (1e-3 if cd == "fp32" else 0.05) * gmax))
+        if not err < tol:
+            bad.append((err, n))
+    assert not bad, sorted(bad, reverse=True)[:10]
+
+
 def test_fp32_backward_matches_reference_golden():
     fx = np.load(os.path.join(GOLDEN, "model_L2_T27_B2.npz"))
     _, model = make_pair(2, 27, "fp32")
