@@ -152,6 +152,53 @@ def test_detected_keypoints_confidence_channel(cd, tol):
     assert not bad, sorted(bad, reverse=True)[:10]
 
 
+def test_zero_length_bones_and_static_clip():
+    """Two inputs the reference handles by special cases.  (1) Coincident joints: zero-length bones get length 1 and direction 0
+    (KASportsFormer.py:51) -- forward and backward against the oracle.  (2) A static clip (every frame the same): all temporal similarities tie
+    exactly, `topk` + `ge` keeps every neighbour (graph.py:109-111); whatever the reference's BLAS does with the ties, the result must be finite
+    and the same for every frame, because nothing in the model distinguishes frames but their content."""
+    oracle, model = make_pair(1, 27, "fp32")
+    x, y = O.synthetic_clips(2, 27, seed=11)
+    x[:, :, 1, :2] = x[:, :, 0, :2]            # bone 0-1 has zero length in every frame
+    x[0, 5, 9, :2] = x[0, 5, 8, :2]            # and one more in a single frame
+    oracle.train()
+    ref = oracle(x)
+    l_ref, _ = O.loss_total(ref, y)
+    l_ref.backward()
+    model.train()
+    pred = model(x.cuda())
+    loss, _ = O.loss_total(pred, y.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    assert torch.isfinite(pred).all()
+    assert float((pred.cpu() - ref).abs().max()) < 1e-3
+    ref_grads = dict(oracle.named_parameters())
+    gmax = max(float(q.grad.abs().max()) for q in ref_grads.values() if q.grad is not None)
+    for n, p in model.named_parameters():
+        r = ref_grads[n].grad
+        if r is not None:
+            assert float((p.grad.cpu() - r).abs().max()) < 2e-3 * max(float(r.abs().max()), 1e-3 * gmax), n
+    import kasportsformer_amd as K
+    for cd in ("fp32", "bf16"):
+        # default initialisation (BatchNorm1d(T) carries per-FRAME affine parameters: random ones would tell the frames apart), layer scales raised
+        # from 1e-5 to 1 so that the mixers actually contribute
+        torch.manual_seed(5)
+        m2 = K.KASportsFormer(n_layers=2, num_heads=8, n_frames=27, compute_dtype=cd)
+        sd = m2.state_dict()
+        for k in sd:
+            if "layer_scale" in k:
+                sd[k] = torch.ones_like(sd[k])
+        m2.load_state_dict(sd)
+        m2 = m2.cuda().eval()
+        frame = O.synthetic_clips(3, 1, seed=12)[0]
+        static = frame.expand(3, 27, 17, 3).contiguous().cuda()
+        with torch.no_grad():
+            out = m2(static)
+        assert torch.isfinite(out).all()
+        spread = float((out - out[:, :1]).abs().max())
+        assert spread <= (1e-5 if cd == "fp32" else 2e-2) * max(1.0, float(out.abs().max())), (cd, spread)
+
+
 def test_fp32_backward_matches_reference_golden():
     fx = np.load(os.path.join(GOLDEN, "model_L2_T27_B2.npz"))
     _, model = make_pair(2, 27, "fp32")
