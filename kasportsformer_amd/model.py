@@ -306,6 +306,8 @@ class KASportsFormer(nn.Module):
         """x [B, T, 17, 3] float32 on the GPU -> [B, T, 17, 3] (or the [B, T, 17, 512] tanh features).
         Returns a fresh writable tensor and never modifies x (train_and_evaluate_sp.py:55 mutates the output)."""
         self._check_input(x)
+        if x.shape[0] == 0:        # the reference returns an empty result in both modes (checked against it); no kernel can be launched on zero clips
+            return x.new_empty((0, self.n_frames, 17, 512 if return_rep else 3))
         if self.training and torch.is_grad_enabled() and self.pos_embed.requires_grad:
             if return_rep:
                 raise NotImplementedError("gradients through return_rep=True are not built")

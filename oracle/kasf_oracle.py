@@ -80,8 +80,8 @@ def bone_decompose(x: torch.Tensor) -> torch.Tensor:
 
 def _heads(t: torch.Tensor, n: int, H: int):
     """[B,T,J,n*C] -> n tensors [B,H,T,J,d] (selfattention.py:47-49)."""
-    B, T, J, _ = t.shape
-    t = t.reshape(B, T, J, n, H, -1).permute(3, 0, 4, 1, 2, 5)
+    B, T, J, W = t.shape
+    t = t.reshape(B, T, J, n, H, W // (n * H)).permute(3, 0, 4, 1, 2, 5)      # explicit head width, as the reference writes it: also valid for B = 0
     return [t[i] for i in range(n)]
 
 

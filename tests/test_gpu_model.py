@@ -199,6 +199,18 @@ def test_zero_length_bones_and_static_clip():
         assert spread <= (1e-5 if cd == "fp32" else 2e-2) * max(1.0, float(out.abs().max())), (cd, spread)
 
 
+def test_empty_batch():
+    """B = 0: an empty result in both modes, as the reference returns (no kernel runs on zero clips)."""
+    _, model = make_pair(1, 27, "bf16")
+    x = torch.empty(0, 27, 17, 3, device="cuda")
+    for mode in (model.eval, model.train):
+        mode()
+        with torch.no_grad():
+            assert tuple(model(x).shape) == (0, 27, 17, 3)
+            assert tuple(model(x, return_rep=True).shape) == (0, 27, 17, 512)
+    assert tuple(model(x).shape) == (0, 27, 17, 3)          # training mode with autograd enabled
+
+
 def test_fp32_backward_matches_reference_golden():
     fx = np.load(os.path.join(GOLDEN, "model_L2_T27_B2.npz"))
     _, model = make_pair(2, 27, "fp32")
