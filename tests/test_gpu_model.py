@@ -211,6 +211,32 @@ def test_empty_batch():
     assert tuple(model(x).shape) == (0, 27, 17, 3)          # training mode with autograd enabled
 
 
+def test_large_batches():
+    """SURVEY config 5's global batch on one GPU (B = 2048, T = 27, 26 layers, bf16: 940k tokens, 29k token tiles): finite, and every clip's
+    evaluation output bit-identical to what the same clip gives inside a batch of 256 (no index arithmetic wraps, no tile is skipped);
+    one training step at B = 512 (twice the benchmark batch) stays finite."""
+    import kasportsformer_amd as K
+    torch.manual_seed(3)
+    m = K.KASportsFormer(n_layers=26, num_heads=8, n_frames=27, compute_dtype="bf16").cuda().eval()
+    x = O.synthetic_clips(2048, 27, seed=21)[0].cuda()
+    with torch.no_grad():
+        big = m(x)
+        assert torch.isfinite(big).all()
+        for lo in (0, 1024, 1792):
+            assert torch.equal(big[lo:lo + 256], m(x[lo:lo + 256])), lo
+    del big
+    m.train()
+    m.attach_param_grads = False
+    opt = K.FusedAdamW(m, lr=5e-4, weight_decay=0.01)
+    xb, yb = (t.cuda() for t in O.synthetic_clips(512, 27, seed=22))
+    opt.zero_grad()
+    loss, parts = K.loss3(m(xb), yb)
+    loss.backward()
+    opt.step()
+    torch.cuda.synchronize()
+    assert all(float(v) == float(v) for v in parts) and bool(torch.isfinite(m._flat).all()) and bool(torch.isfinite(m.flat_grad[:m.n_live]).all())
+
+
 def test_fp32_backward_matches_reference_golden():
     fx = np.load(os.path.join(GOLDEN, "model_L2_T27_B2.npz"))
     _, model = make_pair(2, 27, "fp32")
