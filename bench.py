@@ -165,7 +165,6 @@ def main():
             os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     import kasportsformer_amd as K
-    from oracle import kasf_oracle as O      # synthetic input generator only (checker-side data recipe)
 
     torch.manual_seed(114514)                # configs/*.yaml:17
     model = K.KASportsFormer(n_layers=LAYERS, num_heads=8, n_frames=T, compute_dtype="bf16").cuda().train()
@@ -173,12 +172,11 @@ def main():
     opt = K.FusedAdamW(model, lr=5e-4, weight_decay=0.01)
     dp = None
     if world > 1 or args.force_dp:
-        dp = K.DataParallel(model, overlap=os.environ.get("KASF_DP_OVERLAP", "1") != "0")
-        opt.grad_scale = 1.0 / world
+        dp = K.DataParallel(model, overlap=os.environ.get("KASF_DP_OVERLAP", "1") != "0", optimizer=opt)     # sets opt.grad_scale = 1 / world
         if os.environ.get("KASF_DP_SKIP_ALLREDUCE") == "1":          # diagnosis only: process group alive, no collective in the step
             model.grad_stage_hook = None
-            dp.finish_gradients = lambda: None
-    x, y = O.synthetic_clips(args.batch, T, seed=1234 + rank)
+            dp.finish_gradients = lambda *a: None
+    x, y = K.synthetic_clips(args.batch, T, seed=1234 + rank)
     x, y = x.cuda(), y.cuda()
 
     def step():

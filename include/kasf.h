@@ -36,6 +36,7 @@ extern "C" {
 
 #define KASF_FLAG_TRAIN 1       /* BatchNorm batch statistics + running-stat update; keep activations for backward */
 #define KASF_FLAG_RETURN_REP 2  /* out is the [B,T,17,512] tanh representation (forward(x, return_rep=True)) */
+#define KASF_FLAG_KEEP 4        /* keep activations for kasf_backward WITHOUT batch statistics: autograd through model.eval() (BatchNorm on running stats) */
 
 typedef struct kasf_model kasf_model;
 
@@ -78,12 +79,14 @@ int64_t kasf_workspace_bytes(const kasf_model* m, int32_t batch, int32_t flags);
 int kasf_forward(const kasf_model* m, const float* params, const void* packed, float* buffers, const float* x, float* out, void* workspace,
                  int64_t workspace_bytes, int32_t batch, int32_t flags, void* stream);
 
-/* Gradients of a preceding kasf_forward(KASF_FLAG_TRAIN) on the same workspace.  dout [B,T,17,3] fp32.
+/* Gradients of a preceding kasf_forward(KASF_FLAG_TRAIN or KASF_FLAG_KEEP) on the same workspace; `flags` = the forward's flags:
+ * KASF_FLAG_TRAIN selects the batch-statistics BatchNorm backward (otherwise running statistics are constants), KASF_FLAG_RETURN_REP means
+ * dout is the gradient of the [B,T,17,512] representation (otherwise dout [B,T,17,3] fp32).
  * Accumulates (+=) into grads[0, live); the caller zeroes it.  Stages [stage_begin, stage_end) of
  * kasf_backward_stages() are run; call with (0, stages) for the whole backward, or stage by stage to
  * overlap the gradient all-reduce of finished ranges. */
 int kasf_backward(const kasf_model* m, const float* params, const void* packed, const float* dout, float* grads, void* workspace,
-                  int64_t workspace_bytes, int32_t batch, int32_t stage_begin, int32_t stage_end, void* stream);
+                  int64_t workspace_bytes, int32_t batch, int32_t flags, int32_t stage_begin, int32_t stage_end, void* stream);
 
 /* losses[4] = {total, mpjpe, n_mpjpe, velocity}; dpred = grad_scale * dTotal/dpred */
 int kasf_loss3(const float* pred, const float* target, float* dpred, float* losses, int32_t batch, int32_t n_frames, float lambda_n_mpjpe,

@@ -12,8 +12,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libkasf_hip.so")
 
 DTYPE_F32, DTYPE_BF16 = 0, 1
-FLAG_TRAIN, FLAG_RETURN_REP = 1, 2
+FLAG_TRAIN, FLAG_RETURN_REP, FLAG_KEEP = 1, 2, 4
 EVAL_COLS = 22
+ABI_VERSION = 2          # kasf_version() of the library these prototypes describe (a stale in-tree .so is refused)
 
 
 class KasfConfig(C.Structure):
@@ -47,7 +48,7 @@ SIGNATURES = {
     "kasf_pack_weights": (_i32, [_vp, _vp, _vp, _vp]),
     "kasf_workspace_bytes": (_i64, [_vp, _i32, _i32]),
     "kasf_forward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
-    "kasf_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
+    "kasf_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
     "kasf_loss3": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _f32, _f32, _vp]),
     "kasf_adamw_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _vp]),
     "kasf_gather_clips": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
@@ -86,6 +87,8 @@ def load():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    if lib.kasf_version() != ABI_VERSION:
+        raise KasfError(f"{LIB_PATH} is version {lib.kasf_version()}, the host code expects {ABI_VERSION}: rebuild it (make -C kasportsformer_amd/csrc)")
     _lib = lib
     return lib
 

@@ -74,13 +74,32 @@ def load_adamw_state_dict(optimizer, sd: dict):
     pg.update(lr=float(group["lr"]), betas=tuple(group["betas"]), eps=float(group["eps"]), weight_decay=float(group["weight_decay"]))
 
 
-def checkpoint_save(checkpoint_path, epoch, lr, optimizer, model, min_mpjpe, wandb_id, module_prefix: bool = True):
+def _load_file(path):
+    """``torch.load(weights_only=True)`` that also accepts what the reference's loop pickles next to the tensors: ``min_mpjpe`` is the
+    ``np.float64`` that ``np.mean`` returned (train_and_evaluate_sp.py:350-351), i.e. ``numpy.core.multiarray.scalar`` + a dtype object."""
+    import numpy as np
+    allow = [np.dtype, np.float64, np.float32, np.int64, type(np.dtype(np.float64)), type(np.dtype(np.float32)), type(np.dtype(np.int64))]
+    for mod in ("numpy._core.multiarray", "numpy.core.multiarray"):
+        try:
+            allow.append(getattr(__import__(mod, fromlist=["scalar"]), "scalar"))
+        except (ImportError, AttributeError):
+            pass
+    with torch.serialization.safe_globals(allow):
+        return torch.load(path, map_location="cpu", weights_only=True)
+
+
+def checkpoint_save(checkpoint_path, epoch, lr, optimizer, model, min_mpjpe, wandb_id, module_prefix: bool = True, data_parallel=None):
     """utils/utilities.py:110-118, same argument order.  ``module_prefix=True`` writes the keys the reference's DataParallel-wrapped
-    ``load_state_dict(strict=True)`` expects."""
+    ``load_state_dict(strict=True)`` expects.  With ``data_parallel`` (every rank must call): rank 0's BatchNorm buffers are broadcast first
+    -- ``nn.DataParallel`` keeps replica 0's running statistics (train_and_evaluate_sp.py:262-264) -- and only rank 0 writes the file."""
+    if data_parallel is not None:
+        data_parallel.sync_buffers_from_rank0()
+        if data_parallel.rank != 0:
+            return
     msd = {((PREFIX + k) if module_prefix else k): v.detach().cpu().clone() for k, v in model.state_dict().items()}
     tmp = str(checkpoint_path) + ".tmp"
     torch.save({"epoch": epoch + 1, "learning_rate": lr, "optimizer": adamw_state_dict(optimizer) if optimizer is not None else None, "model": msd,
-                "min_mpjpe": min_mpjpe, "wandb_id": wandb_id}, tmp)
+                "min_mpjpe": float(min_mpjpe), "wandb_id": wandb_id}, tmp)
     os.replace(tmp, checkpoint_path)
 
 
@@ -89,7 +108,7 @@ def checkpoint_load(checkpoint_path, model, optimizer=None, resume: bool = False
     the keys are prefixed; with ``resume`` also restores the optimiser and returns ``epoch`` / ``lr`` / ``min_mpjpe`` / ``wandb_run_id``."""
     if not os.path.exists(checkpoint_path):
         raise Exception("checkpoint path is wrong, check your configuration")          # sp:300-301
-    ck = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
+    ck = _load_file(checkpoint_path)
     model.load_state_dict(strip_module_prefix(ck["model"]), strict=True)
     info = {"epoch": 0, "lr": None, "min_mpjpe": float("inf"), "wandb_run_id": None}
     if resume:

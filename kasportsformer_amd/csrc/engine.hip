@@ -336,7 +336,8 @@ struct Ctx {
     hipStream_t s;
     int B, T, dt, es;
     int64_t M;
-    bool train;
+    bool train;              // activations are kept for a backward pass
+    bool bn_train;           // BatchNorm uses batch statistics and updates the running ones (KASF_FLAG_TRAIN)
     const void* pk(int64_t elem_off) const { return A + elem_off * es; }
     void* w(int64_t byte_off) const { return ws + byte_off; }
 };
@@ -368,7 +369,7 @@ void block_forward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void* 
                                 c.T, o.mode);
         const double count = o.mode == 0 ? (double)c.B * c.T * 128 : (double)c.B * 17 * 128;
         kasf_launch_gcn_apply(c.dt, c.s, x_in, c.w(w.xn), c.w(w.y), (const double*)c.w(w.stats), P + o.bn_w, P + o.bn_b, c.buf + o.bn_rm, c.buf + o.bn_rv,
-                              (float*)c.w(w.coef), P + o.ls1, c.w(w.x_mid), c.B, c.T, o.mode, count, c.train ? 1 : 0, 0.1f);
+                              (float*)c.w(w.coef), P + o.ls1, c.w(w.x_mid), c.B, c.T, o.mode, count, c.bn_train ? 1 : 0, 0.1f);
     }
     if (o.kind != KIND_GRAPH && !mixer_done)
         kasf_launch_linear_res(c.dt, c.s, c.w(w.o), c.pk(o.p_proj), P + o.proj_b, P + o.ls1, x_in, c.w(w.x_mid), c.M);
@@ -403,7 +404,7 @@ void block_backward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void*
                              c.B, c.T, o.mode);
         const double count = o.mode == 0 ? (double)c.B * c.T * 128 : (double)c.B * 17 * 128;
         kasf_launch_gcn_bwd2(c.dt, c.s, c.w(sc.rbuf), c.w(w.y), (const float*)c.w(w.coef), w.mask >= 0 ? (const uint32_t*)c.w(w.mask) : nullptr, c.w(sc.duv),
-                             c.B, c.T, o.mode, (const double*)c.w(w.bstats), G + o.bn_w, G + o.bn_b, count);
+                             c.B, c.T, o.mode, (const double*)c.w(w.bstats), G + o.bn_w, G + o.bn_b, count, c.bn_train ? 1 : 0);
         kasf_launch_dgrad_lnbwd(c.dt, c.s, c.w(sc.duv), 256, c.pk(o.p_mixT), c.w(sc.rbuf), x_in, P + o.n1w, g_mid, dst, accumulate, G + o.n1w, G + o.n1b,
                                 c.M);
         kasf_launch_wgrad(c.dt, c.s, c.w(sc.duv), 256, 256, c.w(w.xn), 128, 128, nullptr, nullptr, G + o.mix_w, 128, G + o.uv_b, c.M, (float*)c.w(sc.wg_part), WG_PARTIAL_FLOATS);
@@ -488,7 +489,7 @@ int check_model(const kasf_model* m) {
 extern "C" {
 
 const char* kasf_last_error(void) { return g_err.c_str(); }
-int kasf_version(void) { return 1; }
+int kasf_version(void) { return 2; }
 
 int kasf_model_create(const kasf_config* cfg, kasf_model** out) {
     if (cfg == nullptr || out == nullptr) return kasf_set_error(2, "null argument");
@@ -586,20 +587,20 @@ int kasf_pack_weights(const kasf_model* m, const float* params, void* packed, vo
 int64_t kasf_workspace_bytes(const kasf_model* m, int32_t batch, int32_t flags) {
     if (m == nullptr || batch < 1) return 0;
     Plan p;
-    build_plan(m, batch, (flags & KASF_FLAG_TRAIN) != 0, false, p);
+    build_plan(m, batch, (flags & (KASF_FLAG_TRAIN | KASF_FLAG_KEEP)) != 0, false, p);
     return p.total;
 }
 int32_t kasf_ws_entries(const kasf_model* m, int32_t batch, int32_t flags) {
     if (m == nullptr || batch < 1) return 0;
     Plan p;
-    build_plan(m, batch, (flags & KASF_FLAG_TRAIN) != 0, true, p);
+    build_plan(m, batch, (flags & (KASF_FLAG_TRAIN | KASF_FLAG_KEEP)) != 0, true, p);
     return (int32_t)p.entries.size();
 }
 int kasf_ws_entry(const kasf_model* m, int32_t batch, int32_t flags, int32_t idx, char* name, int32_t cap, int64_t* byte_offset, int64_t* numel,
                   int32_t* elem_kind) {
     if (check_model(m)) return 2;
     Plan p;
-    build_plan(m, batch, (flags & KASF_FLAG_TRAIN) != 0, true, p);
+    build_plan(m, batch, (flags & (KASF_FLAG_TRAIN | KASF_FLAG_KEEP)) != 0, true, p);
     if (idx < 0 || idx >= (int32_t)p.entries.size()) return kasf_set_error(2, "workspace entry index out of range");
     const WsEntry& e = p.entries[idx];
     if (name != nullptr && cap > 0) { strncpy(name, e.name.c_str(), cap - 1); name[cap - 1] = 0; }
@@ -614,12 +615,13 @@ int kasf_forward(const kasf_model* m, const float* params, const void* packed, f
     if (check_model(m)) return 2;
     if (!params || !packed || !buffers || !x || !out || !workspace) return kasf_set_error(2, "null pointer argument");
     if (m->d_pro == nullptr) return kasf_set_error(4, "layout-only model cannot run");
-    const bool train = (flags & KASF_FLAG_TRAIN) != 0;
+    const bool bn_train = (flags & KASF_FLAG_TRAIN) != 0;
+    const bool train = bn_train || (flags & KASF_FLAG_KEEP) != 0;        // keep every layer's activations
     Plan p;
     build_plan(m, batch, train, false, p);
     if (workspace_bytes < p.total) return kasf_set_error(5, "workspace too small (see kasf_workspace_bytes)");
     Ctx c{m, params, (const char*)packed, buffers, nullptr, (char*)workspace, (hipStream_t)stream, batch, m->cfg.n_frames, m->cfg.dtype, esize(m),
-          (int64_t)batch * m->cfg.n_frames * 17, train};
+          (int64_t)batch * m->cfg.n_frames * 17, train, bn_train};
     g_err.clear();
     HIPCHK(hipMemsetAsync(c.w(p.stats_begin), 0, p.stats_bytes, c.s));
     if (train) HIPCHK(hipMemcpyAsync(c.w(p.x3), x, c.M * 3 * sizeof(float), hipMemcpyDeviceToDevice, c.s));
@@ -664,7 +666,7 @@ int kasf_forward(const kasf_model* m, const float* params, const void* packed, f
 }
 
 int kasf_backward(const kasf_model* m, const float* params, const void* packed, const float* dout, float* grads, void* workspace, int64_t workspace_bytes,
-                  int32_t batch, int32_t stage_begin, int32_t stage_end, void* stream) {
+                  int32_t batch, int32_t flags, int32_t stage_begin, int32_t stage_end, void* stream) {
     if (check_model(m)) return 2;
     if (!params || !packed || !dout || !grads || !workspace) return kasf_set_error(2, "null pointer argument");
     const int L = m->cfg.n_layers;
@@ -673,7 +675,7 @@ int kasf_backward(const kasf_model* m, const float* params, const void* packed, 
     build_plan(m, batch, true, false, p);
     if (workspace_bytes < p.total) return kasf_set_error(5, "workspace too small (see kasf_workspace_bytes)");
     Ctx c{m, params, (const char*)packed, nullptr, grads, (char*)workspace, (hipStream_t)stream, batch, m->cfg.n_frames, m->cfg.dtype, esize(m),
-          (int64_t)batch * m->cfg.n_frames * 17, true};
+          (int64_t)batch * m->cfg.n_frames * 17, true, (flags & KASF_FLAG_TRAIN) != 0};
     g_err.clear();
     const TopOff& t = m->top;
     for (int st = stage_begin; st < stage_end; ++st) {
@@ -683,7 +685,10 @@ int kasf_backward(const kasf_model* m, const float* params, const void* packed, 
             HIPCHK(hipMemsetAsync(c.w(p.bstats_begin), 0, p.bstats_bytes, c.s));
             HIPCHK(hipMemsetAsync(c.w(p.g_limb), 0, c.M * 128 * c.es, c.s));
             const void* x_final = c.w(p.layers[L - 1].gate_out);
-            kasf_launch_head_bwd(c.dt, c.s, dout, c.w(p.rep), params + t.head_w, c.w(p.sc[0].hbuf), grads + t.head_w, grads + t.head_b, c.M);
+            if (flags & KASF_FLAG_RETURN_REP)      // the forward returned the tanh features: dout is [B,T,17,512], the head took no part
+                kasf_launch_rep_bwd(c.dt, c.s, dout, c.w(p.rep), c.w(p.sc[0].hbuf), c.M);
+            else
+                kasf_launch_head_bwd(c.dt, c.s, dout, c.w(p.rep), params + t.head_w, c.w(p.sc[0].hbuf), grads + t.head_w, grads + t.head_b, c.M);
             kasf_launch_dgrad_lnbwd(c.dt, c.s, c.w(p.sc[0].hbuf), 512, c.pk(t.p_fcT), nullptr, x_final, params + t.norm_w, nullptr, gbuf(0), 0, grads + t.norm_w,
                                     grads + t.norm_b, c.M, c.w(p.sc[0].xn_a), params + t.norm_b);
             kasf_launch_wgrad(c.dt, c.s, c.w(p.sc[0].hbuf), 512, 512, c.w(p.sc[0].xn_a), 128, 128, nullptr, nullptr, grads + t.fc_w, 128, grads + t.fc_b, c.M,
@@ -761,7 +766,8 @@ int kasf_adamw_step(float* params, const float* grads, float* exp_avg, float* ex
                     float weight_decay, int32_t step_index, float grad_scale, void* stream) {
     if (!params || !grads || !exp_avg || !exp_avg_sq) return kasf_set_error(2, "null pointer argument");
     if (n % 4 != 0 || step_index < 1) return kasf_set_error(2, "n must be a multiple of 4 and step_index >= 1");
-    const float bc1 = 1.0f - powf(beta1, (float)step_index), bc2 = 1.0f - powf(beta2, (float)step_index);
+    // torch.optim.AdamW forms the bias corrections in double (1 - 0.999^t cancels badly in fp32 at small t)
+    const float bc1 = (float)(1.0 - pow((double)beta1, (double)step_index)), bc2 = (float)(1.0 - pow((double)beta2, (double)step_index));
     kasf_launch_adamw((hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale);
     HIPCHK(hipGetLastError());
     return 0;

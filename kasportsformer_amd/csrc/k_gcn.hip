@@ -302,15 +302,16 @@ __device__ __forceinline__ void dy_chunk(const T* rbuf, const T* y, const float*
 }
 
 // what k_gcn_bwd_finalize did in a one-workgroup launch: every workgroup derives the node table itself; workgroup 0 accumulates d(bn weight / bias)
-__device__ __forceinline__ void bwd2_prologue(float* sC, const float* coef, const double* bstats, float* d_w, float* d_b, int nodes, double count) {
+__device__ __forceinline__ void bwd2_prologue(float* sC, const float* coef, const double* bstats, float* d_w, float* d_b, int nodes, double count,
+                                              int training) {
     if ((int)threadIdx.x < nodes) {
         const int n = threadIdx.x;
         sC[n * C2_LD + 0] = coef[n * COEF_LD];
         sC[n * C2_LD + 1] = coef[n * COEF_LD + 2];
         sC[n * C2_LD + 2] = coef[n * COEF_LD + 3];
         const double s0 = stat_sum(bstats, 2 * n), s1 = stat_sum(bstats, 2 * n + 1);
-        sC[n * C2_LD + 3] = (float)(s0 / count);
-        sC[n * C2_LD + 4] = (float)(s1 / count);
+        sC[n * C2_LD + 3] = training ? (float)(s0 / count) : 0.f;      // evaluation-mode BatchNorm: mean / variance are constants, dy = scale * r
+        sC[n * C2_LD + 4] = training ? (float)(s1 / count) : 0.f;
         if (blockIdx.x == 0) {
             d_b[n] += (float)s0;
             d_w[n] += (float)s1;
@@ -322,9 +323,9 @@ __device__ __forceinline__ void bwd2_prologue(float* sC, const float* coef, cons
 template <typename T>
 __global__ __launch_bounds__(256) void k_gcn_bwd2_spatial(const T* __restrict__ rbuf, const T* __restrict__ y, const float* __restrict__ coefg,
                                                           T* __restrict__ duv, int64_t M, const double* __restrict__ bstats, float* __restrict__ d_w,
-                                                          float* __restrict__ d_b, int nodes, double count) {
+                                                          float* __restrict__ d_b, int nodes, double count, int training) {
     __shared__ float coef[96 * C2_LD];
-    bwd2_prologue(coef, coefg, bstats, d_w, d_b, nodes, count);
+    bwd2_prologue(coef, coefg, bstats, d_w, d_b, nodes, count, training);
     const int sub = threadIdx.x & 15;
     for (int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x; item < M * 16; item += (int64_t)gridDim.x * 256) {
         const int64_t tok = item >> 4, frame0 = (tok / KASF_J) * KASF_J;
@@ -352,9 +353,9 @@ __global__ __launch_bounds__(256) void k_gcn_bwd2_spatial(const T* __restrict__ 
 template <typename T, int L>
 __global__ __launch_bounds__(256) void k_gcn_bwd2_temporal(const T* __restrict__ rbuf, const T* __restrict__ y, const float* __restrict__ coefg,
                                                            const uint32_t* __restrict__ mask, T* __restrict__ duv, int Tn, const double* __restrict__ bstats,
-                                                           float* __restrict__ d_w, float* __restrict__ d_b, int nodes, double count) {
+                                                           float* __restrict__ d_w, float* __restrict__ d_b, int nodes, double count, int training) {
     __shared__ float coef[96 * C2_LD];
-    bwd2_prologue(coef, coefg, bstats, d_w, d_b, nodes, count);
+    bwd2_prologue(coef, coefg, bstats, d_w, d_b, nodes, count, training);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sDy = reinterpret_cast<float*>(smem);        // [L][SX_LD]
     float* sDinv = sDy + L * SX_LD;
@@ -414,10 +415,10 @@ void agg_temporal_TL(hipStream_t s, const void* uv, const void* xn, void* y, uin
 }
 template <typename T, int L>
 void bwd2_temporal_TL(hipStream_t s, const void* r, const void* y, const float* coef, const uint32_t* mask, void* duv, int B, int Tn, const double* bstats,
-                      float* d_w, float* d_b, double count) {
+                      float* d_w, float* d_b, double count, int training) {
     set_smem(k_gcn_bwd2_temporal<T, L>, bwd2_smem<L>());
     hipLaunchKernelGGL((k_gcn_bwd2_temporal<T, L>), dim3(B * KASF_J), dim3(256), bwd2_smem<L>(), s, (const T*)r, (const T*)y, coef, mask, (T*)duv, Tn, bstats,
-                       d_w, d_b, Tn, count);
+                       d_w, d_b, Tn, count, training);
 }
 
 template <typename T>
@@ -434,13 +435,13 @@ void agg_fwd_T(hipStream_t s, const void* uv, const void* xn, void* y, uint32_t*
 }
 template <typename T>
 void bwd2_T(hipStream_t s, const void* r, const void* y, const float* coef, const uint32_t* mask, void* duv, int B, int Tn, int mode, const double* bstats,
-            float* d_w, float* d_b, double count) {
+            float* d_w, float* d_b, double count, int training) {
     const int64_t M = (int64_t)B * Tn * KASF_J;
     if (mode == 0) hipLaunchKernelGGL(k_gcn_bwd2_spatial<T>, dim3(ew_grid(M)), dim3(256), 0, s, (const T*)r, (const T*)y, coef, (T*)duv, M, bstats, d_w, d_b,
-                                      KASF_J, count);
-    else if (Tn == 27) bwd2_temporal_TL<T, 27>(s, r, y, coef, mask, duv, B, Tn, bstats, d_w, d_b, count);
-    else if (Tn == 81) bwd2_temporal_TL<T, 81>(s, r, y, coef, mask, duv, B, Tn, bstats, d_w, d_b, count);
-    else if (Tn == 9) bwd2_temporal_TL<T, 9>(s, r, y, coef, mask, duv, B, Tn, bstats, d_w, d_b, count);
+                                      KASF_J, count, training);
+    else if (Tn == 27) bwd2_temporal_TL<T, 27>(s, r, y, coef, mask, duv, B, Tn, bstats, d_w, d_b, count, training);
+    else if (Tn == 81) bwd2_temporal_TL<T, 81>(s, r, y, coef, mask, duv, B, Tn, bstats, d_w, d_b, count, training);
+    else if (Tn == 9) bwd2_temporal_TL<T, 9>(s, r, y, coef, mask, duv, B, Tn, bstats, d_w, d_b, count, training);
     else kasf_set_error(3, "temporal GCN: n_frames must be one of 9, 27, 81");
 }
 
@@ -488,8 +489,8 @@ void kasf_launch_gcn_bwd1(int dt, hipStream_t s, const void* g, const void* xn, 
     else hipLaunchKernelGGL(k_gcn_bwd1<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)g, (const bf16*)xn, (const bf16*)y, coef, ls1, (bf16*)r, dls1, bstats, M, T, mode, nodes);
 }
 void kasf_launch_gcn_bwd2(int dt, hipStream_t s, const void* r, const void* y, const float* coef, const uint32_t* mask, void* duv, int B, int T,
-                          int mode, const double* bstats, float* d_bn_w, float* d_bn_b, double count) {
+                          int mode, const double* bstats, float* d_bn_w, float* d_bn_b, double count, int training) {
     kasf_gcn_init();
-    if (dt == KASF_F32) bwd2_T<float>(s, r, y, coef, mask, duv, B, T, mode, bstats, d_bn_w, d_bn_b, count);
-    else bwd2_T<bf16>(s, r, y, coef, mask, duv, B, T, mode, bstats, d_bn_w, d_bn_b, count);
+    if (dt == KASF_F32) bwd2_T<float>(s, r, y, coef, mask, duv, B, T, mode, bstats, d_bn_w, d_bn_b, count, training);
+    else bwd2_T<bf16>(s, r, y, coef, mask, duv, B, T, mode, bstats, d_bn_w, d_bn_b, count, training);
 }

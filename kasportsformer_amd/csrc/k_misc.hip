@@ -626,6 +626,24 @@ void kasf_launch_head_fwd(int dt, hipStream_t s, const void* rep, const float* W
     if (dt == KASF_F32) hipLaunchKernelGGL(k_head_fwd<float>, dim3(grid), dim3(256), 0, s, (const float*)rep, W, b, out, M);
     else hipLaunchKernelGGL(k_head_fwd<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)rep, W, b, out, M);
 }
+// backward of forward(x, return_rep=True) (KASportsFormer.py:342-343): the output is tanh(fc(norm(x))), so dpre = drep * (1 - rep^2)
+template <typename T>
+static __global__ __launch_bounds__(256) void k_rep_bwd(const float* __restrict__ drep, const T* __restrict__ rep, T* __restrict__ dpre, int64_t n8) {
+    for (int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x; item < n8; item += (int64_t)gridDim.x * 256) {
+        float d[8], r[8];
+        load8(drep + item * 8, d);
+        load8(rep + item * 8, r);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d[e] *= 1.0f - r[e] * r[e];
+        store8(dpre + item * 8, d);
+    }
+}
+void kasf_launch_rep_bwd(int dt, hipStream_t s, const float* drep, const void* rep, void* dpre, int64_t M) {
+    const int64_t n8 = M * 64, blocks = (n8 + 255) / 256;
+    const unsigned grid = (unsigned)(blocks > 4096 ? 4096 : blocks);
+    if (dt == KASF_F32) hipLaunchKernelGGL(k_rep_bwd<float>, dim3(grid), dim3(256), 0, s, drep, (const float*)rep, (float*)dpre, n8);
+    else hipLaunchKernelGGL(k_rep_bwd<bf16>, dim3(grid), dim3(256), 0, s, drep, (const bf16*)rep, (bf16*)dpre, n8);
+}
 void kasf_launch_head_bwd(int dt, hipStream_t s, const float* dy, const void* rep, const float* W, void* dpre, float* dW, float* db, int64_t M) {
     const unsigned grid = ew_grid(M * 16, 256);
     if (dt == KASF_F32) hipLaunchKernelGGL(k_head_bwd<float>, dim3(grid), dim3(256), 0, s, dy, (const float*)rep, W, (float*)dpre, dW, db, M);

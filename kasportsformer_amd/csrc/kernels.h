@@ -97,7 +97,8 @@ void kasf_launch_gcn_bwd1(int dt, hipStream_t s, const void* g, const void* xn, 
                           float* dls1, double* bstats, int B, int T, int mode);
 // BatchNorm-backward finalisation (means of the backward sums, d(bn weight / bias)) is part of bwd2
 void kasf_launch_gcn_bwd2(int dt, hipStream_t s, const void* r, const void* y, const float* coef, const uint32_t* mask, void* duv, int B, int T,
-                          int mode, const double* bstats, float* d_bn_w, float* d_bn_b, double count);
+                          int mode, const double* bstats, float* d_bn_w, float* d_bn_b, double count, int training = 1);
+// training == 0: backward of an evaluation-mode BatchNorm (running statistics are constants: no batch-mean terms)
 
 // ---- k_misc.hip ----
 void kasf_launch_prologue_fwd(int dt, hipStream_t s, const float* x, const float* params, const KasfProOff* off, void* xj, void* xb, void* xl,
@@ -113,6 +114,8 @@ void kasf_launch_gate_bwd(int dt, hipStream_t s, const void* g, const void* g1, 
                           int64_t part_floats);   // g1/g2: optional extra addends of the incoming gradient; part: scratch for per-workgroup partials
 void kasf_launch_head_fwd(int dt, hipStream_t s, const void* rep, const float* W, const float* b, float* out, int64_t M);
 void kasf_launch_head_bwd(int dt, hipStream_t s, const float* dy, const void* rep, const float* W, void* dpre, float* dW, float* db, int64_t M);
+// return_rep=True backward: dpre = drep * (1 - rep^2), drep [M,512] fp32
+void kasf_launch_rep_bwd(int dt, hipStream_t s, const float* drep, const void* rep, void* dpre, int64_t M);
 void kasf_launch_cast_to_f32(int dt, hipStream_t s, const void* src, float* dst, int64_t n);
 void kasf_launch_cast_from_f32(int dt, hipStream_t s, const float* src, void* dst, int64_t n);
 void kasf_launch_add_inplace(int dt, hipStream_t s, void* dst, const void* a, int64_t n);   // dst += a

@@ -140,11 +140,24 @@ class Evaluator:
                 "activity_name_sequence": names, "mpjpe_activity": [float(v) for v in m_act], "mpjpe_joint": j_act.mean(axis=0)}
 
 
-def evaluate_one_epoch(model, test_loader, flip: bool = True, device="cuda", action_names=None, distributed: bool = False):
+def _broadcast_buffers(model, data_parallel=None):
+    import torch.distributed as dist
+    if data_parallel is not None:
+        return data_parallel.sync_buffers_from_rank0()
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        for t in (model._flat_buffers, model._nbt):
+            dist.broadcast(t, src=0)
+
+
+def evaluate_one_epoch(model, test_loader, flip: bool = True, device="cuda", action_names=None, distributed: bool = False, data_parallel=None):
     """evaluate_one_epoch_new (train_and_evaluate_sp.py:27-149) / evaluate_one_epoch (train_and_evaluate_wp.py:25-135): ``test_loader``
-    yields (joint_input, joint_label_scaled, joint_factor, joint_action, joint_res) like the reference's test DataLoader."""
+    yields (joint_input, joint_label_scaled, joint_factor, joint_action, joint_res) like the reference's test DataLoader.
+    ``distributed``: every rank evaluates its shard and the per-action tables are summed.  All ranks must then evaluate the SAME model:
+    BatchNorm running statistics are per-rank during training, so rank 0's are broadcast first (``nn.DataParallel`` keeps replica 0's)."""
     was_training = model.training
     model.eval()
+    if distributed:
+        _broadcast_buffers(model, data_parallel)
     ev = Evaluator(device=device, action_names=action_names)
     for joint_input, joint_label_scaled, joint_factor, joint_action, joint_res in test_loader:
         pred = predict_flip_tta(model, joint_input.to(device), flip)

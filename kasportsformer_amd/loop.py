@@ -27,7 +27,7 @@ def train_one_epoch(model, train_loader, optimizer, data_parallel=None, lambda_n
         count += x.shape[0]
         loss_total.backward()
         if data_parallel is not None:
-            data_parallel.finish_gradients()
+            data_parallel.finish_gradients(optimizer)
         optimizer.step()
     avg = (sums / max(count, 1)).cpu().tolist()               # the only host synchronisation of the epoch
     return {"loss_total": avg[0], "loss_mpjpe": avg[1], "loss_n_mpjpe": avg[2], "loss_velocity": avg[3]}

@@ -71,16 +71,18 @@ class _KasfFunction(torch.autograd.Function):
     """Whole-model autograd node: forward and backward are single C-ABI calls."""
 
     @staticmethod
-    def forward(ctx, x, anchor, model):
-        out, ws = model._launch_forward(x, return_rep=False, keep=True)
-        ctx.model, ctx.ws, ctx.batch = model, ws, x.shape[0]
+    def forward(ctx, x, anchor, model, return_rep):
+        out, ws, flags = model._launch_forward(x, return_rep=return_rep, keep=True)
+        ctx.model, ctx.ws, ctx.batch, ctx.flags = model, ws, x.shape[0], flags
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        ctx.model._launch_backward(ctx.ws, dout, ctx.batch)
+        if ctx.ws is None:
+            raise RuntimeError("Trying to backward through the graph a second time (the kept activations were freed)")
+        ctx.model._launch_backward(ctx.ws, dout, ctx.batch, ctx.flags)
         ctx.ws = None
-        return None, None, None
+        return None, None, None, None
 
 
 class KASportsFormer(nn.Module):
@@ -162,8 +164,10 @@ class KASportsFormer(nn.Module):
             if tuple(p.shape) != tuple(self._p_entries[n][1]):
                 raise RuntimeError(f"shape mismatch for {n}")
         self._packed = None
-        self._packed_version = None
+        self._packed_dirty = True
+        self.static_weights = False         # True: trust mark_weights_dirty() instead of re-packing on every forward (inference serving)
         self._flatten()
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.mark_weights_dirty())
 
     # ------------------------------------------------------------------ flat storage management
     def _flatten(self):
@@ -197,7 +201,7 @@ class KASportsFormer(nn.Module):
             self._set_buffer(n, counters[i])
         self._nbt = counters
         self._packed = None
-        self._packed_version = None
+        self._packed_dirty = True
 
     def _set_buffer(self, dotted, tensor):
         mod = self
@@ -212,8 +216,10 @@ class KASportsFormer(nn.Module):
         return out
 
     def mark_weights_dirty(self):
-        """Call after modifying parameters through raw pointers (FusedAdamW does)."""
-        self._packed_version = None
+        """The kernel-side weight arena is stale: re-pack before the next forward.  Only matters with ``static_weights=True``; by default
+        every forward re-packs (one ~0.1 ms launch), because an ``nn.Parameter`` can be edited in ways no hook sees (``torch.optim`` steps,
+        ``p.data.fill_()``, ``load_state_dict``) and the reference module picks all of them up on its next call."""
+        self._packed_dirty = True
 
     # ------------------------------------------------------------------ native calls
     def _device_handle(self):
@@ -231,10 +237,10 @@ class KASportsFormer(nn.Module):
         h = self._device_handle()
         if self._packed is None or self._packed.device != self._flat.device:
             self._packed = torch.empty(self._lib.kasf_packed_bytes(h), dtype=torch.uint8, device=self._flat.device)
-            self._packed_version = None
-        if self._packed_version != self._flat._version:
+            self._packed_dirty = True
+        if self._packed_dirty or not self.static_weights:
             _lib.check(self._lib.kasf_pack_weights(h, self._flat.data_ptr(), self._packed.data_ptr(), self._stream()))
-            self._packed_version = self._flat._version
+            self._packed_dirty = False
 
     def _check_input(self, x):
         if not isinstance(x, torch.Tensor) or x.dim() != 4 or x.shape[2] != 17 or x.shape[3] != 3:
@@ -251,25 +257,25 @@ class KASportsFormer(nn.Module):
         self._ensure_packed()
         x = x.contiguous()
         B = x.shape[0]
-        flags = (_lib.FLAG_TRAIN if self.training else 0) | (_lib.FLAG_RETURN_REP if return_rep else 0)
-        ws_flags = flags | (_lib.FLAG_TRAIN if keep else 0)
-        if keep and not self.training:
-            raise RuntimeError("backward through an eval-mode (running-statistics BatchNorm) forward is not built; call model.train()")
-        nbytes = self._lib.kasf_workspace_bytes(h, B, ws_flags)
+        flags = (_lib.FLAG_TRAIN if self.training else 0) | (_lib.FLAG_RETURN_REP if return_rep else 0) | (_lib.FLAG_KEEP if keep else 0)
+        nbytes = self._lib.kasf_workspace_bytes(h, B, flags)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
         out = torch.empty((B, self.n_frames, 17, 512 if return_rep else 3), dtype=torch.float32, device=x.device)
         _lib.check(self._lib.kasf_forward(h, self._flat.data_ptr(), self._packed.data_ptr(), self._flat_buffers.data_ptr(), x.data_ptr(),
                                           out.data_ptr(), ws.data_ptr(), nbytes, B, flags, self._stream()))
         if self.training:
             self._nbt += 1                      # BatchNorm num_batches_tracked (graph.py:37)
-        return out, ws
+        return out, ws, flags
 
-    def _launch_backward(self, ws, dout, B):
+    def _launch_backward(self, ws, dout, B, flags):
         h = self._device_handle()
         dout = dout.contiguous().float()
-        g = torch.zeros(self.n_flat, dtype=torch.float32, device=dout.device)
+        # kasf_backward accumulates: a second backward before the optimizer step (gradient accumulation) adds to the same flat array,
+        # exactly like p.grad does in the reference
+        fresh = self.flat_grad is None or (self.attach_param_grads and self._live[0][0].grad is None)    # the latter: optimizer.zero_grad(set_to_none=True)
+        g = torch.zeros(self.n_flat, dtype=torch.float32, device=dout.device) if fresh else self.flat_grad
         stages = self._lib.kasf_backward_stages(h)
-        args = (h, self._flat.data_ptr(), self._packed.data_ptr(), dout.data_ptr(), g.data_ptr(), ws.data_ptr(), ws.numel(), B)
+        args = (h, self._flat.data_ptr(), self._packed.data_ptr(), dout.data_ptr(), g.data_ptr(), ws.data_ptr(), ws.numel(), B, flags)
         if self.grad_stage_hook is None:
             _lib.check(self._lib.kasf_backward(*args, 0, stages, self._stream()))
         else:
@@ -297,8 +303,10 @@ class KASportsFormer(nn.Module):
             for p, off, n, shape in self._live:
                 v = g[off:off + n].view(shape)
                 if p.grad is None:
-                    p.grad = v
-                else:
+                    p.grad = v                   # a view of the flat array: later backward passes accumulate into it in place
+                elif p.grad.data_ptr() != v.data_ptr():
+                    if not fresh:
+                        raise RuntimeError("p.grad was replaced between two backward passes without zero_grad(); cannot accumulate")
                     p.grad += v
 
     # ------------------------------------------------------------------ reference interface
@@ -308,11 +316,9 @@ class KASportsFormer(nn.Module):
         self._check_input(x)
         if x.shape[0] == 0:        # the reference returns an empty result in both modes (checked against it); no kernel can be launched on zero clips
             return x.new_empty((0, self.n_frames, 17, 512 if return_rep else 3))
-        if self.training and torch.is_grad_enabled() and self.pos_embed.requires_grad:
-            if return_rep:
-                raise NotImplementedError("gradients through return_rep=True are not built")
-            return _KasfFunction.apply(x, self.pos_embed, self)
-        out, _ = self._launch_forward(x, return_rep, keep=False)
+        if torch.is_grad_enabled() and self.pos_embed.requires_grad:
+            return _KasfFunction.apply(x, self.pos_embed, self, bool(return_rep))
+        out, _, _ = self._launch_forward(x, return_rep, keep=False)
         return out
 
     def __del__(self):

@@ -20,7 +20,7 @@ import torch.distributed as dist
 
 
 class DataParallel:
-    def __init__(self, model, process_group=None, overlap=True, stages_per_bucket=7):
+    def __init__(self, model, process_group=None, overlap=True, stages_per_bucket=7, optimizer=None):
         """``stages_per_bucket`` backward stages (layers) share one all-reduce: 4 buckets of ~30 MB instead of 27 of 4.5 MB keep the
         per-bucket host and launch overhead off the step (xGMI ring all-reduce of 117 MB is ~1 ms; the point of the buckets is overlap)."""
         if not dist.is_initialized():
@@ -30,10 +30,29 @@ class DataParallel:
                           "share hardware queues (about -6 % throughput).  Export GPU_MAX_HW_QUEUES=8 before starting the ranks.")
         self.model, self.group, self.overlap = model, process_group, overlap
         self.world = dist.get_world_size(process_group)
+        self.rank = dist.get_rank(process_group)
         self._pending = []
+        self.optimizer = None
+        if optimizer is not None:
+            self.attach_optimizer(optimizer)
         self.sync_from_rank0()
         model.grad_stage_hook = self._on_stage if overlap else None
         model.grad_stage_group = stages_per_bucket
+
+    def attach_optimizer(self, optimizer):
+        """The all-reduce is a SUM: the mean over ranks is taken by the optimizer step (``FusedAdamW.grad_scale = 1 / world_size``)."""
+        if not hasattr(optimizer, "grad_scale"):
+            raise TypeError("DataParallel folds 1/world_size into FusedAdamW.grad_scale; for a torch.optim optimizer divide the gradients yourself "
+                            "(model.flat_grad[:model.n_live] /= world) after finish_gradients()")
+        optimizer.grad_scale = 1.0 / self.world
+        self.optimizer = optimizer
+
+    def sync_buffers_from_rank0(self):
+        """BatchNorm running statistics / counters of rank 0 to every rank: what evaluation and checkpoints must see (``nn.DataParallel``
+        only ever keeps replica 0's buffer updates, train_and_evaluate_sp.py:262-264).  9.4 KB."""
+        m = self.model
+        for t in (m._flat_buffers, m._nbt):
+            dist.broadcast(t, src=0, group=self.group)
 
     def sync_from_rank0(self):
         """Broadcast parameters and BatchNorm buffers (DataParallel keeps replica 0's buffers)."""
@@ -45,9 +64,17 @@ class DataParallel:
     def _on_stage(self, stage, grad_slice):
         self._pending.append(dist.all_reduce(grad_slice, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
-    def finish_gradients(self):
-        """Call after loss.backward(): waits for the bucketed all-reduces (or runs one when overlap is off)."""
+    def finish_gradients(self, optimizer=None):
+        """Call after loss.backward(): waits for the bucketed all-reduces (or runs one when overlap is off).  Pass (or attach) the optimizer so
+        that its ``grad_scale`` is 1/world_size; stepping with an unscaled optimizer at world_size > 1 raises instead of silently training at
+        world_size times the gradient."""
         m = self.model
+        opt = optimizer if optimizer is not None else self.optimizer
+        if opt is not None and self.optimizer is not opt:
+            self.attach_optimizer(opt)
+        if self.world > 1 and self.optimizer is None:
+            raise RuntimeError("DataParallel.finish_gradients: no optimizer attached (DataParallel(model, optimizer=opt) or finish_gradients(opt)): "
+                               "the all-reduced gradient is a sum over ranks and nobody would divide it by world_size")
         if self.overlap:
             for w in self._pending:
                 w.wait()

@@ -22,7 +22,7 @@ def test_header_symbols_are_exported():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/kasf.h but not exported"
         assert name in _lib.SIGNATURES, f"{name} has no ctypes prototype"
-    assert lib.kasf_version() == 1
+    assert lib.kasf_version() == _lib.ABI_VERSION
 
 
 def test_layout_covers_reference_state_dict(golden_dir):

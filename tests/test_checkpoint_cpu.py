@@ -86,3 +86,30 @@ def test_reference_written_checkpoint_resumes_here(tmp_path):
     torch.save(bad, str(tmp_path / "bad.pth"))
     with pytest.raises(RuntimeError):
         K.checkpoint_load(str(tmp_path / "bad.pth"), model)                           # strict=True like the reference
+
+
+def test_checkpoint_with_numpy_scalar_min_mpjpe_loads(tmp_path):
+    """The reference's loop stores ``min_mpjpe = mpjpe`` where ``mpjpe`` came out of ``np.mean`` (train_and_evaluate_sp.py:350-351): the file
+    then pickles a ``numpy.core.multiarray.scalar`` next to the tensors, which a bare ``weights_only=True`` load refuses."""
+    import numpy as np
+    oracle, model = _pair()
+    path = tmp_path / "ref_best.pth"
+    torch.save({"epoch": 2, "learning_rate": 5e-4, "optimizer": None, "model": {"module." + k: v for k, v in oracle.state_dict().items()},
+                "min_mpjpe": np.mean(np.array([40.0, 44.5])), "wandb_id": "w"}, str(path))
+    with pytest.raises(Exception):
+        torch.load(str(path), map_location="cpu", weights_only=True)            # what round 1 did
+    info = K.checkpoint_load(str(path), model, K.FusedAdamW(model), resume=True)
+    assert info["min_mpjpe"] == 42.25 and info["epoch"] == 2
+    # and the writer never produces such a file itself, whatever it is handed
+    out = tmp_path / "ours.pth"
+    K.checkpoint_save(str(out), 1, 5e-4, None, model, np.float64(41.5), "w")
+    assert type(torch.load(str(out), map_location="cpu", weights_only=True)["min_mpjpe"]) is float
+
+
+def test_product_synthetic_clips_equal_the_checkers():
+    """bench.py / smoke draw their inputs from kasportsformer_amd.synthetic (the product never imports oracle/); same recipe, same bits."""
+    for kw in (dict(B=3, T=27), dict(B=2, T=9, seed=5, res=(1920, 1080), det_conf=True)):
+        a, b = K.synthetic_clips(**kw), O.synthetic_clips(**kw)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        ea, eb = K.synthetic_test_extras(a[1]), O.synthetic_test_extras(b[1])
+        assert all(torch.equal(u, v) for u, v in zip(ea[:3], eb[:3])) and ea[3] == eb[3]

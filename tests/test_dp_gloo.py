@@ -50,11 +50,39 @@ def _worker(rank, world, port, overlap, q):
                 if m.grad_stage_hook is not None:
                     m.grad_stage_hook(st, g[b.value:e.value])
         m.flat_grad = g
-        dp.finish_gradients()
+        if world > 1:
+            try:
+                dp.finish_gradients()                       # nobody would divide the summed gradient by world_size
+                raise AssertionError("finish_gradients without an optimizer must raise at world_size > 1")
+            except RuntimeError:
+                pass
+        opt = K.FusedAdamW(m)
+        dp.finish_gradients(opt)
+        assert opt.grad_scale == 1.0 / world
         assert covered[:m.n_live].all() and not covered[m.n_live:].any()      # dead norm1_limb tail is never reduced
         expect = sum(r + 1 for r in range(world)) * pattern
         assert torch.equal(g[:m.n_live], expect[:m.n_live])
         assert torch.count_nonzero(g[m.n_live:]) == 0
+        # training leaves every rank with ITS OWN BatchNorm running statistics; evaluation and checkpoints must see rank 0's on every rank
+        # (nn.DataParallel keeps replica 0's buffers, train_and_evaluate_sp.py:262-264)
+        from kasportsformer_amd.evaluate import _broadcast_buffers
+        for how in ("evaluate", "checkpoint"):
+            m._flat_buffers.fill_(float(rank + 1))
+            m._nbt.fill_(rank + 11)
+            if how == "evaluate":
+                _broadcast_buffers(m, None)                 # what evaluate_one_epoch(distributed=True) does first
+            else:
+                import tempfile
+                path = os.path.join(tempfile.gettempdir(), f"kasf_dp_gloo_{port}.pth")
+                K.checkpoint_save(path, 0, 5e-4, None, m, 1.0, "id", data_parallel=dp)
+                dist.barrier()
+                sd = K.strip_module_prefix(torch.load(path, map_location="cpu", weights_only=True)["model"])
+                key = "layers_with_bone.0.graph_spatial.mixer.batch_norm.running_mean"
+                assert float(sd[key][0]) == 1.0 and int(sd[key.replace("running_mean", "num_batches_tracked")]) == 11
+                dist.barrier()
+                if rank == 0:
+                    os.remove(path)
+            assert float(m._flat_buffers.min()) == 1.0 and float(m._flat_buffers.max()) == 1.0 and int(m._nbt[0]) == 11, (how, rank)
         q.put((rank, "ok"))
     except Exception as ex:  # pragma: no cover
         q.put((rank, repr(ex)))

@@ -25,9 +25,8 @@ def run(use_dp):
     m = K.KASportsFormer(n_layers=3, num_heads=8, n_frames=27, compute_dtype="bf16").cuda().train()
     m.attach_param_grads = False
     opt = K.FusedAdamW(m, lr=5e-4, weight_decay=0.01)
-    dp = K.DataParallel(m) if use_dp else None
-    if dp is not None:
-        opt.grad_scale = 1.0 / dist.get_world_size()
+    dp = K.DataParallel(m, optimizer=opt) if use_dp else None
+    assert dp is None or opt.grad_scale == 1.0 / dist.get_world_size()
     x, y = (t.cuda() for t in O.synthetic_clips(4, 27, seed=3))
     grads = None
     for step in range(3):

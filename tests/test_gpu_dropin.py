@@ -1,0 +1,166 @@
+"""The module used the way the reference's scripts use theirs (train_and_evaluate_sp.py:262-273,171-176,241-243): a stock ``torch.optim``
+optimizer over ``model.parameters()``, ``load_state_dict`` / ``checkpoint_load`` into a model that has already run, in-place parameter
+edits, gradient accumulation, autograd through ``return_rep=True`` and through ``model.eval()``.  Every one of these changes parameters
+(or needs activations) behind the kernel-side packed-weight arena's back: round 1 kept a stale arena there."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import kasf_oracle as O
+from tests.gpu_util import make_pair
+
+pytestmark = pytest.mark.gpu
+
+
+def _grads_close(model, oracle, tol, floor):
+    ref = dict(oracle.named_parameters())
+    gmax = max(float(q.grad.abs().max()) for q in ref.values() if q.grad is not None)
+    bad = []
+    for n, p in model.named_parameters():
+        r = ref[n].grad
+        assert (r is None) == (p.grad is None), n
+        if r is not None:
+            err = float((p.grad.detach().cpu() - r).abs().max() / max(float(r.abs().max()), floor * gmax))
+            if not err < tol:
+                bad.append((err, n))
+    assert not bad, sorted(bad, reverse=True)[:8]
+
+
+def test_torch_optim_adamw_over_model_parameters_tracks_oracle():
+    """Three steps with torch.optim.AdamW(model.parameters()) -- exactly train_and_evaluate_sp.py:270-272 -- against the oracle stepping
+    with the same optimizer class: the forward of step k+1 must see the weights step k wrote through the nn.Parameter views."""
+    oracle, model = make_pair(1, 27, "fp32")
+    opt_ref = torch.optim.AdamW(oracle.parameters(), lr=5e-3, weight_decay=0.01)          # a large lr: a frozen forward would show at once
+    opt = torch.optim.AdamW(model.parameters(), lr=5e-3, weight_decay=0.01)
+    oracle.train(); model.train()
+    import kasportsformer_amd as K
+    for step in range(3):
+        x, y = O.synthetic_clips(2, 27, seed=200 + step)
+        pred_ref = oracle(x)
+        opt_ref.zero_grad()
+        l_ref, _ = O.loss_total(pred_ref, y)
+        l_ref.backward()
+        opt_ref.step()
+        pred = model(x.cuda())                                # train_and_evaluate_sp.py:208-243 order: forward, zero_grad, loss, backward, step
+        opt.zero_grad()
+        l, _ = K.loss3(pred, y.cuda())
+        l.backward()
+        opt.step()
+        assert float((pred.detach().cpu() - pred_ref.detach()).abs().max()) < 2e-3 * max(1.0, float(pred_ref.abs().max())), step
+        assert abs(l.item() - l_ref.item()) < 2e-3 * max(1.0, abs(l_ref.item())), (step, l.item(), l_ref.item())
+    sd = model.state_dict()
+    worst = max(float((sd[n].cpu() - p.detach()).abs().max()) for n, p in oracle.named_parameters())
+    assert worst < 5e-3, worst                                # three AdamW steps of 5e-3 each could move a weight by 1.5e-2
+
+
+@pytest.mark.parametrize("cd", ["fp32", "bf16"])
+def test_load_state_dict_after_a_forward_is_picked_up(cd):
+    """forward -> load_state_dict(other) -> forward  ==  a fresh model loaded with `other`, bit for bit; same for an in-place edit."""
+    import kasportsformer_amd as K
+    _, a = make_pair(2, 27, cd, salt=0)
+    _, b = make_pair(2, 27, cd, salt=1)
+    x = O.synthetic_clips(3, 27, seed=5)[0].cuda()
+    a.eval(); b.eval()
+    with torch.no_grad():
+        ya0, yb = a(x), b(x)
+        assert not torch.equal(ya0, yb)
+        a.load_state_dict(b.state_dict(), strict=True)
+        assert torch.equal(a(x), yb)
+        for p in a.parameters():                              # raw .data edits bump no version counter anywhere
+            p.data.mul_(0.5)
+        for p in b.parameters():
+            p.data.mul_(0.5)
+        assert torch.equal(a(x), b(x)) and not torch.equal(a(x), yb)
+        # opt-in static arena for serving: stale until told otherwise
+        a.static_weights = True
+        y_half = a(x)
+        a.layers_with_bone[0].att_spatial.mlp.fc1.weight.data.add_(1.0)
+        assert torch.equal(a(x), y_half)
+        a.mark_weights_dirty()
+        assert not torch.equal(a(x), y_half)
+
+
+def test_checkpoint_load_after_training_then_evaluate(tmp_path):
+    """train -> save best -> keep training -> checkpoint_load(best) into the SAME (already run) model -> evaluate: equals a fresh model loaded
+    from the file (train_and_evaluate_sp.py:171-176 after :350-358)."""
+    import kasportsformer_amd as K
+    _, model = make_pair(2, 27, "fp32")
+    opt = K.FusedAdamW(model, lr=5e-3)
+    xs, ys = (t.cuda() for t in O.synthetic_clips(8, 27, seed=31))
+    xt, yt = O.synthetic_clips(4, 27, seed=32)
+    extras = O.synthetic_test_extras(yt, seed=33)
+    loader = [(xt, extras[0], extras[1], extras[3], extras[2])]
+    model.train()
+    path = tmp_path / "best.pth"
+    for s in range(4):
+        opt.zero_grad()
+        K.loss3(model(xs), ys)[0].backward()
+        opt.step()
+        if s == 1:
+            K.checkpoint_save(str(path), s, 5e-3, opt, model, np.float64(50.0), "w")
+    after = K.evaluate_one_epoch(model, loader)
+    K.checkpoint_load(str(path), model)
+    best = K.evaluate_one_epoch(model, loader)
+    fresh = K.KASportsFormer(n_layers=2, num_heads=8, n_frames=27, compute_dtype="fp32").cuda()
+    K.checkpoint_load(str(path), fresh)
+    want = K.evaluate_one_epoch(fresh, loader)
+    assert best["mpjpe"] == want["mpjpe"] and best["p_mpjpe"] == want["p_mpjpe"]
+    assert best["mpjpe"] != after["mpjpe"]
+
+
+@pytest.mark.parametrize("cd,tol", [("fp32", 2e-3), ("bf16", 0.35)])
+def test_gradients_through_return_rep(cd, tol):
+    """forward(x, return_rep=True) is differentiable in the reference (KASportsFormer.py:342-343): the head takes no part."""
+    oracle, model = make_pair(2, 27, cd)
+    x, _ = O.synthetic_clips(2, 27, seed=9)
+    w = torch.randn(2, 27, 17, 512, generator=torch.Generator().manual_seed(1))
+    oracle.train(); model.train()
+    rep_ref = oracle(x, return_rep=True)
+    (rep_ref * w).sum().backward()
+    rep = model(x.cuda(), return_rep=True)
+    assert float((rep.detach().cpu() - rep_ref.detach()).abs().max()) < (1e-3 if cd == "fp32" else 0.12)
+    (rep * w.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    assert model.head.weight.grad is None and model.head.bias.grad is None
+    assert oracle.head.weight.grad is None
+    _grads_close(model, oracle, tol, 1e-3 if cd == "fp32" else 0.05)
+
+
+@pytest.mark.parametrize("cd,tol", [("fp32", 2e-3), ("bf16", 0.35)])
+def test_backward_through_eval_mode_forward(cd, tol):
+    """model.eval() with autograd enabled: BatchNorm normalises with its running statistics (constants), the reference differentiates
+    through that; running statistics and num_batches_tracked stay untouched."""
+    oracle, model = make_pair(2, 27, cd)
+    x, y = O.synthetic_clips(3, 27, seed=13)
+    oracle.eval(); model.eval()
+    buf_before = model._flat_buffers.clone()
+    O.loss_total(oracle(x), y)[0].backward()
+    pred = model(x.cuda())
+    O.loss_total(pred, y.cuda())[0].backward()
+    torch.cuda.synchronize()
+    assert torch.equal(model._flat_buffers, buf_before) and int(model._nbt.sum()) == 0
+    _grads_close(model, oracle, tol, 1e-3 if cd == "fp32" else 0.05)
+
+
+def test_gradient_accumulation_over_two_backwards():
+    """Two micro-batches before one optimizer step: p.grad and the flat gradient FusedAdamW reads both hold the SUM (torch semantics)."""
+    import kasportsformer_amd as K
+    oracle, model = make_pair(1, 27, "fp32")
+    oracle.train(); model.train()
+    for seed in (41, 42):
+        x, y = O.synthetic_clips(2, 27, seed=seed)
+        O.loss_total(oracle(x), y)[0].backward()
+        K.loss3(model(x.cuda()), y.cuda())[0].backward()
+    torch.cuda.synchronize()
+    _grads_close(model, oracle, 2e-3, 1e-3)
+    g = model.flat_grad
+    for p, off, n, shape in model._live[:40]:
+        assert p.grad.data_ptr() == g[off:off + n].data_ptr()          # one array, two views
+    # zero_grad(set_to_none=True) of a stock optimizer starts a fresh accumulation
+    torch.optim.SGD(model.parameters(), lr=0.1).zero_grad()
+    x, y = O.synthetic_clips(2, 27, seed=41)
+    for q in oracle.parameters():
+        q.grad = None
+    O.loss_total(oracle(x), y)[0].backward()
+    K.loss3(model(x.cuda()), y.cuda())[0].backward()
+    _grads_close(model, oracle, 2e-3, 1e-3)
