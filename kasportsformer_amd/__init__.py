@@ -12,6 +12,8 @@ Public surface mirrors the reference's interface for this path:
   train_one_epoch                       train_and_evaluate_sp.py:201-243
   warmup_lr, ReduceLROnPlateau          train_and_evaluate_sp.py:273,325-329,393-397
   checkpoint_save, checkpoint_load      utils/utilities.py:110-118, train_and_evaluate_sp.py:171-176,285-301
+  slice_source, split_clips,            data/reader/sp_reader.py:25-169,205-249, data/reader/wp_reader.py:25-135,159-199 (offline clip slicing)
+  mysplit_clips, resample
 """
 from .model import KASportsFormer, load_model
 from .functional import loss3
@@ -23,8 +25,9 @@ from .loop import train_one_epoch
 from .schedule import warmup_lr, apply_warmup, ReduceLROnPlateau
 from .evaluate import joint_flip, predict_flip_tta, clip_metrics, Evaluator, evaluate_one_epoch
 from .synthetic import synthetic_clips, synthetic_test_extras
+from .slicing import slice_source, split_clips, mysplit_clips, resample
 
 __all__ = ["KASportsFormer", "load_model", "loss3", "FusedAdamW", "DataParallel", "joint_flip", "predict_flip_tta", "clip_metrics", "Evaluator",
            "evaluate_one_epoch", "PackedClips", "DeviceClipLoader", "pack_clip_directory", "read_clip_file", "shard_indices",
            "checkpoint_save", "checkpoint_load", "strip_module_prefix", "adamw_state_dict", "load_adamw_state_dict", "warmup_lr", "apply_warmup", "ReduceLROnPlateau", "train_one_epoch",
-           "synthetic_clips", "synthetic_test_extras"]
+           "synthetic_clips", "synthetic_test_extras", "slice_source", "split_clips", "mysplit_clips", "resample"]

@@ -300,7 +300,10 @@ class KASportsFormer(nn.Module):
                     self.grad_stage_hook(st, g[lo:hi])
         self.flat_grad = g
         if self.attach_param_grads:
+            untouched = (self.head.weight, self.head.bias) if flags & _lib.FLAG_RETURN_REP else ()
             for p, off, n, shape in self._live:
+                if any(p is q for q in untouched) and p.grad is None:
+                    continue                         # return_rep=True: the head took no part, its .grad stays None as in the reference
                 v = g[off:off + n].view(shape)
                 if p.grad is None:
                     p.grad = v                   # a view of the flat array: later backward passes accumulate into it in place

@@ -204,6 +204,71 @@ def clips_fixture():
     print("wrote clips/ and clips_expected.npz:", {k: v.shape for k, v in exp.items()})
 
 
+def synthetic_source(dataset, seed):
+    """A miniature of the monolithic source pickles the reference slices (sp_reader.py:25-103 field names): per-frame arrays plus a video id
+    per frame.  Video lengths cover every branch of the two slicers at T = 9: exact multiples, a tail >= T/2, a tail < T/2, a video shorter
+    than T, one shorter than T/2, an id that re-appears later, and a short LAST video (which both slicers drop)."""
+    rng = np.random.RandomState(seed)
+
+    def split(lengths, ids, with_test):
+        n = int(sum(lengths))
+        d = {"joint_2d": (rng.rand(n, 17, 3) * 1000).astype(np.float64), "joint3d_image": (rng.rand(n, 17, 3) * 1000).astype(np.float64),
+             "source": np.concatenate([np.full(k, v) for k, v in zip(lengths, ids)])}
+        if dataset == "sp":
+            d["camera_name"] = np.concatenate([np.full(k, "outdoors" if i % 2 == 0 else "indoors") for i, k in enumerate(lengths)])
+        if seed % 2 == 1:
+            d["confidence"] = rng.rand(n, 17).astype(np.float64)
+        if with_test:
+            acts = ["soccer", "tennis", "jump"]
+            d["action"] = np.concatenate([np.full(k, acts[i % 3]) for i, k in enumerate(lengths)])
+            d["2.5d_factor"] = (rng.rand(n) * 0.4 + 0.8).astype(np.float64)
+            d["joints_2.5d_image"] = (rng.randn(n, 17, 3) * 300).astype(np.float64)
+        return d
+    return {"train": split([27, 20, 5, 9, 14, 3, 31, 6], ["a", "b", "c", "d", "e", "f", "c", "g"], False),
+            "test": split([18, 13, 4, 9, 22, 7], ["t0", "t1", "t2", "t3", "t1", "t5"], True)}
+
+
+def slicing_fixture():
+    """Offline clip slicing: the REFERENCE readers (data/reader/sp_reader.py, wp_reader.py) run on miniature source
+    files; the source arrays and everything the readers return are stored as data.  ``np.random.seed`` is set right before the slicing
+    call: ``resample`` draws from numpy's global generator."""
+    import importlib
+    import pickle
+    import tempfile
+    sys.path.insert(0, "/root/reference/data")
+    T = 9
+    out = {}
+    for tag, mod, cls, getter in (("sp", "reader.sp_reader", "DataReaderSportsPose", "get_sliced_data_sp"),
+                                  ("wp", "reader.wp_reader", "DataReaderWorldPose", "get_sliced_data_wp")):
+        for variant, seed in (("a", 10), ("b", 11)):                    # b: with a 'confidence' field (detector input)
+            src = synthetic_source(tag, seed)
+            with tempfile.NamedTemporaryFile(suffix=".pkl", delete=False) as f:
+                pickle.dump(src, f)
+            reader = getattr(importlib.import_module(mod), cls)(n_frames=T, sample_stride=1, data_stride_train=T // 3, data_stride_test=T,
+                                                                source_file_path=f.name)
+            os.remove(f.name)
+            np.random.seed(1000 + seed)
+            train_dict, test_dict = getattr(reader, getter)()
+            ids_train, ids_test = reader.get_split_id()
+            k = f"{tag}_{variant}_"
+            for split in ("train", "test"):
+                for name, arr in src[split].items():
+                    out[k + f"src_{split}_{name}"] = np.asarray(arr)
+            out[k + "ids_train"] = np.stack([np.asarray(list(c), dtype=np.int64) for c in ids_train])
+            out[k + "ids_test"] = np.stack([np.asarray(list(c), dtype=np.int64) for c in ids_test])
+            for name, arr in train_dict.items():
+                out[k + "train_" + name] = np.asarray(arr)
+            for name, arr in test_dict.items():
+                out[k + "test_" + name] = np.asarray(arr)
+    # resample on its own, every branch (sp_reader.py:129-150)
+    np.random.seed(77)
+    rs = importlib.import_module("reader.sp_reader").DataReaderSportsPose.resample
+    for i, (a, b, kw) in enumerate(((5, 9, {}), (20, 9, {}), (9, 9, {}), (4, 27, {}), (7, 9, {"randomness": False}), (30, 9, {"replay": True}), (4, 9, {"replay": True}))):
+        out[f"resample_{i}"] = np.asarray(list(rs(None, a, b, **kw)), dtype=np.int64)
+    np.savez_compressed(os.path.join(HERE, "slicing.npz"), **out)
+    print("wrote slicing.npz:", len(out), "arrays;", {k: v.shape for k, v in out.items() if "ids_" in k})
+
+
 def main():
     Ref, bone_decomposer, LC, EC = import_reference()
     torch.set_num_threads(8)
@@ -211,6 +276,8 @@ def main():
         return clips_fixture()
     if sys.argv[1:] == ["eval"]:                             # only the evaluation fixture
         return eval_fixture(Ref, EC)
+    if sys.argv[1:] == ["slicing"]:                          # only the offline clip-slicing fixture
+        return slicing_fixture()
 
     # 1. state_dict manifest of the full 26-layer model (names/shapes/dtypes only)
     full = Ref(n_layers=26, dim_in=3, dim_feat=128, dim_rep=512, dim_out=3, mlp_ratio=4, num_heads=8, n_frames=27)
@@ -258,6 +325,7 @@ def main():
     print("wrote functional.npz")
     eval_fixture(Ref, EC)
     clips_fixture()
+    slicing_fixture()
 
 
 if __name__ == "__main__":
