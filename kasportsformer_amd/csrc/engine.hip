@@ -283,8 +283,8 @@ void build_plan(const kasf_model* m, int B, bool train, bool names, Plan& p) {
             if (kind == KIND_GRAPH) {
                 w.xn = take(M * 128, 0, "xn", l, b);
                 w.y = take(M * 128, 0, "y", l, b);
-                w.coef = take(96 * 8, 1, "bn_coef", l, b);
-                w.mask = (b & 1) ? take(groupsT * T * 3, 3, "adj_mask", l, b) : -1;
+                w.coef = take(KASF_MAX_NODES * 8, 1, "bn_coef", l, b);
+                w.mask = (b & 1) ? take(groupsT * T * kasf_gcn_mask_words(T), 3, "adj_mask", l, b) : -1;
             }
             w.x_mid = take(M * 128, 0, "x_mid", l, b);
             w.xn2 = (train && m->cfg.dtype == KASF_BF16) ? take(M * 128, 0, "xn2", l, b) : -1;   // LN2(x_mid), streamed by the fused MLP backward
@@ -495,7 +495,9 @@ int kasf_model_create(const kasf_config* cfg, kasf_model** out) {
     if (cfg == nullptr || out == nullptr) return kasf_set_error(2, "null argument");
     if (cfg->num_heads != 8) return kasf_set_error(3, "num_heads must be 8 (head dim 16); other values are not built");
     if (cfg->n_layers < 1 || cfg->n_layers > 64) return kasf_set_error(3, "n_layers out of range");
-    if (cfg->n_frames != 9 && cfg->n_frames != 27 && cfg->n_frames != 81) return kasf_set_error(3, "n_frames must be 9, 27 or 81");
+    // any clip length the reference can build (BatchNorm1d(n_frames), top-4 of T similarities needs T >= 4); 9 / 27 / 81 have tuned temporal
+    // kernels (and T <= 96 the MFMA attention cores), other lengths run generic ones
+    if (cfg->n_frames < 4 || cfg->n_frames > KASF_MAX_NODES) return kasf_set_error(3, "n_frames must be in [4, 256]");
     if (cfg->neighbour_num < 1 || cfg->neighbour_num > 4) return kasf_set_error(3, "neighbour_num must be 1..4");
     if (cfg->neighbour_num != 4) return kasf_set_error(3, "neighbour_num != 4 is not wired through yet");
     if (cfg->dtype != KASF_F32 && cfg->dtype != KASF_BF16) return kasf_set_error(3, "dtype must be KASF_DTYPE_F32 or KASF_DTYPE_BF16");
@@ -796,7 +798,7 @@ int kasf_tta_merge(const float* pred, const float* pred_of_flipped, float* out, 
 int kasf_eval_metrics(const float* pred, const float* label_scaled, const float* factor, const float* res, const int32_t* action, int32_t batch,
                       int32_t n_frames, int32_t n_actions, float* mpjpe, float* p_mpjpe, float* accel, float* jpe, double* action_sums, void* stream) {
     if (!pred || !label_scaled || !factor || !res || !mpjpe || !p_mpjpe || !accel || !jpe) return kasf_set_error(2, "null pointer argument");
-    if (n_frames < 3 || n_frames > 128) return kasf_set_error(2, "eval_metrics: n_frames must be in [3,128]");
+    if (n_frames < 3 || n_frames > 256) return kasf_set_error(2, "eval_metrics: n_frames must be in [3,256]");
     if ((action == nullptr) != (action_sums == nullptr)) return kasf_set_error(2, "eval_metrics: action and action_sums go together");
     kasf_launch_eval_metrics((hipStream_t)stream, pred, label_scaled, factor, res, action, batch, n_frames, n_actions, mpjpe, p_mpjpe, accel, jpe, action_sums);
     HIPCHK(hipGetLastError());

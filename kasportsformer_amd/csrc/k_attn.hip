@@ -65,35 +65,39 @@ __device__ __forceinline__ void stage_group(float* s, const T* src, int64_t ld, 
 // miscomputed): every pass recomputes the 16-wide dot products from LDS.
 template <typename T>
 __global__ __launch_bounds__(256) void k_attn_fwd(const T* __restrict__ Q, int64_t ldq, const T* __restrict__ K, const T* __restrict__ V, int64_t ldkv,
-                                                  T* __restrict__ O, int L, int Tn, int mode) {
+                                                  T* __restrict__ O, int L, int Tn, int mode, int HP) {
+    const int W = HP * 16;                        // HP heads at a time (8 unless the track is too long for K and V of all heads to fit LDS)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sK = reinterpret_cast<float*>(smem);
-    float* sV = sK + L * 128;
+    float* sV = sK + L * W;
     const int G = blockIdx.x;
-    stage_group<T>(sK, K, ldkv, G, L, Tn, mode, 0, 8, 1.0f);
-    stage_group<T>(sV, V, ldkv, G, L, Tn, mode, 0, 8, 1.0f);
-    __syncthreads();
-    for (int item = threadIdx.x; item < L * 8; item += blockDim.x) {
-        const int i = item >> 3, h = item & 7;
-        const int64_t tok = tok_of(G, i, Tn, mode);
-        float q[16];
-        load16(Q + tok * ldq + h * 16, q);
+    for (int h0 = 0; h0 < 8; h0 += HP) {
+        __syncthreads();
+        stage_group<T>(sK, K, ldkv, G, L, Tn, mode, h0, HP, 1.0f);
+        stage_group<T>(sV, V, ldkv, G, L, Tn, mode, h0, HP, 1.0f);
+        __syncthreads();
+        for (int item = threadIdx.x; item < L * HP; item += blockDim.x) {
+            const int i = item / HP, h = item % HP;
+            const int64_t tok = tok_of(G, i, Tn, mode);
+            float q[16];
+            load16(Q + tok * ldq + (h0 + h) * 16, q);
 #pragma unroll
-        for (int d = 0; d < 16; ++d) q[d] *= 0.25f;
-        float mx = -INFINITY;
-        for (int j = 0; j < L; ++j) mx = fmaxf(mx, dot16(q, sK + j * 128 + h * 16));
-        float sum = 0.f, o[16];
+            for (int d = 0; d < 16; ++d) q[d] *= 0.25f;
+            float mx = -INFINITY;
+            for (int j = 0; j < L; ++j) mx = fmaxf(mx, dot16(q, sK + j * W + h * 16));
+            float sum = 0.f, o[16];
 #pragma unroll
-        for (int d = 0; d < 16; ++d) o[d] = 0.f;
-        for (int j = 0; j < L; ++j) {
-            const float e = __expf(dot16(q, sK + j * 128 + h * 16) - mx);
-            sum += e;
-            axpy16(o, e, sV + j * 128 + h * 16);
+            for (int d = 0; d < 16; ++d) o[d] = 0.f;
+            for (int j = 0; j < L; ++j) {
+                const float e = __expf(dot16(q, sK + j * W + h * 16) - mx);
+                sum += e;
+                axpy16(o, e, sV + j * W + h * 16);
+            }
+            const float inv = 1.0f / sum;
+#pragma unroll
+            for (int d = 0; d < 16; ++d) o[d] *= inv;
+            store16(O + tok * 128 + (h0 + h) * 16, o);
         }
-        const float inv = 1.0f / sum;
-#pragma unroll
-        for (int d = 0; d < 16; ++d) o[d] *= inv;
-        store16(O + tok * 128 + h * 16, o);
     }
 }
 
@@ -173,12 +177,14 @@ template <typename K> void set_smem(K k, size_t bytes) {
 template <typename T>
 void fwd_T(hipStream_t s, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, void* o, int B, int Tn, int mode) {
     const int L = mode == 0 ? KASF_J : Tn, groups = mode == 0 ? B * Tn : B * KASF_J;
-    const size_t sh = (size_t)2 * L * 128 * sizeof(float);
-    if (sh > 160 * 1024) { kasf_set_error(3, "attention: n_frames too large for the LDS-resident kernel (max 160)"); return; }
-    int threads = ((L * 8 + 63) / 64) * 64;
+    int HP = 8;
+    auto bytes = [&](int hp) { return (size_t)2 * L * hp * 16 * sizeof(float); };
+    while (HP > 1 && bytes(HP) > 128 * 1024) HP >>= 1;
+    if (bytes(HP) > 160 * 1024) { kasf_set_error(3, "attention: n_frames too large for the LDS-resident kernel"); return; }
+    int threads = ((L * HP + 63) / 64) * 64;
     if (threads > 256) threads = 256;
-    set_smem(k_attn_fwd<T>, sh);
-    hipLaunchKernelGGL(k_attn_fwd<T>, dim3(groups), dim3(threads), sh, s, (const T*)q, ldq, (const T*)k, (const T*)v, ldkv, (T*)o, L, Tn, mode);
+    set_smem(k_attn_fwd<T>, bytes(HP));
+    hipLaunchKernelGGL(k_attn_fwd<T>, dim3(groups), dim3(threads), bytes(HP), s, (const T*)q, ldq, (const T*)k, (const T*)v, ldkv, (T*)o, L, Tn, mode, HP);
 }
 template <typename T>
 void bwd_T(hipStream_t s, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, const void* d_o, void* dq, int64_t lddq, void* dk,

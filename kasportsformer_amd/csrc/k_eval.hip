@@ -92,7 +92,7 @@ __device__ inline void jacobi3(double A[3][3], double V[3][3]) {
     }
 }
 
-constexpr int EV_THR = 128;            // >= T (81)
+constexpr int EV_THR = 256;            // >= T: one thread per frame
 constexpr int EV_COLS = 22;            // mpjpe, p_mpjpe, accel, jpe[17], frames, accel frames
 
 // One workgroup per clip.  pred [B,T,17,3] normalised model output; label_scaled [B,T,17,3] (mm); factor [B,T]; res [B,2] = (w,h);

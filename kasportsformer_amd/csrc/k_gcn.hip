@@ -17,7 +17,7 @@ struct SkelTable { int nb[KASF_J][4]; float coef[KASF_J][4]; };
 __constant__ SkelTable c_skel;
 
 constexpr int COEF_LD = 8;      // per node: scale, shift, mean, rstd, c1, c2, -, -
-constexpr int MASK_W = 3;       // 32-bit words per adjacency row (T <= 96)
+constexpr int MASK_W = 3;       // 32-bit words per adjacency row of the T <= 96 instantiations (any T: kasf_gcn_mask_words)
 constexpr int SX_LD = 132;      // padded fp32 row of the temporal tiles
 
 // Batch statistics are accumulated in KASF_STAT_SLOTS copies ([slot][96 nodes][2] doubles, slot = workgroup index mod slots): a thousand
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void k_gcn_apply(const T* __restrict__ x_in, c
                                                    float* __restrict__ run_mean, float* __restrict__ run_var, float* __restrict__ coef,
                                                    const float* __restrict__ ls1, T* __restrict__ out, int64_t M, int Tn, int mode, int nodes, double count,
                                                    int training, float momentum) {
-    __shared__ float sC[96][2];
+    __shared__ float sC[KASF_MAX_NODES][2];
     if ((int)threadIdx.x < nodes) {
         const int n = threadIdx.x;
         float scale, shift, mean, rstd, varu;
@@ -245,9 +245,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_gcn_bwd1(const T* __restrict__ g, const T* __restrict__ xn, const T* __restrict__ y, const float* __restrict__ coef,
                                                   const float* __restrict__ ls1, T* __restrict__ rbuf, float* __restrict__ dls1,
                                                   double* __restrict__ bstats, int64_t M, int Tn, int mode, int nodes) {
-    __shared__ float sStat[96 * 2];
+    __shared__ float sStat[KASF_MAX_NODES * 2];
     __shared__ float sRed[16 * 128];
-    if (threadIdx.x < 2 * nodes) sStat[threadIdx.x] = 0.f;
+    for (int idx = threadIdx.x; idx < 2 * nodes; idx += 256) sStat[idx] = 0.f;
     __syncthreads();
     const int sub = threadIdx.x & 15, rl = threadIdx.x >> 4;
     float ls[8], dls[8];
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void k_gcn_bwd1(const T* __restrict__ g, const
         for (int k = 0; k < 16; ++k) s += sRed[k * 128 + threadIdx.x];
         atomicAdd(dls1 + threadIdx.x, s);
     }
-    if (threadIdx.x < 2 * nodes) atomicAdd(stat_slot(bstats) + threadIdx.x, (double)sStat[threadIdx.x]);
+    for (int idx = threadIdx.x; idx < 2 * nodes; idx += 256) atomicAdd(stat_slot(bstats) + idx, (double)sStat[idx]);
 }
 
 // dy of one 8-channel chunk: BN backward with the finalised per-node means
@@ -324,7 +324,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_gcn_bwd2_spatial(const T* __restrict__ rbuf, const T* __restrict__ y, const float* __restrict__ coefg,
                                                           T* __restrict__ duv, int64_t M, const double* __restrict__ bstats, float* __restrict__ d_w,
                                                           float* __restrict__ d_b, int nodes, double count, int training) {
-    __shared__ float coef[96 * C2_LD];
+    __shared__ float coef[KASF_MAX_NODES * C2_LD];
     bwd2_prologue(coef, coefg, bstats, d_w, d_b, nodes, count, training);
     const int sub = threadIdx.x & 15;
     for (int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x; item < M * 16; item += (int64_t)gridDim.x * 256) {
@@ -354,7 +354,7 @@ template <typename T, int L>
 __global__ __launch_bounds__(256) void k_gcn_bwd2_temporal(const T* __restrict__ rbuf, const T* __restrict__ y, const float* __restrict__ coefg,
                                                            const uint32_t* __restrict__ mask, T* __restrict__ duv, int Tn, const double* __restrict__ bstats,
                                                            float* __restrict__ d_w, float* __restrict__ d_b, int nodes, double count, int training) {
-    __shared__ float coef[96 * C2_LD];
+    __shared__ float coef[KASF_MAX_NODES * C2_LD];
     bwd2_prologue(coef, coefg, bstats, d_w, d_b, nodes, count, training);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sDy = reinterpret_cast<float*>(smem);        // [L][SX_LD]
@@ -387,6 +387,149 @@ __global__ __launch_bounds__(256) void k_gcn_bwd2_temporal(const T* __restrict__
                 const float w = sDinv[r] * sDinv[c];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) acc[e] += w * sDy[r * SX_LD + sub * 8 + e];
+            }
+        }
+        store8(duv + tok(c) * 256 + 128 + sub * 8, acc);
+    }
+}
+
+// ------------------------------------------------------------------ temporal aggregate / backward for ANY number of frames (4 <= T <= 256)
+// The instantiations above keep the whole T x T similarity matrix of a track in LDS, which stops fitting near T = 100.  Here S is produced 16
+// rows at a time (same MFMA products, same k order: still bitwise symmetric), the row's threshold / mask / degree are taken from that
+// block, and only the masks (T x MW words) and degrees of the whole track stay resident; the LN(x) tile is then overwritten by the V rows
+// for the aggregation.  One thread scans one row: a plain fallback (T = 243 and friends), not a tuned kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void k_gcn_agg_temporal_g(const T* __restrict__ uv, const T* __restrict__ xn, T* __restrict__ y,
+                                                            uint32_t* __restrict__ mask, double* __restrict__ stats, int L, int MW, int kth, int n_tracks) {
+    constexpr int EPC = Tile<T>::EPC, CPR = Tile<T>::CPR;
+    const int LP = (L + 15) / 16 * 16, NTL = LP / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* sX = reinterpret_cast<T*>(smem);                 // [LP][128] swizzled LN(x) rows, later [L][128] linear V rows
+    float* sS = reinterpret_cast<float*>(sX + LP * 128);   // [16][LP+1] one row block of the similarity
+    float* sDinv = sS + 16 * (LP + 1);                  // [L]
+    float* sStat = sDinv + LP;                          // [L][2]
+    uint32_t* sMask = reinterpret_cast<uint32_t*>(sStat + 2 * LP);   // [L][MW]
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
+    for (int idx = threadIdx.x; idx < 2 * L; idx += 256) sStat[idx] = 0.f;
+    for (int G = blockIdx.x; G < n_tracks; G += gridDim.x) {
+        const int b = G / KASF_J, j = G % KASF_J;
+        auto tok = [&](int r) { return ((int64_t)b * L + r) * KASF_J + j; };
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < LP * CPR; idx += 256) {
+            const int r = idx / CPR, ch = idx % CPR;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (r < L) v = *reinterpret_cast<const f32x4*>(xn + tok(r) * 128 + ch * EPC);
+            *reinterpret_cast<f32x4*>(sX + Tile<T>::chunk_off(r, ch)) = v;
+        }
+        __syncthreads();
+        for (int rb = 0; rb < NTL; ++rb) {
+            for (int tn = w; tn < NTL; tn += 4) {
+                f32x4 acc[1][1];
+                zero_acc(acc);
+                mma_k128<1, 1>(sX, tn * 16, sX, rb * 16, acc);      // acc[q] = S[row rb*16 + li][col tn*16 + 4*lg + q]
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sS[li * (LP + 1) + tn * 16 + 4 * lg + q] = acc[0][0][q];
+            }
+            __syncthreads();
+            const int r = rb * 16 + (int)threadIdx.x;
+            if (threadIdx.x < 16 && r < L) {
+                const float* row = sS + threadIdx.x * (LP + 1);
+                float top[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                for (int c = 0; c < L; ++c) {
+                    float v = row[c];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (v > top[e]) { const float t = top[e]; top[e] = v; v = t; }
+                    }
+                }
+                const float thr = kth <= 1 ? top[0] : (kth == 2 ? top[1] : (kth == 3 ? top[2] : top[3]));
+                int deg = 0;
+                for (int wi = 0; wi < MW; ++wi) {
+                    uint32_t wd = 0u;
+                    for (int c = wi * 32; c < L && c < wi * 32 + 32; ++c)
+                        if (row[c] >= thr) { wd |= 1u << (c & 31); ++deg; }
+                    sMask[r * MW + wi] = wd;
+                    mask[((int64_t)G * L + r) * MW + wi] = wd;
+                }
+                sDinv[r] = 1.0f / sqrtf((float)deg);
+            }
+            __syncthreads();
+        }
+        for (int idx = threadIdx.x; idx < L * CPR; idx += 256) {     // the similarity is done with LN(x): the tile now holds the V rows (linear)
+            const int r = idx / CPR, ch = idx % CPR;
+            *reinterpret_cast<f32x4*>(sX + r * 128 + ch * EPC) = *reinterpret_cast<const f32x4*>(uv + tok(r) * 256 + 128 + ch * EPC);
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < L * 16; idx += 256) {
+            const int r = idx >> 4, sub = idx & 15;
+            float acc[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+            const float dr = sDinv[r];
+            for (int wi = 0; wi < MW; ++wi) {
+                uint32_t bits = sMask[r * MW + wi];
+                while (bits) {
+                    const int c = wi * 32 + __builtin_ctz(bits);
+                    bits &= bits - 1;
+                    const float wgt = dr * sDinv[c];
+                    float v[8];
+                    load8(sX + c * 128 + sub * 8, v);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e] += wgt * v[e];
+                }
+            }
+            float u[8];
+            load8(uv + tok(r) * 256 + sub * 8, u);
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { acc[e] += u[e]; const float q = to_f(from_f<T>(acc[e])); s1 += q; s2 += q * q; }
+            store8(y + tok(r) * 128 + sub * 8, acc);
+            s1 = reduce16(s1);
+            s2 = reduce16(s2);
+            if (sub == 0) { atomicAdd(&sStat[r * 2], s1); atomicAdd(&sStat[r * 2 + 1], s2); }
+        }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 2 * L; idx += 256) atomicAdd(stat_slot(stats) + idx, (double)sStat[idx]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_gcn_bwd2_temporal_g(const T* __restrict__ rbuf, const T* __restrict__ y, const float* __restrict__ coefg,
+                                                             const uint32_t* __restrict__ mask, T* __restrict__ duv, int L, int MW,
+                                                             const double* __restrict__ bstats, float* __restrict__ d_w, float* __restrict__ d_b, double count,
+                                                             int training) {
+    __shared__ float coef[KASF_MAX_NODES * C2_LD];
+    bwd2_prologue(coef, coefg, bstats, d_w, d_b, L, count, training);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sDy = reinterpret_cast<float*>(smem);        // [L][SX_LD]
+    float* sDinv = sDy + L * SX_LD;
+    uint32_t* sMask = reinterpret_cast<uint32_t*>(sDinv + L);
+    const int G = blockIdx.x, b = G / KASF_J, j = G % KASF_J;
+    auto tok = [&](int r) { return ((int64_t)b * L + r) * KASF_J + j; };
+    for (int idx = threadIdx.x; idx < L * 16; idx += 256) {
+        const int r = idx >> 4, sub = idx & 15;
+        float dy[8];
+        dy_chunk(rbuf, y, coef, tok(r), r, sub, dy);
+        store8(duv + tok(r) * 256 + sub * 8, dy);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sDy[r * SX_LD + sub * 8 + e] = dy[e];
+    }
+    for (int r = threadIdx.x; r < L; r += 256) {
+        int deg = 0;
+        for (int e = 0; e < MW; ++e) { const uint32_t wd = mask[((int64_t)G * L + r) * MW + e]; sMask[r * MW + e] = wd; deg += __popc(wd); }
+        sDinv[r] = 1.0f / sqrtf((float)deg);
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < L * 16; idx += 256) {
+        const int c = idx >> 4, sub = idx & 15;
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        for (int r = 0; r < L; ++r) {
+            if ((sMask[r * MW + (c >> 5)] >> (c & 31)) & 1u) {
+                const float wgt = sDinv[r] * sDinv[c];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += wgt * sDy[r * SX_LD + sub * 8 + e];
             }
         }
         store8(duv + tok(c) * 256 + 128 + sub * 8, acc);
@@ -431,7 +574,14 @@ void agg_fwd_T(hipStream_t s, const void* uv, const void* xn, void* y, uint32_t*
     } else if (Tn == 27) agg_temporal_TL<T, 27>(s, uv, xn, y, mask, stats, B, Tn);
     else if (Tn == 81) agg_temporal_TL<T, 81>(s, uv, xn, y, mask, stats, B, Tn);
     else if (Tn == 9) agg_temporal_TL<T, 9>(s, uv, xn, y, mask, stats, B, Tn);
-    else kasf_set_error(3, "temporal GCN: n_frames must be one of 9, 27, 81");
+    else {
+        const int LP = (Tn + 15) / 16 * 16, MW = kasf_gcn_mask_words(Tn);
+        const size_t sh = (size_t)LP * 128 * sizeof(T) + (size_t)(16 * (LP + 1) + 3 * LP) * sizeof(float) + (size_t)Tn * MW * sizeof(uint32_t);
+        set_smem(k_gcn_agg_temporal_g<T>, sh);
+        const int tracks = B * KASF_J, per = (tracks + 1023) / 1024;
+        hipLaunchKernelGGL((k_gcn_agg_temporal_g<T>), dim3((tracks + per - 1) / per), dim3(256), sh, s, (const T*)uv, (const T*)xn, (T*)y, mask, stats, Tn, MW, 4,
+                           tracks);
+    }
 }
 template <typename T>
 void bwd2_T(hipStream_t s, const void* r, const void* y, const float* coef, const uint32_t* mask, void* duv, int B, int Tn, int mode, const double* bstats,
@@ -442,7 +592,13 @@ void bwd2_T(hipStream_t s, const void* r, const void* y, const float* coef, cons
     else if (Tn == 27) bwd2_temporal_TL<T, 27>(s, r, y, coef, mask, duv, B, Tn, bstats, d_w, d_b, count, training);
     else if (Tn == 81) bwd2_temporal_TL<T, 81>(s, r, y, coef, mask, duv, B, Tn, bstats, d_w, d_b, count, training);
     else if (Tn == 9) bwd2_temporal_TL<T, 9>(s, r, y, coef, mask, duv, B, Tn, bstats, d_w, d_b, count, training);
-    else kasf_set_error(3, "temporal GCN: n_frames must be one of 9, 27, 81");
+    else {
+        const int MW = kasf_gcn_mask_words(Tn);
+        const size_t sh = (size_t)(Tn * SX_LD + Tn) * sizeof(float) + (size_t)Tn * MW * sizeof(uint32_t);
+        set_smem(k_gcn_bwd2_temporal_g<T>, sh);
+        hipLaunchKernelGGL((k_gcn_bwd2_temporal_g<T>), dim3(B * KASF_J), dim3(256), sh, s, (const T*)r, (const T*)y, coef, mask, (T*)duv, Tn, MW, bstats, d_w,
+                           d_b, count, training);
+    }
 }
 
 }  // namespace

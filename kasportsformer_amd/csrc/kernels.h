@@ -60,9 +60,12 @@ void kasf_launch_mlp_bwd_q(hipStream_t s, const void* x, const void* xn, const v
                            float* dgamma, float* dbeta, int64_t M, const float* W2 = nullptr, const float* b2 = nullptr, const float* ls2 = nullptr,
                            float* dls2 = nullptr);   // W2/b2/ls2/dls2 (fp32 masters): also finish fc2 (dls2, scaled dW2, db2 = ls2 * gsum in place)
 // bf16 forward with all weights resident in registers (persistent workgroups)
-// BatchNorm batch-statistics buffers: KASF_STAT_SLOTS copies of [96 nodes][2] doubles (k_gcn.hip: producers pick a copy by workgroup index)
+// BatchNorm batch-statistics buffers: KASF_STAT_SLOTS copies of [KASF_MAX_NODES][2] doubles (k_gcn.hip: producers pick a copy by workgroup index)
 #define KASF_STAT_SLOTS 4
-#define KASF_STAT_LD 192
+#define KASF_MAX_NODES 256                 // BatchNorm1d channels = joints (17) or frames: n_frames <= 256
+#define KASF_STAT_LD (2 * KASF_MAX_NODES)
+// 32-bit words per row of the stored temporal adjacency (bit c of word c >> 5 = "frame c is a neighbour")
+inline int kasf_gcn_mask_words(int n_frames) { return n_frames <= 96 ? 3 : (n_frames + 31) / 32; }
 
 void kasf_launch_mlp_fwd_r(hipStream_t s, const void* x, const float* ln_g, const float* ln_b, const void* W1, const float* b1, const void* W2,
                            const float* b2, const float* ls2, void* out, int64_t M, void* xn_out);

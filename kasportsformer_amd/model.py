@@ -107,8 +107,8 @@ class KASportsFormer(nn.Module):
             unsupported.append("use_layer_scale=False / qkv_bias / qkv_scale / hierarchical / use_temporal_similarity=False")
         if num_heads != 8:
             unsupported.append("num_heads != 8 (configs/*.yaml:84)")
-        if neighbour_num != 4 or n_frames not in (9, 27, 81):
-            unsupported.append("neighbour_num != 4 or n_frames not in {9, 27, 81}")
+        if neighbour_num != 4 or not 4 <= n_frames <= 256:
+            unsupported.append("neighbour_num != 4 or n_frames outside [4, 256]")
         if unsupported:
             raise NotImplementedError("kasportsformer_amd builds the shipped configuration only; unsupported: " + "; ".join(unsupported))
         if compute_dtype not in ("bf16", "fp32"):

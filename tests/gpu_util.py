@@ -54,8 +54,10 @@ def oracle_stage_hooks(oracle):
 
 
 def decode_masks(words: torch.Tensor, G: int, T: int) -> torch.Tensor:
-    """[G*T*3] uint32 words (kasf_ws_entry 'adj_mask': row r of track g at ((g*T + r)*3 + w), bit c of word c>>5) -> bool [G,T,T]."""
-    w = words.cpu().view(G, T, 3).to(torch.int64) & 0xFFFFFFFF
+    """[G*T*MW] uint32 words (kasf_ws_entry 'adj_mask': row r of track g at ((g*T + r)*MW + w), bit c of word c>>5; MW = 3 up to 96 frames,
+    ceil(T/32) beyond) -> bool [G,T,T]."""
+    mw = 3 if T <= 96 else (T + 31) // 32
+    w = words.cpu().view(G, T, mw).to(torch.int64) & 0xFFFFFFFF
     cols = torch.arange(T)
     return ((w[:, :, (cols >> 5)] >> (cols & 31)) & 1).bool()
 
@@ -89,9 +91,12 @@ class forced_adjacency:
         forced = self.masks[self.calls % self.L]
         self.calls += 1
         sim = g.detach() @ g.detach().transpose(1, 2)
-        top = sim.topk(k + 1, dim=-1)[0]
+        top = sim.topk(min(k + 1, sim.shape[-1]), dim=-1)[0]
         natural = sim >= top[..., k - 1:k]
-        near = (top[..., k - 1] - top[..., k]).abs() <= self.near_tie * sim.abs().amax(dim=-1)
+        if sim.shape[-1] > k:
+            near = (top[..., k - 1] - top[..., k]).abs() <= self.near_tie * sim.abs().amax(dim=-1)
+        else:                                                  # exactly k frames: every frame is a neighbour, nothing to tie with
+            near = torch.zeros(sim.shape[:-1], dtype=torch.bool)
         bad = (natural != forced).any(dim=-1)
         self.rows += bad.numel(); self.mismatched += int(bad.sum()); self.unexplained += int((bad & ~near).sum())
         self.bits += natural.numel(); self.bits_equal += int((natural == forced).sum())

@@ -418,7 +418,7 @@ def _mask_agreement(cd, L, T, B, seed):
     return rows, mismatched, near_tie_rows, unexplained, 100.0 * bits_equal / bits
 
 
-@pytest.mark.parametrize("L,T,B", [(2, 27, 3), (1, 81, 2), (1, 9, 4)])
+@pytest.mark.parametrize("L,T,B", [(2, 27, 3), (1, 81, 2), (1, 9, 4), (1, 243, 1), (1, 100, 1), (1, 5, 2)])
 def test_temporal_topk_adjacency_masks_fp32_bit_exact(L, T, B):
     """fp32 mode: the stored adjacency bit masks equal torch's `sim >= topk(sim, 4)[..., -1:]` (graph.py:104-112) row for row.  The only rows
     allowed to differ are exact near-ties of the ORACLE's own similarities (4th and 5th largest within summation-order noise)."""
@@ -504,3 +504,46 @@ def test_full_depth_26_layers_against_oracle(cd):
         assert err < 1e-3 and max(drift) < 1e-3 and cosine > 0.99999 and abs(loss.item() - l_ref.item()) < 1e-4 * max(1.0, abs(l_ref.item()))
     else:   # bf16: activations are re-rounded to bf16 by every one of the 156 blocks; observed 0.105 / 0.958 with O(1) layer scales.  Bars = observed x 2
         assert err < 0.2 and cosine > 0.92
+
+
+@pytest.mark.parametrize("T,B", [(243, 1), (100, 2), (33, 2), (5, 3), (4, 2)])
+@pytest.mark.parametrize("cd,tol", [("fp32", 2e-3), ("bf16", 0.5)])
+def test_arbitrary_clip_lengths(cd, tol, T, B):
+    """The reference builds for any n_frames (KASportsFormer.py:291-295, README.md:59): 243 is the long configuration of this model family;
+    100 is past the MFMA attention cores (<= 96), 33 past the fused attention block (<= 32), 5 and 4 are the shortest clips whose rows
+    still have four similarities to pick from (torch.topk(k=4) raises below that).  Forward, loss and every gradient against the oracle
+    following the same neighbour decisions (tests/gpu_util.py forced_adjacency)."""
+    oracle, model = make_pair(1, T, cd)
+    x, y = O.synthetic_clips(B, T, seed=7)
+    oracle.train(); model.train()
+    with forced_adjacency(model, x) as fa:
+        ref = oracle(x)
+        l_ref, _ = O.loss_total(ref, y)
+        l_ref.backward()
+    pred = model(x.cuda())
+    loss, _ = O.loss_total(pred, y.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    err = _abs_err(pred, ref) / max(1.0, float(ref.abs().max()))
+    assert err < (1e-3 if cd == "fp32" else 0.12), err
+    if cd == "fp32":
+        assert fa.unexplained == 0, fa.summary()
+    ref_grads = dict(oracle.named_parameters())
+    gmax = max(float(q.grad.abs().max()) for q in ref_grads.values() if q.grad is not None)
+    bad, dots = [], [0.0, 0.0, 0.0]
+    for n, p in model.named_parameters():
+        r = ref_grads[n].grad
+        assert (r is None) == (p.grad is None), n
+        if r is None:
+            continue
+        g = p.grad.detach().double().cpu()
+        e = float((g - r.double()).abs().max() / max(float(r.abs().max()), (1e-3 if cd == "fp32" else 0.05) * gmax))
+        dots[0] += float((g * r.double()).sum()); dots[1] += float((g * g).sum()); dots[2] += float((r.double() ** 2).sum())
+        if not e < tol:
+            bad.append((e, n))
+    cosine = dots[0] / (dots[1] ** 0.5 * dots[2] ** 0.5)
+    assert cosine > (0.999999 if cd == "fp32" else 0.995), cosine
+    assert not bad, sorted(bad, reverse=True)[:8]
+    model.eval()
+    with torch.no_grad():
+        assert torch.isfinite(model(x.cuda())).all()
