@@ -72,7 +72,7 @@ def kernel_rooflines(M):
     xn = torch.empty_like(x)
     fwd = lambda: lib.kasf_op_mlp_fwd(1, p(x), p(gam), p(bet), p(w1), p(b1), p(w2), p(b2), p(ls), p(out), M, p(xn), st())    # training-mode forward: also stores LN(x)
     dap = torch.empty(4 * M * 128, device=dev, dtype=bf)
-    part2 = torch.empty(2 * 64 * 65536, device=dev)
+    part2 = torch.empty(2 * 64 * 65536 + 2048, device=dev)
     # the engine's bf16 backward: data gradient + both weight gradients + LayerNorm backward in k_mlp_bwd_s / k_lnbwd_sum4 / k_mlp_wfinish
     bwd = lambda: lib.kasf_op_mlp_bwd_fused(p(x), p(xn), p(gout), p(gam), p(w1), p(b1), p(w2ts), p(w1t), p(dap), p(part2), p(dW1), p(dW2), p(db1),
                                             p(gs), p(gin), p(dg), p(db), M, st())

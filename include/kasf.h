@@ -55,6 +55,10 @@ int kasf_version(void);
 int kasf_model_create(const kasf_config* cfg, kasf_model** out);
 void kasf_model_destroy(kasf_model* m);
 
+/* 0 = healthy.  Non-zero: a kernel's bounded wait on another workgroup ran out (the affected gradient rows were poisoned with NaN instead of
+ * hanging the GPU); blocking device read -- for tests and post-mortems, not for the step loop. */
+int kasf_model_status(const kasf_model* m, int32_t* status);
+
 /* ---- parameter / buffer layout: one flat fp32 array each; entries carry the reference's state_dict names ---- */
 int64_t kasf_param_count(const kasf_model* m);       /* elements of the flat parameter (and gradient) array, multiple of 4 */
 int64_t kasf_param_live_count(const kasf_model* m);  /* [0, live) receive gradients; [live, count) are the never-used norm1_limb */
@@ -133,7 +137,8 @@ int kasf_op_mlp_bwd(int32_t dtype, const void* x, const void* g, const float* ln
 /* bf16 only: fused MLP backward (hidden-quarter ownership, weights in registers): data gradient AND both weight gradients.
  * g_in = g + LNbwd(dA); dw1 [512,128] += dZ^T LN(x); db1 [512] += colsum(dZ); dw2_unscaled [128,512] += g^T H;
  * gsum [128] += colsum(g); dgamma/dbeta += LayerNorm parameter gradients.  dapart: 4*M*128 elements of scratch (bf16);
- * partial: >= 2*64*65536 floats of scratch. */
+ * partial: >= 2*64*65536 + 2048 floats of scratch (the tail holds the inter-workgroup hand-off flags; word 2*64*65536 + 1024 is set to 1 if a
+ * bounded wait ran out). */
 int kasf_op_mlp_bwd_fused(const void* x, const void* xn /* LN(x) from kasf_op_mlp_fwd */, const void* g, const float* ln_g, const void* w1, const float* b1, const void* w2t_scaled,
                           const void* w1t, void* dapart, float* partial, float* dw1, float* dw2_unscaled, float* db1, float* gsum, void* g_in,
                           float* dgamma, float* dbeta, int64_t M, void* stream);

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libkasf_hip.so")
 DTYPE_F32, DTYPE_BF16 = 0, 1
 FLAG_TRAIN, FLAG_RETURN_REP, FLAG_KEEP = 1, 2, 4
 EVAL_COLS = 22
-ABI_VERSION = 2          # kasf_version() of the library these prototypes describe (a stale in-tree .so is refused)
+ABI_VERSION = 3          # kasf_version() of the library these prototypes describe (a stale in-tree .so is refused)
 
 
 class KasfConfig(C.Structure):
@@ -35,6 +35,7 @@ SIGNATURES = {
     "kasf_version": (_i32, []),
     "kasf_model_create": (_i32, [C.POINTER(KasfConfig), C.POINTER(_vp)]),
     "kasf_model_destroy": (None, [_vp]),
+    "kasf_model_status": (_i32, [_vp, _pi32]),
     "kasf_param_count": (_i64, [_vp]),
     "kasf_param_live_count": (_i64, [_vp]),
     "kasf_param_entries": (_i32, [_vp]),

@@ -38,7 +38,7 @@ static bool single_stream() {
     static const bool v = getenv("KASF_SINGLE_STREAM") != nullptr;
     return v;
 }
-constexpr int64_t WG_PARTIAL_FLOATS = 2 * 64 * 65536;       // per-split weight-gradient tiles: 256 workgroups x 128x128, or 64 ranges x (dW1 + dW2) of the MLP
+constexpr int64_t WG_PARTIAL_FLOATS = KASF_MLP_PARTIAL_FLOATS + KASF_MLP_FLAG_WORDS;   // per-split weight-gradient tiles: 256 workgroups x 128x128, or 64 ranges x (dW1 + dW2) of the MLP; + its hand-off flags
 
 struct BlkWs { int64_t qkv, kv, o, xn, y, mask, x_mid, xn2, x_out, stats, bstats, coef; };
 struct LayerWs { BlkWs b[6]; int64_t gate_out, alpha; };
@@ -73,6 +73,7 @@ struct kasf_model {
     // branches 1 and 2 fork onto these and join before the gate (pure event fork/join: graph-capture safe)
     hipStream_t side[2] = {nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+    unsigned* d_err = nullptr;       // set by a kernel whose bounded inter-workgroup wait ran out (kasf_model_status)
 };
 
 int kasf_set_error(int code, const char* msg) {
@@ -388,7 +389,7 @@ void block_backward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void*
         // hidden-quarter kernel: dgrad + both weight gradients fused, then the 4-way partial sum + LayerNorm backward
         kasf_launch_mlp_bwd_q(c.s, c.w(w.x_mid), c.w(w.xn2), g_out, P + o.n2w, c.pk(o.p_fc1), P + o.fc1b, c.pk(o.p_fc2Ts), c.pk(o.p_fc1T), c.w(sc.hbuf),
                               (float*)c.w(sc.wg_part), G + o.fc1w, G + o.fc2w, G + o.fc1b, G + o.fc2b, g_mid, G + o.n2w, G + o.n2b, c.M, P + o.fc2w, P + o.fc2b,
-                              P + o.ls2, G + o.ls2);        // includes the fc2 layer-scale finish
+                              P + o.ls2, G + o.ls2, c.m->d_err);        // includes the fc2 layer-scale finish
     } else {
         kasf_launch_mlp_bwd(c.dt, c.s, c.w(w.x_mid), g_out, P + o.n2w, P + o.n2b, c.pk(o.p_fc1), P + o.fc1b, c.pk(o.p_fc2Ts), c.pk(o.p_fc1T), c.w(sc.hbuf),
                             c.w(sc.dzbuf), c.w(sc.xn_a), g_mid, G + o.n2w, G + o.n2b, c.M);
@@ -489,7 +490,7 @@ int check_model(const kasf_model* m) {
 extern "C" {
 
 const char* kasf_last_error(void) { return g_err.c_str(); }
-int kasf_version(void) { return 2; }
+int kasf_version(void) { return 3; }
 
 int kasf_model_create(const kasf_config* cfg, kasf_model** out) {
     if (cfg == nullptr || out == nullptr) return kasf_set_error(2, "null argument");
@@ -507,6 +508,8 @@ int kasf_model_create(const kasf_config* cfg, kasf_model** out) {
     HIPCHK(hipMalloc((void**)&m->d_pack, m->pack.size() * sizeof(KasfPackDesc)));
     HIPCHK(hipMalloc((void**)&m->d_tile_start, m->pack_tile_start.size() * sizeof(int)));
     HIPCHK(hipMalloc((void**)&m->d_pro, sizeof(KasfProOff)));
+    HIPCHK(hipMalloc((void**)&m->d_err, 64));
+    HIPCHK(hipMemset(m->d_err, 0, 64));
     HIPCHK(hipMemcpy(m->d_pack, m->pack.data(), m->pack.size() * sizeof(KasfPackDesc), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(m->d_tile_start, m->pack_tile_start.data(), m->pack_tile_start.size() * sizeof(int), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(m->d_pro, &m->pro, sizeof(KasfProOff), hipMemcpyHostToDevice));
@@ -535,6 +538,7 @@ void kasf_model_destroy(kasf_model* m) {
     if (m->d_pack) (void)hipFree(m->d_pack);
     if (m->d_tile_start) (void)hipFree(m->d_tile_start);
     if (m->d_pro) (void)hipFree(m->d_pro);
+    if (m->d_err) (void)hipFree(m->d_err);
     for (int i = 0; i < 2; ++i) {
         if (m->side[i]) (void)hipStreamDestroy(m->side[i]);
         if (m->ev_join[i]) (void)hipEventDestroy(m->ev_join[i]);
@@ -574,6 +578,15 @@ int kasf_stage_grad_range(const kasf_model* m, int32_t stage, int64_t* begin, in
     if (stage == 0) { *begin = 0; *end = 0; }
     else if (stage <= L) { *begin = m->layers[L - stage].begin; *end = m->layers[L - stage].end; }
     else { *begin = m->top.begin; *end = m->top.end; }
+    return 0;
+}
+
+int kasf_model_status(const kasf_model* m, int32_t* status) {
+    if (check_model(m)) return 2;
+    if (status == nullptr) return kasf_set_error(2, "null argument");
+    unsigned v = 0;
+    if (m->d_err != nullptr) HIPCHK(hipMemcpy(&v, m->d_err, sizeof(v), hipMemcpyDeviceToHost));      // blocking: a debugging / test call, not part of the step
+    *status = (int32_t)v;
     return 0;
 }
 
@@ -684,6 +697,8 @@ int kasf_backward(const kasf_model* m, const float* params, const void* packed, 
         // the running gradient w.r.t. the current layer's output alternates between two buffers
         auto gbuf = [&](int k) { return c.w((k & 1) ? p.g_prev : p.g_layer); };
         if (st == 0) {
+            for (int br = 0; br < 3 && kasf_mlp_bwd_xchg_enabled(); ++br)      // hand-off flags of the experimental fused MLP backward: zero once per pass (every finishing kernel re-zeroes them)
+                HIPCHK(hipMemsetAsync((char*)c.w(p.sc[br].wg_part) + (size_t)KASF_MLP_PARTIAL_FLOATS * 4, 0, (size_t)KASF_MLP_FLAG_WORDS * 4, c.s));
             HIPCHK(hipMemsetAsync(c.w(p.bstats_begin), 0, p.bstats_bytes, c.s));
             HIPCHK(hipMemsetAsync(c.w(p.g_limb), 0, c.M * 128 * c.es, c.s));
             const void* x_final = c.w(p.layers[L - 1].gate_out);
@@ -834,6 +849,8 @@ int kasf_op_mlp_bwd_fused(const void* x, const void* xn, const void* g, const fl
                           const void* w1t, void* dapart, float* partial, float* dw1, float* dw2_unscaled, float* db1, float* gsum, void* g_in,
                           float* dgamma, float* dbeta, int64_t M, void* stream) {
     if (!x || !xn || !g || !dapart || !partial || !dw1 || !dw2_unscaled || !db1 || !gsum || !g_in) return kasf_set_error(2, "null pointer argument");
+    if (kasf_mlp_bwd_xchg_enabled())
+        HIPCHK(hipMemsetAsync(partial + KASF_MLP_PARTIAL_FLOATS, 0, (size_t)KASF_MLP_FLAG_WORDS * 4, (hipStream_t)stream));     // hand-off flags + timeout word
     kasf_launch_mlp_bwd_q((hipStream_t)stream, x, xn, g, ln_g, w1, b1, w2t_scaled, w1t, dapart, partial, dw1, dw2_unscaled, db1, gsum, g_in, dgamma,
                           dbeta, M);
     HIPCHK(hipGetLastError());

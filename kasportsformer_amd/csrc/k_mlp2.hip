@@ -264,6 +264,10 @@ __global__ __launch_bounds__(NW * 64) void k_mlp_bwd_q(const bf16* __restrict__ 
 }
 
 // g_in = g + LNbwd( sum_q dApart[q] ; x, gamma );  dgamma / dbeta block partials -> atomics.  16 lanes per token row.
+// The kernel is pure streaming (6 x 256 B in, 256 B out per token) and used to run at what 8 waves per CU with 96 B in flight per lane can
+// pull (5.5 TB/s): RPT rows per thread are now loaded back to back before any of them is consumed, which doubles the bytes in flight at the
+// same number of workgroups (the grid stays capped: every workgroup ends with 384 same-address atomics).
+template <int RPT>
 __global__ __launch_bounds__(256) void k_lnbwd_sum4(const bf16* __restrict__ dApart, const bf16* __restrict__ X, const bf16* __restrict__ G,
                                                     const float* __restrict__ gamma, bf16* __restrict__ g_in, float* __restrict__ dgamma,
                                                     float* __restrict__ dbeta, float* __restrict__ gsum, int64_t M) {
@@ -272,40 +276,53 @@ __global__ __launch_bounds__(256) void k_lnbwd_sum4(const bf16* __restrict__ dAp
     float gm[8], dg[8], db[8], gsv[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { gm[e] = gamma[sub * 8 + e]; dg[e] = 0.f; db[e] = 0.f; gsv[e] = 0.f; }
-    for (int64_t row = (int64_t)blockIdx.x * 16 + rl; row < M; row += (int64_t)gridDim.x * 16) {
-        float d[8], x[8], t[8];
-        load8(dApart + row * 128 + sub * 8, d);
+    for (int64_t row0 = ((int64_t)blockIdx.x * RPT) * 16 + rl; row0 < M; row0 += (int64_t)gridDim.x * 16 * RPT) {
+        bf16x8 pq[RPT][4], xr[RPT], gr[RPT];
 #pragma unroll
-        for (int qq = 1; qq < 4; ++qq) {
-            load8(dApart + ((int64_t)qq * M + row) * 128 + sub * 8, t);
+        for (int u = 0; u < RPT; ++u) {
+            const int64_t row = row0 + 16 * u;
+            if (row < M) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) d[e] += t[e];
+                for (int qq = 0; qq < 4; ++qq) pq[u][qq] = *reinterpret_cast<const bf16x8*>(dApart + ((int64_t)qq * M + row) * 128 + sub * 8);
+                xr[u] = *reinterpret_cast<const bf16x8*>(X + row * 128 + sub * 8);
+                gr[u] = *reinterpret_cast<const bf16x8*>(G + row * 128 + sub * 8);
+            }
         }
-        load8(X + row * 128 + sub * 8, x);
-        float s = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s += x[e];
-        const float mean = reduce16(s) * (1.0f / 128.0f);
-        float qv = 0.f;
+        for (int u = 0; u < RPT; ++u) {
+            const int64_t row = row0 + 16 * u;
+            if (row >= M) break;                        // uniform over the 16 lanes of a row
+            float d[8], x[8], t[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { x[e] -= mean; qv += x[e] * x[e]; }
-        const float rstd = rsqrtf(reduce16(qv) * (1.0f / 128.0f) + KASF_LN_EPS);
-        float s1 = 0.f, s2 = 0.f;
+            for (int e = 0; e < 8; ++e) {
+                d[e] = ((float)pq[u][0][e] + (float)pq[u][1][e]) + ((float)pq[u][2][e] + (float)pq[u][3][e]);
+                x[e] = (float)xr[u][e];
+                t[e] = (float)gr[u][e];
+            }
+            float s = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            x[e] *= rstd;
-            dg[e] += d[e] * x[e];
-            db[e] += d[e];
-            d[e] *= gm[e];
-            s1 += d[e];
-            s2 += d[e] * x[e];
+            for (int e = 0; e < 8; ++e) s += x[e];
+            const float mean = reduce16(s) * (1.0f / 128.0f);
+            float qv = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { x[e] -= mean; qv += x[e] * x[e]; }
+            const float rstd = rsqrtf(reduce16(qv) * (1.0f / 128.0f) + KASF_LN_EPS);
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                x[e] *= rstd;
+                dg[e] += d[e] * x[e];
+                db[e] += d[e];
+                d[e] *= gm[e];
+                s1 += d[e];
+                s2 += d[e] * x[e];
+            }
+            s1 = reduce16(s1) * (1.0f / 128.0f);
+            s2 = reduce16(s2) * (1.0f / 128.0f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { gsv[e] += t[e]; t[e] += rstd * (d[e] - s1 - x[e] * s2); }      // gsv: colsum(g) for the fc2 bias / layer-scale gradients
+            store8(g_in + row * 128 + sub * 8, t);
         }
-        s1 = reduce16(s1) * (1.0f / 128.0f);
-        s2 = reduce16(s2) * (1.0f / 128.0f);
-        load8(G + row * 128 + sub * 8, t);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { gsv[e] += t[e]; t[e] += rstd * (d[e] - s1 - x[e] * s2); }      // gsv: colsum(g) for the fc2 bias / layer-scale gradients
-        store8(g_in + row * 128 + sub * 8, t);
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) { red[0][rl][sub * 8 + e] = dg[e]; red[1][rl][sub * 8 + e] = db[e]; red[2][rl][sub * 8 + e] = gsv[e]; }
@@ -477,8 +494,11 @@ __global__ __launch_bounds__(F_THR) void k_mlp_fwd_r(const bf16* __restrict__ X,
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_mlp_wfinish(const float* __restrict__ p1, const float* __restrict__ p2, float* __restrict__ dW1,
                                                      float* __restrict__ dW2, int splits, const float* __restrict__ W2, const float* __restrict__ b2,
-                                                     const float* __restrict__ ls, float* __restrict__ gsum_db2, float* __restrict__ dls) {
+                                                     const float* __restrict__ ls, float* __restrict__ gsum_db2, float* __restrict__ dls,
+                                                     unsigned* __restrict__ zero_words, int n_zero) {
     __shared__ f32x4 sHalf[128];
+    if (blockIdx.x == 255)         // the hand-off flags of k_mlp_bwd_s<true> (complete by stream order) are cleared for the next launch on this scratch
+        for (int k = threadIdx.x; k < n_zero; k += 256) zero_words[k] = 0u;
     __shared__ float sDot[2];
     const int lane = threadIdx.x & 127, half = threadIdx.x >> 7;
     const bool second = blockIdx.x >= 128;
@@ -536,6 +556,10 @@ __global__ __launch_bounds__(256) void k_mlp_wfinish(const float* __restrict__ p
 
 }  // namespace
 
+bool kasf_mlp_bwd_xchg_enabled() {
+    static const bool on = getenv("KASF_MLP_BWD_XCHG") != nullptr;
+    return on;
+}
 // scratch needs: dApart = 4*M*128 bf16;  partial >= 2 * ranges * 65536 floats (returned through *ranges_out)
 int kasf_mlp_bwd_q_ranges(int64_t M) {
     const int64_t tiles = (M + Q_BM - 1) / Q_BM;
@@ -544,7 +568,7 @@ int kasf_mlp_bwd_q_ranges(int64_t M) {
 }
 void kasf_launch_mlp_bwd_q(hipStream_t s, const void* x, const void* xn, const void* g, const float* ln_g, const void* W1, const float* b1,
                            const void* W2ts, const void* W1t, void* dApart, float* partial, float* dW1, float* dW2, float* db1, float* gsum, void* g_in,
-                           float* dgamma, float* dbeta, int64_t M, const float* W2, const float* b2, const float* ls2, float* dls2) {
+                           float* dgamma, float* dbeta, int64_t M, const float* W2, const float* b2, const float* ls2, float* dls2, unsigned* err) {
     const int ranges = kasf_mlp_bwd_q_ranges(M);
     const int64_t tiles = (M + Q_BM - 1) / Q_BM;
     const int tpr = (int)((tiles + ranges - 1) / ranges);
@@ -552,6 +576,18 @@ void kasf_launch_mlp_bwd_q(hipStream_t s, const void* x, const void* xn, const v
     float* p1 = partial;
     float* p2 = partial + (int64_t)used * 512 * 128;
     static const bool lockstep = getenv("KASF_MLP_BWD_LOCKSTEP") != nullptr;                          // measurement switch: the symmetric kernel
+    // The in-kernel reduction of the four dA partials (k_mlp_bwd_s<true>) is correct and placement-independent but SLOWER than the
+    // two-kernel chain on the hardware (173 vs 159 us per launch): it stays an opt-in experiment.
+    const bool sum4 = !kasf_mlp_bwd_xchg_enabled();
+    unsigned* flags = reinterpret_cast<unsigned*>(partial + KASF_MLP_PARTIAL_FLOATS);                 // [64 ranges][16] + the timeout word
+    if (!lockstep && !sum4 && M * 1024 < (int64_t(1) << 32)) {        // (the hand-off addresses its [4][M][128] buffer with 32-bit byte offsets)
+        // in-kernel reduction of the four dA partials: no second pass over them.  The flags are zero here: cleared by the engine at the start
+        // of a backward pass / by the op entry point, and by every k_mlp_wfinish for the launch that follows it.
+        kasf_launch_mlp_bwd_x(s, x, xn, g, ln_g, W1, b1, W2ts, W1t, dApart, p1, p2, db1, gsum, g_in, dgamma, dbeta, flags, err ? err : flags + KASF_MLP_ERR_WORD, M,
+                              tpr, used);
+        hipLaunchKernelGGL(k_mlp_wfinish, dim3(256), dim3(256), 0, s, p1, p2, dW1, dW2, used, W2, b2, ls2, gsum, dls2, flags, 16 * used);
+        return;
+    }
     if (!lockstep) {
         kasf_launch_mlp_bwd_s(s, xn, g, W1, b1, W2ts, W1t, dApart, p1, p2, db1, M, tpr, used);
     } else {
@@ -560,12 +596,18 @@ void kasf_launch_mlp_bwd_q(hipStream_t s, const void* x, const void* xn, const v
         hipLaunchKernelGGL(k_mlp_bwd_q<Q_NW>, dim3(4 * used), dim3(Q_NW * 64), sh, s, (const bf16*)xn, (const bf16*)g, (const bf16*)W1, b1, (const bf16*)W2ts,
                            (const bf16*)W1t, (bf16*)dApart, p1, p2, db1, M, tpr);
     }
-    int64_t blocks = (M + 15) / 16;
-    if (blocks > 512) blocks = 512;                     // few blocks: every block ends with 384 same-address atomics (contended atomics serialise)
-    hipLaunchKernelGGL(k_lnbwd_sum4, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16*)dApart, (const bf16*)x, (const bf16*)g, ln_g, (bf16*)g_in, dgamma,
-                       dbeta, gsum, M);
+    static const int rpt = getenv("KASF_SUM4_RPT") ? atoi(getenv("KASF_SUM4_RPT")) : 2;               // measurement switches
+    static const int cap = getenv("KASF_SUM4_BLOCKS") ? atoi(getenv("KASF_SUM4_BLOCKS")) : 512;
+    int64_t blocks = (M + 16 * rpt - 1) / (16 * rpt);
+    if (blocks > cap) blocks = cap;                     // few blocks: every block ends with 384 same-address atomics (contended atomics serialise)
+    if (rpt == 1) hipLaunchKernelGGL(k_lnbwd_sum4<1>, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16*)dApart, (const bf16*)x, (const bf16*)g, ln_g, (bf16*)g_in,
+                                     dgamma, dbeta, gsum, M);
+    else if (rpt == 2) hipLaunchKernelGGL(k_lnbwd_sum4<2>, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16*)dApart, (const bf16*)x, (const bf16*)g, ln_g,
+                                          (bf16*)g_in, dgamma, dbeta, gsum, M);
+    else hipLaunchKernelGGL(k_lnbwd_sum4<4>, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16*)dApart, (const bf16*)x, (const bf16*)g, ln_g, (bf16*)g_in,
+                            dgamma, dbeta, gsum, M);
     // after k_lnbwd_sum4 (gsum complete): both partial reductions + the fc2 layer-scale algebra (W2 == nullptr: dW2 stays unscaled)
-    hipLaunchKernelGGL(k_mlp_wfinish, dim3(256), dim3(256), 0, s, p1, p2, dW1, dW2, used, W2, b2, ls2, gsum, dls2);
+    hipLaunchKernelGGL(k_mlp_wfinish, dim3(256), dim3(256), 0, s, p1, p2, dW1, dW2, used, W2, b2, ls2, gsum, dls2, (unsigned*)nullptr, 0);
 }
 
 void kasf_launch_mlp_fwd_r(hipStream_t s, const void* x, const float* ln_g, const float* ln_b, const void* W1, const float* b1, const void* W2,

@@ -55,10 +55,20 @@ void kasf_launch_mlp_bwd(int dt, hipStream_t s, const void* x, const void* g, co
 // dApart: 4*M*128 bf16 scratch; partial: >= 2*64*65536 floats; dW2 / gsum are the UNSCALED fc2 weight gradient and colsum(g)
 // (finish with kasf_launch_finalize_ls).  Writes g_in = g + LNbwd(dA) and accumulates dgamma/dbeta, dW1, db1.
 // xn = LN(x) as stored by the forward pass.
+// partial layout: [0, KASF_MLP_PARTIAL_FLOATS) per-range weight-gradient tiles, then KASF_MLP_FLAG_WORDS 32-bit words: the hand-off flags of the in-kernel
+// partial reduction ([64 ranges][4 quarters][4 waves], must be ZERO at launch; cleared again by the finishing kernel) and, at KASF_MLP_ERR_WORD, a word
+// that is set to 1 if a bounded wait between workgroups ever ran out (err != nullptr: that word is used instead).
+#define KASF_MLP_PARTIAL_FLOATS (2 * 64 * 65536)
+#define KASF_MLP_FLAG_WORDS 2048
+#define KASF_MLP_ERR_WORD 1024
 void kasf_launch_mlp_bwd_q(hipStream_t s, const void* x, const void* xn, const void* g, const float* ln_g, const void* W1, const float* b1,
                            const void* W2ts, const void* W1t, void* dApart, float* partial, float* dW1, float* dW2, float* db1, float* gsum, void* g_in,
                            float* dgamma, float* dbeta, int64_t M, const float* W2 = nullptr, const float* b2 = nullptr, const float* ls2 = nullptr,
-                           float* dls2 = nullptr);   // W2/b2/ls2/dls2 (fp32 masters): also finish fc2 (dls2, scaled dW2, db2 = ls2 * gsum in place)
+                           float* dls2 = nullptr, unsigned* err = nullptr);   // W2/b2/ls2/dls2 (fp32 masters): also finish fc2 (dls2, scaled dW2, db2 = ls2 * gsum in place)
+bool kasf_mlp_bwd_xchg_enabled();     // KASF_MLP_BWD_XCHG=1: the experimental in-kernel reduction of the dA partials (needs zeroed hand-off flags)
+void kasf_launch_mlp_bwd_x(hipStream_t s, const void* x, const void* xn, const void* g, const float* ln_g, const void* W1, const float* b1, const void* W2ts,
+                           const void* W1t, void* dApart, float* p1, float* p2, float* db1, float* gsum, void* g_in, float* dgamma, float* dbeta, unsigned* flags,
+                           unsigned* err, int64_t M, int tiles_per_range, int used);
 // bf16 forward with all weights resident in registers (persistent workgroups)
 // BatchNorm batch-statistics buffers: KASF_STAT_SLOTS copies of [KASF_MAX_NODES][2] doubles (k_gcn.hip: producers pick a copy by workgroup index)
 #define KASF_STAT_SLOTS 4

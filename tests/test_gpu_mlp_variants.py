@@ -11,8 +11,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_symmetric_mlp_kernels_still_match():
-    env = dict(os.environ, KASF_MLP_FWD_LOCKSTEP="1", KASF_MLP_BWD_LOCKSTEP="1")
+@pytest.mark.parametrize("switches", [{"KASF_MLP_FWD_LOCKSTEP": "1", "KASF_MLP_BWD_LOCKSTEP": "1"}, {"KASF_MLP_BWD_XCHG": "1"}])
+def test_symmetric_mlp_kernels_still_match(switches):
+    env = dict(os.environ, **switches)
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_ops.py"), "-x", "-q", "-m", "gpu", "-k", "mlp"],
                          env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]

@@ -32,7 +32,7 @@ for label, xo in (("with xn store", xn), ("no xn store", None)):
 
 # fused backward (k_mlp_bwd_s): same timers, indices 16..29
 g = torch.randn(M, 128, device=dev).to(bf); w2ts = (torch.randn(512, 128, device=dev) * 0.05).to(bf); w1t = w1.t().contiguous()
-dap = torch.empty(4 * M * 128, device=dev, dtype=bf); part2 = torch.empty(2 * 64 * 65536, device=dev)
+dap = torch.empty(4 * M * 128, device=dev, dtype=bf); part2 = torch.empty(2 * 64 * 65536 + 2048, device=dev)
 dW1 = torch.zeros(512, 128, device=dev); dW2 = torch.zeros(128, 512, device=dev); db1 = torch.zeros(512, device=dev); gs = torch.zeros(128, device=dev)
 gin = torch.empty_like(x); dg_ = torch.zeros(128, device=dev); db_ = torch.zeros(128, device=dev)
 bwd = lambda: lib.kasf_op_mlp_bwd_fused(p(x), p(xn), p(g), p(gam), p(w1), p(b1), p(w2ts), p(w1t), p(dap), p(part2), p(dW1), p(dW2), p(db1), p(gs), p(gin), p(dg_), p(db_), M, st())
