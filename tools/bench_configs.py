@@ -10,7 +10,13 @@ import torch
 import kasportsformer_amd as K
 from oracle import kasf_oracle as O     # synthetic clip recipe only
 
-FWD_GFLOP = {27: 27.44, 81: 85.28}      # SURVEY §8(d), per clip
+class _Flop(dict):
+    """Forward GFLOP per clip: 17 T tokens x (26 layers x (2,252,288 + 3 x 4 T x 128) + head 134,144 + embeddings 2,304)."""
+    def __missing__(self, T):
+        return 17 * T * (26 * (2252288 + 1536 * T) + 136448) / 1e9
+
+
+FWD_GFLOP = _Flop()                     # 27 -> 27.44, 81 -> 85.28
 
 
 def timed(fn, steps, warmup):
@@ -24,9 +30,9 @@ def timed(fn, steps, warmup):
     return (time.perf_counter() - t0) / steps
 
 
-def train(T, B, steps=5, warmup=2):
+def train(T, B, steps=5, warmup=2, cd="bf16"):
     torch.manual_seed(114514)
-    model = K.KASportsFormer(n_layers=26, num_heads=8, n_frames=T, compute_dtype="bf16").cuda().train()
+    model = K.KASportsFormer(n_layers=26, num_heads=8, n_frames=T, compute_dtype=cd).cuda().train()
     model.attach_param_grads = False
     opt = K.FusedAdamW(model, lr=5e-4, weight_decay=0.01)
     x, y = (t.cuda() for t in O.synthetic_clips(B, T, seed=1234))
@@ -37,7 +43,7 @@ def train(T, B, steps=5, warmup=2):
         loss.backward()
         opt.step()
     dt = timed(step, steps, warmup)
-    print(json.dumps({"config": f"train T={T} B={B} bf16", "clips_per_s": B / dt, "ms_per_step": dt * 1e3,
+    print(json.dumps({"config": f"train T={T} B={B} {cd}", "clips_per_s": B / dt, "ms_per_step": dt * 1e3,
                       "mfma_frac": B / dt * 3 * FWD_GFLOP[T] * 1e9 / 2.5e15}), flush=True)
 
 
@@ -62,5 +68,9 @@ if __name__ == "__main__":
         train(81, 128)
     elif what == "train27":
         train(27, 256)
+    elif what == "train27fp32":          # the parity mode (exact-f32 MFMA), same workload: the mode the <= 1e-3 / 0.1 mm claims are made in
+        train(27, 256, steps=2, warmup=1, cd="fp32")
+    elif what == "train243":             # the long-clip configuration of the model family (generic temporal kernels)
+        train(243, 32, steps=3, warmup=1)
     else:
         evaluate()

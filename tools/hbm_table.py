@@ -1,0 +1,55 @@
+"""Achieved HBM bandwidth of the memory-bound kernels against their ALGORITHMIC bytes, from a rocprofv3 kernel trace.
+
+    python tools/hbm_table.py gpurun_out/prof27/t27_kernel_stats.csv [B T] > profiles/r2_op_hbm.json
+
+Duration = the MINIMUM over the launches of the trace (three training steps on three concurrent streams: the minimum is the launch that ran
+closest to alone; the averages in the same file are inflated by the overlap).  Bytes = the external inputs and outputs of the fused op per
+token x M tokens (s = 2 bytes in bf16 mode), as listed in DESIGN §4: re-reads from L2 are not counted, so the figure is a lower bound of what
+moved; peak = 8 TB/s (MI355X_MICROARCH.md).
+"""
+import csv, json, re, sys
+
+stats = sys.argv[1]
+B, T = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (256, 27)
+M, s = B * T * 17, 2
+# bytes per token (bf16): reads + writes of the kernel's external operands
+ALG = {
+    "k_linear_r<3, true, false>": ("LN + QKV linear (N=384), writes LN(x)? no", 128 * s + 384 * s),
+    "k_linear_r<2, true, false>": ("LN + U|V / KV linear (N=256) + LN(x) out", 128 * s + 256 * s + 128 * s),
+    "k_linear_r<1, true, false>": ("LN + Q linear (N=128)", 128 * s + 128 * s),
+    "k_linear_r<1, false, true>": ("proj + layer-scale + residual", 3 * 128 * s),
+    "k_dgrad_r<3, true, false, false, true, 3>": ("dqkv.W + LN backward + residual, emits LN(x)", (384 + 4 * 128) * s),
+    "k_dgrad_r<2, true, true, false, false, 3>": ("GCN: duv.W + LN backward + residual + direct LN(x) gradient", (256 + 4 * 128) * s),
+    "k_dgrad_r<2, false, false, true, true, 3>": ("bone: dkv.W + LN backward, accumulates into g_limb, emits LN(x_limb)", (256 + 4 * 128) * s),
+    "k_dgrad_r<1, true, false, false, true, 3>": ("bone: dq.W + LN backward + residual, emits LN(x)", (128 + 4 * 128) * s),
+    "k_lnbwd_sum4": ("sum of 4 dA partials + LN backward + residual", (4 * 128 + 3 * 128) * s),
+    "k_gcn_agg_spatial": ("skeleton aggregate: U|V in, y out", (256 + 128) * s),
+    "k_gcn_agg_temporal": ("top-4 similarity aggregate: U|V, LN(x) in, y + masks out", (256 + 128 + 128) * s + 12),
+    "k_gcn_apply": ("BatchNorm + ReLU + layer-scale + residual: x, LN(x), y in, x_mid out", 4 * 128 * s),
+    "k_gcn_bwd1": ("through layer-scale / ReLU: g, LN(x), y in, r out", 4 * 128 * s),
+    "k_gcn_bwd2_spatial": ("BatchNorm backward + transposed aggregate: r, y in, dU|dV out", (2 * 128 + 256) * s),
+    "k_gcn_bwd2_temporal": ("BatchNorm backward + transposed masked aggregate: r, y, masks in, dU|dV out", (2 * 128 + 256) * s + 12),
+    "k_gate_fwd": ("3-way softmax gate: 3 streams in, 1 out (+alpha)", 4 * 128 * s + 16),
+    "k_gate_bwd": ("gate backward: g (+2 addends), 3 streams, alpha in; 3 gradients out", 9 * 128 * s + 16),
+    "k_attn_blk_fwd<false>": ("fused attention block fwd: x in; q|k|v, o, x_mid out", (128 + 384 + 128 + 128) * s),
+    "k_attn_blk_fwd<true>": ("fused bone block fwd: x, x_limb in; q, k|v, o, x_mid out", (256 + 384 + 128 + 128) * s),
+    "k_attn_bwd_mfma<1, true>": ("attention backward cores + d_o: q|k|v, g_mid in; dq|dk|dv out", (384 + 128 + 384) * s),
+    "k_wgrad_ring_jobs": ("all weight gradients of an attention block: g_mid, o, dqkv, LN(x) streamed once", (128 + 128 + 384 + 128) * s),
+    "k_mlp_fwd_s": ("fused MLP fwd: x in; x_out, LN(x) out", 3 * 128 * s),
+    "k_mlp_bwd_s<false>": ("fused MLP bwd: LN(x), g in; 4 dA partials out", (2 * 128 + 4 * 128) * s),
+}
+rows = {}
+for r in csv.DictReader(open(stats)):
+    m = re.search(r"(k_[a-z0-9_]+(<[^>]*>)?)", r["Name"])
+    if m:
+        rows[m.group(1)] = r
+out = {"workload": f"B={B}, T={T}: M = {M} tokens, bf16; one training step trace (three streams)", "peak_GBps": 8000, "kernels": {}}
+for k, (what, bpt) in ALG.items():
+    hit = next((v for n, v in rows.items() if n.startswith(k)), None)
+    if hit is None:
+        continue
+    nbytes, tmin, tavg = bpt * M, float(hit["MinNs"]) * 1e-9, float(hit["AverageNs"]) * 1e-9
+    out["kernels"][k] = {"what": what, "algorithmic_bytes_per_token": bpt, "algorithmic_MB_per_launch": round(nbytes / 1e6, 1), "calls": int(hit["Calls"]),
+                         "min_us": round(tmin * 1e6, 1), "in_step_avg_us": round(tavg * 1e6, 1), "achieved_GBps_at_min": round(nbytes / tmin / 1e9),
+                         "frac_of_8TBps": round(nbytes / tmin / 8e12, 3)}
+print(json.dumps(out, indent=1))

@@ -1,0 +1,79 @@
+"""SURVEY §8(d) "MPJPE vs ref": K optimisation steps on synthetic clips with the CPU oracle (torch.optim.AdamW) and with the HIP path (FusedAdamW) from
+identical weights, data order and hyper-parameters, then the evaluation procedure (flip-TTA, de-normalisation, macro-average over actions) on both.
+
+    python tools/mpjpe_200.py [steps=200] > profiles/r2_mpjpe_200steps.json
+
+Reference default initialisation under the yaml seed (the regime real training runs in); 2 layers, batch 8, T = 27 keeps the CPU side to about a minute.
+"""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import kasportsformer_amd as K
+from oracle import kasf_oracle as O
+
+STEPS = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+L, T, B = 2, 27, 8
+xs, ys = O.synthetic_clips(B * 16, T, seed=77)
+xt, yt = O.synthetic_clips(16, T, seed=78)
+label_scaled, factor, res, actions = O.synthetic_test_extras(yt, seed=79)
+torch.manual_seed(114514)
+oracle = O.KASportsFormerOracle(n_layers=L, num_heads=8, n_frames=T)
+init = {k: v.clone() for k, v in oracle.state_dict().items()}
+torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+CHECK = sorted({c for c in (16, 50, 100, STEPS) if c <= STEPS})
+
+
+def oracle_run(threads):
+    """MPJPE of the CPU oracle after each checkpoint; `threads` changes how torch splits its fp32 reductions, i.e. the summation order."""
+    torch.set_num_threads(threads)
+    oracle.load_state_dict(init, strict=True)
+    topt = torch.optim.AdamW(oracle.parameters(), lr=5e-4, weight_decay=0.01)
+    res_at = {}
+    for s in range(STEPS):
+        oracle.train()
+        o = (s % 16) * B
+        topt.zero_grad()
+        O.loss_total(oracle(xs[o:o + B]), ys[o:o + B])[0].backward()
+        topt.step()
+        if s + 1 in CHECK:
+            oracle.eval()
+            with torch.no_grad():
+                pred = O.predict_flip_tta(oracle, xt)
+            r = O.evaluate_batches([(pred.numpy(), label_scaled.numpy(), factor.numpy(), actions, res.numpy())])
+            res_at[s + 1] = {"mpjpe_mm": float(r["mpjpe"]), "p_mpjpe_mm": float(r["p_mpjpe"])}
+    return res_at
+
+
+def hip_run(cd):
+    model = K.KASportsFormer(n_layers=L, num_heads=8, n_frames=T, compute_dtype=cd)
+    model.load_state_dict(init, strict=True)
+    model = model.cuda().train()
+    opt = K.FusedAdamW(model, lr=5e-4, weight_decay=0.01)
+    res_at = {}
+    for s in range(STEPS):
+        model.train()
+        o = (s % 16) * B
+        opt.zero_grad()
+        K.loss3(model(xs[o:o + B].cuda()), ys[o:o + B].cuda())[0].backward()
+        opt.step()
+        if s + 1 in CHECK:
+            got = K.evaluate_one_epoch(model, [(xt, label_scaled, factor, actions, res)], flip=True)
+            res_at[s + 1] = {"mpjpe_mm": got["mpjpe"], "p_mpjpe_mm": got["p_mpjpe"]}
+    return res_at
+
+
+cores = max(1, min(16, os.cpu_count() or 1))
+t0 = time.time()
+ref = oracle_run(cores)
+t_ref = time.time() - t0
+ref2 = oracle_run(max(1, cores // 4))            # the oracle against ITSELF with another reduction split: the fp32 noise floor of this comparison
+out = {"steps": STEPS, "layers": L, "batch": B, "n_frames": T, "init": "reference default init, seed 114514", "oracle_seconds": round(t_ref, 1),
+       "oracle_threads": [cores, max(1, cores // 4)], "checkpoints": {}}
+runs = {"fp32": hip_run("fp32"), "bf16": hip_run("bf16")}
+for c in CHECK:
+    row = {"oracle_mpjpe_mm": ref[c]["mpjpe_mm"], "oracle_vs_oracle_other_thread_count_abs_delta_mm": abs(ref[c]["mpjpe_mm"] - ref2[c]["mpjpe_mm"])}
+    for cd, r in runs.items():
+        row[cd] = {"mpjpe_mm": r[c]["mpjpe_mm"], "abs_delta_mpjpe_mm": abs(r[c]["mpjpe_mm"] - ref[c]["mpjpe_mm"]),
+                   "abs_delta_p_mpjpe_mm": abs(r[c]["p_mpjpe_mm"] - ref[c]["p_mpjpe_mm"])}
+    out["checkpoints"][str(c)] = row
+print(json.dumps(out, indent=1))
