@@ -87,7 +87,10 @@ def kernel_rooflines(M):
     return res
 
 
-TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_traffic.json")
+PROFILES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+TRAFFIC_FILE = os.path.join(PROFILES, "r2_pmc_traffic.json")            # tools/pmc_all.sh + tools/pmc_traffic.py (two --pmc passes over tools/mlp_bench.py)
+IN_STEP_STATS = os.path.join(PROFILES, "r2_train_kernel_stats.csv")      # rocprofv3 --kernel-trace --stats of tools/train_once.py 27 256 (three streams overlap)
+STEP_TRAFFIC_FILE = os.path.join(PROFILES, "r2_pmc_step.json")           # tools/pmc_step.sh: FETCH_SIZE / WRITE_SIZE summed over whole training steps
 TRAFFIC_PARTS = {"k_mlp_fwd_s": {"k_mlp_fwd_s": 1}, "k_mlp_bwd_s(+lnbwd_sum4+wfinish)": {"k_mlp_bwd_s": 1, "k_lnbwd_sum4": 1, "k_mlp_wfinish": 1}}
 
 
@@ -100,6 +103,46 @@ def pmc_traffic(entry, M):
     if any(k not in ks for k in TRAFFIC_PARTS[entry]):
         return None
     return sum(ks[k]["hbm_bytes"] * n for k, n in TRAFFIC_PARTS[entry].items())
+
+
+def in_step_duration(kernel_names):
+    """Average in-step launch duration (seconds) of the named kernels from the committed kernel trace of whole training steps: there three
+    streams overlap, so a launch shares the chip with the other two branches -- the honest figure next to the isolated micro-benchmark."""
+    import csv
+    if not os.path.exists(IN_STEP_STATS):
+        return None
+    total = 0.0
+    for r in csv.DictReader(open(IN_STEP_STATS)):
+        for k in kernel_names:
+            if k + "(" in r["Name"] or k + "<" in r["Name"] or ("N_1" + str(len(k)) + k) in r["Name"]:
+                total += float(r["AverageNs"]) * 1e-9
+                break
+    return total or None
+
+
+def fp32_mode_rate(batch, steps=2):
+    """The parity mode (exact-f32 MFMA: the mode the <= 1e-3 / <= 0.1 mm claims are made in) on the same workload, after the timed region."""
+    import kasportsformer_amd as K
+    torch.manual_seed(114514)
+    m = K.KASportsFormer(n_layers=LAYERS, num_heads=8, n_frames=T, compute_dtype="fp32").cuda().train()
+    m.attach_param_grads = False
+    opt = K.FusedAdamW(m, lr=5e-4, weight_decay=0.01)
+    x, y = (t.cuda() for t in K.synthetic_clips(batch, T, seed=1234))
+
+    def step():
+        opt.zero_grad()
+        loss, _ = K.loss3(m(x), y)
+        loss.backward()
+        opt.step()
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"clips_per_sec": batch / dt, "ms_per_step": dt * 1e3, "steps": steps,
+            "note": "same workload in the fp32 parity mode (exact-f32 MFMA); not part of value"}
 
 
 def cpu_baseline(batch=8, steps=8):
@@ -145,6 +188,7 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="clips per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-roofline", action="store_true")
+    ap.add_argument("--no-fp32", action="store_true", help="skip the fp32 parity-mode throughput leg")
     ap.add_argument("--force-dp", action="store_true", help="testing: take the data-parallel code path (stage-sliced backward, RCCL all-reduce) with one rank")
     args = ap.parse_args()
     # stdout carries exactly ONE line (the JSON): everything else any library prints there (RCCL's version banner on communicator
@@ -258,7 +302,9 @@ def main():
             "final_loss": loss_val,
             "eval": {"clips_per_sec": args.batch * world / dt_eval, "clips_per_sec_flip_tta": args.batch * world / dt_tta,
                      "note": "forward only, same model and batch per GPU, evaluation mode; not part of value"},
-            "parity": "fp32 mode <= 1e-3 vs reference fixtures; 16-step training then evaluation |dMPJPE| = 3e-5 mm (tests/test_gpu_train_parity.py)",
+            "parity": "26-layer forward vs the oracle with the same top-4 neighbour decisions: fp32 mode 4e-6, gradient cosine 1.0000000 (3 near-tie rows of "
+                      "23,868 differ); bf16 mode 0.10 / 0.958 (tests/test_gpu_model.py::test_full_depth_26_layers_against_oracle); training then evaluation "
+                      "|dMPJPE|: fp32 3e-5 mm after 16 steps, profiles/r2_mpjpe_200steps.json after 200",
             "model_mfma_frac": value / world * FLOP_PER_CLIP_TRAIN / (PEAK_BF16_TFLOPS * 1e12),
         }
         if not args.no_kernel_roofline:
@@ -267,9 +313,22 @@ def main():
             dom = max(ks, key=lambda k: ks[k]["seconds"])
             out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ks[dom]["achieved_tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                "frac": ks[dom]["achieved_tflops"] / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(dom, args.batch * T * 17),
-                               "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/r1_pmc_traffic.json)",
+                               "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/r2_pmc_traffic.json)",
                                "launch_ms": ks[dom]["seconds"] * 1e3, "algorithmic_flop_per_launch": ks[dom]["algorithmic_flop"]}
+            if dom in TRAFFIC_PARTS and args.batch == BATCH_PER_GPU:
+                t_in = in_step_duration(list(TRAFFIC_PARTS[dom]))
+                if t_in:                 # the same launches inside whole training steps (committed trace), where they share the chip with two other streams
+                    out["roofline"]["in_step"] = {"launch_ms": t_in * 1e3, "achieved": ks[dom]["algorithmic_flop"] / t_in / 1e12,
+                                                  "frac": ks[dom]["algorithmic_flop"] / t_in / 1e12 / PEAK_BF16_TFLOPS,
+                                                  "source": "profiles/r2_train_kernel_stats.csv (rocprofv3 --kernel-trace --stats -- python3 tools/train_once.py 27 256)"}
+            if os.path.exists(STEP_TRAFFIC_FILE) and args.batch == BATCH_PER_GPU:
+                out["step_hbm_GB"] = json.load(open(STEP_TRAFFIC_FILE))["hbm_GB_per_step"]
             out["kernels"] = {k: {"ms": v["seconds"] * 1e3, "tflops": v["achieved_tflops"]} for k, v in ks.items()}
+        if not args.no_fp32 and world == 1:
+            del model, opt
+            torch.cuda.empty_cache()
+            out["fp32_mode"] = fp32_mode_rate(args.batch)
+            log("fp32 parity-mode leg done")
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         sys.stdout.flush()

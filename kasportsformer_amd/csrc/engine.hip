@@ -347,7 +347,8 @@ void block_forward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void* 
     const float* P = c.P;
     static const bool no_blk = getenv("KASF_NO_ATTN_BLOCK") != nullptr;       // measurement switch: unfused attention forward
     bool mixer_done = false;     // bf16, groups of <= 32 positions: LN + QKV + attention + proj + residual in one kernel (csrc/k_attn_blk.hip)
-    if (c.dt == KASF_BF16 && !no_blk && o.kind != KIND_GRAPH) {
+    const int heads = c.m->cfg.num_heads;
+    if (c.dt == KASF_BF16 && !no_blk && o.kind != KIND_GRAPH && heads == 8) {
         const bool bone = o.kind == KIND_BONE;
         mixer_done = kasf_launch_attn_block_fwd(c.s, bone ? 1 : 0, x_in, bone ? x_limb : nullptr, P + o.n1w, P + o.n1b, bone ? P + o.n1lw : nullptr,
                                                 bone ? P + o.n1lb : nullptr, c.pk(o.p_mix), bone ? c.pk(o.p_kv) : nullptr, c.pk(o.p_proj), P + o.proj_b,
@@ -358,12 +359,12 @@ void block_forward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void* 
     } else if (o.kind == KIND_ATT) {
         kasf_launch_linear(c.dt, c.s, x_in, 128, c.pk(o.p_mix), 128, nullptr, c.w(w.qkv), 384, c.M, 384, P + o.n1w, P + o.n1b, nullptr, 0);
         const char* q = (const char*)c.w(w.qkv);
-        kasf_launch_attn_fwd(c.dt, c.s, q, 384, q + 128 * c.es, q + 256 * c.es, 384, c.w(w.o), c.B, c.T, o.mode);
+        kasf_launch_attn_fwd(c.dt, c.s, q, 384, q + 128 * c.es, q + 256 * c.es, 384, c.w(w.o), c.B, c.T, o.mode, heads);
     } else if (o.kind == KIND_BONE) {
         kasf_launch_linear(c.dt, c.s, x_in, 128, c.pk(o.p_mix), 128, nullptr, c.w(w.qkv), 128, c.M, 128, P + o.n1w, P + o.n1b, nullptr, 0);
         kasf_launch_linear(c.dt, c.s, x_limb, 128, c.pk(o.p_kv), 128, nullptr, c.w(w.kv), 256, c.M, 256, P + o.n1lw, P + o.n1lb, nullptr, 0);
         const char* kv = (const char*)c.w(w.kv);
-        kasf_launch_attn_fwd(c.dt, c.s, c.w(w.qkv), 128, kv, kv + 128 * c.es, 256, c.w(w.o), c.B, c.T, o.mode);
+        kasf_launch_attn_fwd(c.dt, c.s, c.w(w.qkv), 128, kv, kv + 128 * c.es, 256, c.w(w.o), c.B, c.T, o.mode, heads);
     } else {
         kasf_launch_linear(c.dt, c.s, x_in, 128, c.pk(o.p_mix), 128, P + o.uv_b, c.w(sc.uv), 256, c.M, 256, P + o.n1w, P + o.n1b, c.w(w.xn), 0);
         kasf_launch_gcn_agg_fwd(c.dt, c.s, c.w(sc.uv), c.w(w.xn), c.w(w.y), w.mask >= 0 ? (uint32_t*)c.w(w.mask) : nullptr, (double*)c.w(w.stats), c.B,
@@ -413,7 +414,8 @@ void block_backward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void*
     }
     // d_o = g_mid . (ls1 . Wproj);  G_proj = g_mid^T o (unscaled) -> finalize: dWproj, dbproj, dls1
     static const bool no_fdo = getenv("KASF_NO_FUSED_DO") != nullptr;          // measurement switch
-    const bool fdo = c.dt == KASF_BF16 && !no_fdo && (o.mode == 0 ? 17 : c.T) <= 32;   // d_o formed inside the attention backward kernel
+    const int heads = c.m->cfg.num_heads;
+    const bool fdo = c.dt == KASF_BF16 && !no_fdo && heads == 8 && (o.mode == 0 ? 17 : c.T) <= 32;   // d_o formed inside the attention backward kernel
     if (!fdo) kasf_launch_linear(c.dt, c.s, g_mid, 128, c.pk(o.p_projTs), 128, nullptr, c.w(sc.d_o), 128, c.M, 128, nullptr, nullptr, nullptr, 0);
     // bf16: every weight gradient of the block (proj, qkv | q, kv) goes into ONE streaming launch + one finishing launch at the end of the block
     static const bool no_jobs = getenv("KASF_NO_WGRAD_JOBS") != nullptr;       // measurement switch
@@ -429,7 +431,7 @@ void block_backward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void*
         if (fdo) kasf_launch_attn_bwd_fused_do(c.s, q, 384, q + 128 * c.es, q + 256 * c.es, 384, g_mid, c.pk(o.p_projTs), dq, 384, dq + 128 * c.es,
                                                dq + 256 * c.es, 384, c.B, c.T, o.mode);
         else kasf_launch_attn_bwd(c.dt, c.s, q, 384, q + 128 * c.es, q + 256 * c.es, 384, c.w(sc.d_o), dq, 384, dq + 128 * c.es, dq + 256 * c.es, 384, c.B,
-                                  c.T, o.mode);
+                                  c.T, o.mode, heads);
         kasf_launch_dgrad_lnbwd(c.dt, c.s, dq, 384, c.pk(o.p_mixT), nullptr, x_in, P + o.n1w, g_mid, dst, accumulate, G + o.n1w, G + o.n1b, c.M,
                                 c.w(sc.xn_a), P + o.n1b);
         bool done = false;
@@ -454,7 +456,7 @@ void block_backward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void*
         char* dkv = dq + c.M * 128 * c.es;
         if (fdo) kasf_launch_attn_bwd_fused_do(c.s, c.w(w.qkv), 128, kv, kv + 128 * c.es, 256, g_mid, c.pk(o.p_projTs), dq, 128, dkv, dkv + 128 * c.es, 256, c.B,
                                                c.T, o.mode);
-        else kasf_launch_attn_bwd(c.dt, c.s, c.w(w.qkv), 128, kv, kv + 128 * c.es, 256, c.w(sc.d_o), dq, 128, dkv, dkv + 128 * c.es, 256, c.B, c.T, o.mode);
+        else kasf_launch_attn_bwd(c.dt, c.s, c.w(w.qkv), 128, kv, kv + 128 * c.es, 256, c.w(sc.d_o), dq, 128, dkv, dkv + 128 * c.es, 256, c.B, c.T, o.mode, heads);
         kasf_launch_dgrad_lnbwd(c.dt, c.s, dq, 128, c.pk(o.p_mixT), nullptr, x_in, P + o.n1w, g_mid, dst, accumulate, G + o.n1w, G + o.n1b, c.M,
                                 c.w(sc.xn_a), P + o.n1b);
         kasf_launch_dgrad_lnbwd(c.dt, c.s, dkv, 256, c.pk(o.p_kvT), nullptr, x_limb, P + o.n1lw, nullptr, c.w(p.g_limb), 1, G + o.n1lw, G + o.n1lb, c.M,
@@ -494,7 +496,8 @@ int kasf_version(void) { return 3; }
 
 int kasf_model_create(const kasf_config* cfg, kasf_model** out) {
     if (cfg == nullptr || out == nullptr) return kasf_set_error(2, "null argument");
-    if (cfg->num_heads != 8) return kasf_set_error(3, "num_heads must be 8 (head dim 16); other values are not built");
+    if (cfg->num_heads != 2 && cfg->num_heads != 4 && cfg->num_heads != 8 && cfg->num_heads != 16)
+        return kasf_set_error(3, "num_heads must be 2, 4, 8 or 16 (8 = the shipped yaml has the MFMA attention kernels; the others run generic ones)");
     if (cfg->n_layers < 1 || cfg->n_layers > 64) return kasf_set_error(3, "n_layers out of range");
     // any clip length the reference can build (BatchNorm1d(n_frames), top-4 of T similarities needs T >= 4); 9 / 27 / 81 have tuned temporal
     // kernels (and T <= 96 the MFMA attention cores), other lengths run generic ones

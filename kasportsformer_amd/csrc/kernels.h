@@ -90,9 +90,9 @@ void kasf_launch_wgrad_reduce(hipStream_t s, const float* partial, float* out, i
 // ---- k_attn.hip ----
 // mode 0: spatial (groups = B*T frames of 17 tokens), mode 1: temporal (groups = B*17 joint tracks of T tokens)
 void kasf_launch_attn_fwd(int dt, hipStream_t s, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, void* o, int B, int T,
-                          int mode);
+                          int mode, int heads = 8);
 void kasf_launch_attn_bwd(int dt, hipStream_t s, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, const void* d_o, void* dq,
-                          int64_t lddq, void* dk, void* dv, int64_t lddkv, int B, int T, int mode);
+                          int64_t lddq, void* dk, void* dv, int64_t lddkv, int B, int T, int mode, int heads = 8);
 
 // ---- k_attn_mfma.hip (bf16 only; return false when the shape is outside their range) ----
 bool kasf_launch_attn_fwd_mfma(hipStream_t s, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, void* o, int B, int T, int mode);

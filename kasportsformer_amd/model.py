@@ -105,15 +105,15 @@ class KASportsFormer(nn.Module):
             unsupported.append("dropout > 0 (every shipped yaml uses 0)")
         if not use_layer_scale or qkv_bias or qkv_scale is not None or hierarchical or not use_temporal_similarity:
             unsupported.append("use_layer_scale=False / qkv_bias / qkv_scale / hierarchical / use_temporal_similarity=False")
-        if num_heads != 8:
-            unsupported.append("num_heads != 8 (configs/*.yaml:84)")
+        if num_heads not in (2, 4, 8, 16):
+            unsupported.append("num_heads not in {2, 4, 8, 16} (8 = configs/*.yaml:84 runs the MFMA attention kernels, the others generic ones)")
         if neighbour_num != 4 or not 4 <= n_frames <= 256:
             unsupported.append("neighbour_num != 4 or n_frames outside [4, 256]")
         if unsupported:
             raise NotImplementedError("kasportsformer_amd builds the shipped configuration only; unsupported: " + "; ".join(unsupported))
         if compute_dtype not in ("bf16", "fp32"):
             raise ValueError("compute_dtype must be 'bf16' or 'fp32'")
-        self.n_layers, self.n_frames, self.compute_dtype = n_layers, n_frames, compute_dtype
+        self.n_layers, self.n_frames, self.num_heads, self.compute_dtype = n_layers, n_frames, num_heads, compute_dtype
         self.attach_param_grads = True      # False: gradients stay in self.flat_grad only (FusedAdamW path)
         self.grad_stage_hook = None         # callable(stage, begin, end) after each backward stage (data parallel)
         self.flat_grad = None

@@ -97,8 +97,11 @@ def test_host_module_contract(golden_dir):
 def test_unsupported_configurations_raise_like_the_reference():
     import kasportsformer_amd as K
     from torch import nn
+    assert K.KASportsFormer(n_layers=1).num_heads == 4     # the reference's constructor default builds (every yaml overrides it with 8)
     with pytest.raises(NotImplementedError):
-        K.KASportsFormer(num_heads=4)                      # reference default; every yaml overrides to 8
+        K.KASportsFormer(num_heads=3)                      # 128 is not divisible by it: the reference fails later, in the reshape
+    with pytest.raises(NotImplementedError):
+        K.KASportsFormer(num_heads=8, n_frames=3)          # torch.topk(k=4) over 3 frames raises in the reference too
     with pytest.raises(NotImplementedError):
         K.KASportsFormer(num_heads=8, drop=0.1)
     with pytest.raises(NotImplementedError):

@@ -506,7 +506,7 @@ def test_full_depth_26_layers_against_oracle(cd):
         assert err < 0.2 and cosine > 0.92
 
 
-@pytest.mark.parametrize("T,B", [(243, 1), (100, 2), (33, 2), (5, 3), (4, 2)])
+@pytest.mark.parametrize("T,B", [(243, 1), (100, 2), (33, 2), (5, 3), (4, 8)])
 @pytest.mark.parametrize("cd,tol", [("fp32", 2e-3), ("bf16", 0.5)])
 def test_arbitrary_clip_lengths(cd, tol, T, B):
     """The reference builds for any n_frames (KASportsFormer.py:291-295, README.md:59): 243 is the long configuration of this model family;
@@ -547,3 +547,49 @@ def test_arbitrary_clip_lengths(cd, tol, T, B):
     model.eval()
     with torch.no_grad():
         assert torch.isfinite(model(x.cuda())).all()
+
+
+@pytest.mark.parametrize("heads", [4, 16, 2])
+@pytest.mark.parametrize("cd,tol", [("fp32", 2e-3), ("bf16", 0.5)])
+def test_other_head_counts(cd, tol, heads):
+    """`KASportsFormer()` without arguments builds with num_heads=4 (KASportsFormer.py:293; every yaml overrides it with 8): head dimension 32.
+    Other head counts run the generic attention kernels in both modes; forward and all gradients against the oracle."""
+    import kasportsformer_amd as K
+    oracle = O.KASportsFormerOracle(n_layers=2, num_heads=heads, n_frames=27)
+    sd = O.name_seeded_fill(oracle.state_dict())
+    oracle.load_state_dict(sd, strict=True)
+    model = K.KASportsFormer(n_layers=2, num_heads=heads, n_frames=27, compute_dtype=cd)
+    model.load_state_dict(sd, strict=True)
+    model = model.cuda().train()
+    oracle.train()
+    x, y = O.synthetic_clips(2, 27, seed=17)
+    with forced_adjacency(model, x):
+        ref = oracle(x)
+        O.loss_total(ref, y)[0].backward()
+    pred = model(x.cuda())
+    O.loss_total(pred, y.cuda())[0].backward()
+    torch.cuda.synchronize()
+    assert _abs_err(pred, ref) / max(1.0, float(ref.abs().max())) < (1e-3 if cd == "fp32" else 0.12)
+    ref_grads = dict(oracle.named_parameters())
+    gmax = max(float(q.grad.abs().max()) for q in ref_grads.values() if q.grad is not None)
+    bad = []
+    for n, p in model.named_parameters():
+        r = ref_grads[n].grad
+        assert (r is None) == (p.grad is None), n
+        if r is not None:
+            e = float((p.grad.detach().double().cpu() - r.double()).abs().max() / max(float(r.abs().max()), (1e-3 if cd == "fp32" else 0.05) * gmax))
+            if not e < tol:
+                bad.append((e, n))
+    assert not bad, sorted(bad, reverse=True)[:8]
+
+
+def test_bare_constructor_runs():
+    """The reference's own defaults (26 layers, num_heads=4, T=27): a bare drop-in construction trains one step."""
+    import kasportsformer_amd as K
+    torch.manual_seed(1)
+    m = K.KASportsFormer().cuda().train()
+    x, y = (t.cuda() for t in O.synthetic_clips(4, 27, seed=2))
+    loss, _ = K.loss3(m(x), y)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss) and all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
