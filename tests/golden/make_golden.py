@@ -269,6 +269,87 @@ def slicing_fixture():
     print("wrote slicing.npz:", len(out), "arrays;", {k: v.shape for k, v in out.items() if "ids_" in k})
 
 
+def import_reference_harness():
+    """`train_and_evaluate_sp.py` itself (for its `evaluate_one_epoch_new`, sp:27-149): importing the script drags in the logging / baseline-model
+    imports of the whole repository.  Absent third-party modules get inert stand-ins -- `wandb`, `easydict` (a dict with attribute access),
+    `torchprofile`, and the few `timm` names the vendored baselines import at module level; none of them is on the evaluated path."""
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class DropPath(nn.Module):
+        def __init__(self, p=None):
+            super().__init__()
+            self.drop_prob = p
+
+        def forward(self, x):
+            assert not (self.training and self.drop_prob)
+            return x
+
+    class EasyDict(dict):
+        def __init__(self, d=None, **kw):
+            super().__init__()
+            for k, v in dict(d or {}, **kw).items():
+                self[k] = v
+        __getattr__ = dict.__getitem__
+        __setattr__ = dict.__setitem__
+
+    layers = mod("timm.models.layers", DropPath=DropPath, trunc_normal_=nn.init.trunc_normal_, to_2tuple=lambda x: (x, x))
+    helpers = mod("timm.models.helpers", load_pretrained=lambda *a, **k: None)
+    registry = mod("timm.models.registry", register_model=lambda f: f)
+    models = mod("timm.models", layers=layers, helpers=helpers, registry=registry)
+    data = mod("timm.data", IMAGENET_DEFAULT_MEAN=(0.485, 0.456, 0.406), IMAGENET_DEFAULT_STD=(0.229, 0.224, 0.225))
+    timm = mod("timm", models=models, data=data)
+    timm.__path__ = []
+    mod("easydict", EasyDict=EasyDict)
+    wutil = mod("wandb.util", generate_id=lambda: "offline")
+    w = mod("wandb", util=wutil, log=lambda *a, **k: None, init=lambda *a, **k: None)
+    w.__path__ = []
+    mod("torchprofile", profile_macs=lambda *a, **k: 0)
+    if "/root/reference" not in sys.path:
+        sys.path.insert(0, "/root/reference")
+    import train_and_evaluate_sp as S
+    return S, EasyDict
+
+
+def eval_loop_fixture():
+    """Re-pins the evaluation procedure with the reference's OWN loop: `evaluate_one_epoch_new` is run on the reference model
+    and the batches of eval_L2_T27_B4.npz, with and without flip-TTA; the results must equal what that fixture stores (they came out of the
+    restated loop `oracle.evaluate_batches` with the reference's metric functions), and are written next to it."""
+    import logging
+    S, EasyDict = import_reference_harness()
+    from model.KASportsFormer import KASportsFormer as Ref
+    fx = dict(np.load(os.path.join(HERE, "eval_L2_T27_B4.npz")))
+    ref = Ref(n_layers=2, dim_in=3, dim_feat=128, dim_rep=512, dim_out=3, mlp_ratio=4, num_heads=8, n_frames=27)
+    ref.load_state_dict(O.name_seeded_fill(ref.state_dict()), strict=True)
+    ref.eval()
+    x, label_scaled, factor, res = (torch.from_numpy(fx[k]) for k in ("x", "label_scaled", "factor", "res"))
+    actions = [str(a) for a in fx["actions"]]
+    loader = [(x[:2], label_scaled[:2], factor[:2], actions[:2], res[:2]), (x[2:], label_scaled[2:], factor[2:], actions[2:], res[2:])]   # two batches
+    log = logging.getLogger("golden")
+    out = {}
+    for tag, flip in (("tta", True), ("plain", False)):
+        args = EasyDict(num_joints=17, flip=flip, eval_only=True)
+        r = S.evaluate_one_epoch_new(args, ref, loader, "cpu", 0, log)
+        order = np.argsort(np.array(r["activity_name_sequence"]))             # the reference iterates a set: order is arbitrary
+        want_order = np.argsort(fx["activity_name_sequence"])
+        got = {"mpjpe": float(r["mpjpe"]), "p_mpjpe": float(r["p_mpjpe"]), "acc": float(r["acceleration_error"]),
+               "mpjpe_joint": np.asarray(r["mpjpe_joint"], np.float64), "mpjpe_activity": np.asarray(r["mpjpe_activity"], np.float64)[order]}
+        # float32 means of per-action float32 means: the reference walks a Python set, the restatement first-seen order -> one or two float32 ulps
+        assert abs(got["mpjpe"] - float(fx[f"{tag}_mpjpe"])) < 1e-6 * abs(got["mpjpe"]), (tag, got["mpjpe"], float(fx[f"{tag}_mpjpe"]))
+        assert abs(got["p_mpjpe"] - float(fx[f"{tag}_p_mpjpe"])) < 1e-6 * abs(got["p_mpjpe"])
+        assert abs(got["acc"] - float(fx[f"{tag}_acc"])) < 1e-6 * abs(got["acc"])
+        assert np.allclose(got["mpjpe_joint"], fx[f"{tag}_mpjpe_joint"], rtol=1e-6, atol=0), np.abs(got["mpjpe_joint"] - fx[f"{tag}_mpjpe_joint"]).max()   # float32 means over actions in set order
+        assert np.allclose(got["mpjpe_activity"], fx[f"{tag}_mpjpe_activity"][want_order], rtol=1e-6, atol=0)
+        out.update({f"refloop_{tag}_mpjpe": np.float64(got["mpjpe"]), f"refloop_{tag}_p_mpjpe": np.float64(got["p_mpjpe"]), f"refloop_{tag}_acc": np.float64(got["acc"]),
+                    f"refloop_{tag}_mpjpe_joint": got["mpjpe_joint"]})
+    fx.update(out)
+    np.savez_compressed(os.path.join(HERE, "eval_L2_T27_B4.npz"), **fx)
+    print("evaluate_one_epoch_new (reference loop) reproduces eval_L2_T27_B4.npz:", {k: float(v) for k, v in out.items() if np.ndim(v) == 0})
+
+
 def main():
     Ref, bone_decomposer, LC, EC = import_reference()
     torch.set_num_threads(8)
@@ -278,6 +359,8 @@ def main():
         return eval_fixture(Ref, EC)
     if sys.argv[1:] == ["slicing"]:                          # only the offline clip-slicing fixture
         return slicing_fixture()
+    if sys.argv[1:] == ["evalloop"]:                         # re-pin the evaluation fixture with the reference's own loop
+        return eval_loop_fixture()
 
     # 1. state_dict manifest of the full 26-layer model (names/shapes/dtypes only)
     full = Ref(n_layers=26, dim_in=3, dim_feat=128, dim_rep=512, dim_out=3, mlp_ratio=4, num_heads=8, n_frames=27)
@@ -326,6 +409,7 @@ def main():
     eval_fixture(Ref, EC)
     clips_fixture()
     slicing_fixture()
+    eval_loop_fixture()
 
 
 if __name__ == "__main__":

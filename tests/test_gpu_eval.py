@@ -100,6 +100,10 @@ def test_evaluation_matches_reference_fixture_and_oracle():
         assert abs(r2[key] - float(fx[f"tta_{name}"])) < 2e-5 * float(fx[f"tta_{name}"]), (key, r2[key], float(fx[f"tta_{name}"]))
     assert np.allclose(r2["mpjpe_joint"], fx["tta_mpjpe_joint"], rtol=2e-5)
     assert np.allclose(r2["mpjpe_activity"], fx["tta_mpjpe_activity"], rtol=2e-5)
+    # the same against the reference's own evaluation loop (evaluate_one_epoch_new run by tests/golden/make_golden.py `evalloop`)
+    for key, name in (("mpjpe", "mpjpe"), ("p_mpjpe", "p_mpjpe"), ("acceleration_error", "acc")):
+        assert abs(r2[key] - float(fx[f"refloop_tta_{name}"])) < 2e-5 * float(fx[f"refloop_tta_{name}"]), (key, r2[key])
+    assert np.allclose(r2["mpjpe_joint"], fx["refloop_tta_mpjpe_joint"], rtol=2e-5)
 
 
 def test_stacked_tta_forward_equals_two_forwards_and_train_mode_is_kept_separate():

@@ -131,6 +131,10 @@ def test_evaluation_procedure_matches_reference_fixture(golden_dir):
                 assert abs(float(r[key]) - float(fx[f"{tag}_{name}"])) < 1e-5 * float(fx[f"{tag}_{name}"])
             assert np.allclose(r["mpjpe_joint"], fx[f"{tag}_mpjpe_joint"], rtol=1e-5)
             assert np.allclose(r["mpjpe_activity"], fx[f"{tag}_mpjpe_activity"], rtol=1e-5)
+            # ... and against what the reference's OWN loop (evaluate_one_epoch_new, imported by make_golden.py `evalloop`) returned for the same batches
+            for key, name in (("mpjpe", "mpjpe"), ("p_mpjpe", "p_mpjpe"), ("acceleration_error", "acc")):
+                assert abs(float(r[key]) - float(fx[f"refloop_{tag}_{name}"])) < 1e-5 * float(fx[f"refloop_{tag}_{name}"])
+            assert np.allclose(r["mpjpe_joint"], fx[f"refloop_{tag}_mpjpe_joint"], rtol=1e-5)
     per = [O.clip_metrics(fx["pred_tta"][i], fx["label_scaled"][i], fx["factor"][i], tuple(int(v) for v in fx["res"][i])) for i in range(4)]
     for k, name in enumerate(("clip_mpjpe", "clip_jpe", "clip_acc", "clip_pmpjpe")):
         assert np.allclose(np.stack([q[k] for q in per]), fx[name], rtol=1e-5, atol=1e-4)
