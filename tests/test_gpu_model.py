@@ -57,7 +57,7 @@ def test_fp32_forward_matches_reference_golden(name, tol):
             assert _abs_err(sd[k[4:]].to(ref.dtype), ref) < 1e-4, k
 
 
-@pytest.mark.parametrize("cd,tol", [("fp32", 1e-3), ("bf16", 0.12)])
+@pytest.mark.parametrize("cd,tol", [("fp32", 1e-3), ("bf16", 0.05)])      # bf16: observed 2.5e-2 (x 2)
 def test_stage_by_stage_against_oracle(cd, tol):
     """Every FormerModule / layer output of a 2-layer model (layer 0 exercises the bone-embedding start)."""
     oracle, model = make_pair(2, 27, cd)
@@ -74,6 +74,7 @@ def test_stage_by_stage_against_oracle(cd, tol):
         got = ws_tensor(model, ws, 2, name).float().view(r.shape)
         worst[name] = _abs_err(got, r) / max(1.0, float(r.abs().max()))
     worst["pred"] = _abs_err(out, ref) / max(1.0, float(ref.abs().max()))
+    print(f"[stages, {cd}] worst stage error {max(worst.values()):.3e} ({max(worst, key=worst.get)})")
     bad = {k: v for k, v in worst.items() if not v < tol}
     assert not bad, f"stages above {tol}: {bad}\nall: {worst}"
     # prologue: bone decomposition is a gather + fp32 arithmetic -> compare exactly-rounded values tightly
@@ -118,7 +119,10 @@ def test_backward_matches_oracle(cd, tol, L, T, B):
     assert not none_mismatch, none_mismatch
     assert sum(1 for p in model.parameters() if p.grad is None) == 8 * L   # 8 dead norm1_limb tensors per layer
     cosine = dots[0] / (dots[1] ** 0.5 * dots[2] ** 0.5)
-    assert cosine > (0.999999 if cd == "fp32" else 0.995), cosine
+    print(f"[backward, {cd}, L={L} T={T} B={B}] gradient cosine {cosine:.7f}, worst per-tensor error {max(worst.values()):.3e} ({max(worst, key=worst.get)})")
+    assert cosine > (0.999999 if cd == "fp32" else 0.999), cosine                  # bf16: observed >= 0.9995
+    if cd == "bf16" and B * T >= 900:
+        tol = 0.06       # per-tensor bf16 error with >= 15k tokens behind every sum: observed 2.5e-2 (x 2); the handful-of-clips cases reach 0.29
     bad = sorted(((v, k, float(ref_grads[k].grad.abs().max()) / gmax) for k, v in worst.items() if not v < tol), reverse=True)
     assert not bad, f"{len(bad)} gradients above {tol}; worst (err, name, |g|max/gmax): {bad[:12]}"
 

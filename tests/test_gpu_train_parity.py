@@ -47,8 +47,8 @@ def _default_init_pair(cd):
 # fp32 from the reference's default init: the SURVEY §8(d) bar, |dMPJPE| <= 0.1 mm.  With de-identitied (fully random) weights the temporal
 # top-4 neighbour choice sits on near-ties, one flipped neighbour changes a gradient by O(1) and the two runs drift apart chaotically (the
 # reference on two different machines would too): that case gets 2 mm (observed 0.02-0.6 mm, depending on which near-tie the run-to-run noise
-# of the fp32 atomics flips).  bf16 deviations are reported, with room.
-@pytest.mark.parametrize("init,cd,tol_mm", [("default", "fp32", 0.1), ("seeded", "fp32", 2.0), ("default", "bf16", 10.0), ("seeded", "bf16", 10.0)])
+# of the fp32 atomics flips).  bf16 deviations are reported; bars = observed (2.0 / 3.6 mm of 334-340 mm) x 2.
+@pytest.mark.parametrize("init,cd,tol_mm", [("default", "fp32", 0.1), ("seeded", "fp32", 2.0), ("default", "bf16", 4.0), ("seeded", "bf16", 7.0)])
 def test_training_then_evaluation_tracks_oracle(init, cd, tol_mm):
     import kasportsformer_amd as K
     oracle, model = make_pair(L, T, cd) if init == "seeded" else _default_init_pair(cd)
