@@ -8,7 +8,6 @@ import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import kasportsformer_amd as K
-from oracle import kasf_oracle as O     # synthetic clip recipe only
 
 class _Flop(dict):
     """Forward GFLOP per clip: 17 T tokens x (26 layers x (2,252,288 + 3 x 4 T x 128) + head 134,144 + embeddings 2,304)."""
@@ -35,7 +34,7 @@ def train(T, B, steps=5, warmup=2, cd="bf16"):
     model = K.KASportsFormer(n_layers=26, num_heads=8, n_frames=T, compute_dtype=cd).cuda().train()
     model.attach_param_grads = False
     opt = K.FusedAdamW(model, lr=5e-4, weight_decay=0.01)
-    x, y = (t.cuda() for t in O.synthetic_clips(B, T, seed=1234))
+    x, y = (t.cuda() for t in K.synthetic_clips(B, T, seed=1234))
 
     def step():
         opt.zero_grad()
@@ -51,7 +50,7 @@ def evaluate(T=27, batches=(32, 64, 128, 256, 512), steps=10, warmup=3):
     torch.manual_seed(114514)
     model = K.KASportsFormer(n_layers=26, num_heads=8, n_frames=T, compute_dtype="bf16").cuda().eval()
     for B in batches:
-        x, _ = O.synthetic_clips(B, T, seed=1234)
+        x, _ = K.synthetic_clips(B, T, seed=1234)
         x = x.cuda()
         with torch.no_grad():
             dt = timed(lambda: model(x), steps, warmup)

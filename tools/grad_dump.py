@@ -2,13 +2,12 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, kasportsformer_amd as K
-from oracle import kasf_oracle as O
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 torch.manual_seed(114514)
 m = K.KASportsFormer(n_layers=26, num_heads=8, n_frames=27, compute_dtype="bf16").cuda().train()
 m.attach_param_grads = False
 opt = K.FusedAdamW(m, lr=5e-4, weight_decay=0.01)
-x, y = (t.cuda() for t in O.synthetic_clips(B, 27, seed=5))
+x, y = (t.cuda() for t in K.synthetic_clips(B, 27, seed=5))
 reps = []
 for rep in range(3):
     opt.zero_grad()

@@ -3,11 +3,10 @@ buy at small batch?"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, kasportsformer_amd as K
-from oracle import kasf_oracle as O
 torch.manual_seed(0)
 m = K.KASportsFormer(n_layers=26, num_heads=8, n_frames=27, compute_dtype="bf16").cuda().eval()
 for B in (8, 32, 64, 256):
-    x = O.synthetic_clips(B, 27, seed=3)[0].cuda()
+    x = K.synthetic_clips(B, 27, seed=3)[0].cuda()
     xs = x.clone()
     with torch.no_grad():
         ref = m(x).clone()
