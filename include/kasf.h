@@ -157,6 +157,12 @@ int kasf_op_attention_fwd(int32_t dtype, const void* q, int64_t ldq, const void*
                           int32_t mode, void* stream);
 int kasf_op_attention_bwd(int32_t dtype, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, const void* d_o, void* dq, int64_t lddq,
                           void* dk, void* dv, int64_t lddkv, int32_t batch, int32_t n_frames, int32_t mode, void* stream);
+/* bf16, 8 heads, groups of <= 32 positions: the same with d_o = g_mid . wproj_t_scaled^T formed inside the kernel (what the training step runs:
+ * attention.py's proj + layer-scale data gradient folded in); wproj_t_scaled [128 in][128 out] = (ls1 . Wproj)^T packed bf16.
+ * form 0: persistent kernel (default in the engine), 1: one group per workgroup (round-1 form, kept as the comparison point): bit-identical results */
+int kasf_op_attention_bwd_fused_do(const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, const void* g_mid, const void* wproj_t_scaled,
+                                   void* dq, int64_t lddq, void* dk, void* dv, int64_t lddkv, int32_t batch, int32_t n_frames, int32_t mode, int32_t form,
+                                   void* stream);
 /* fp32 <-> model dtype */
 int kasf_op_cast(int32_t dtype, const void* src, void* dst, int64_t n, int32_t to_f32, void* stream);
 

@@ -66,6 +66,7 @@ SIGNATURES = {
     "kasf_op_dgrad_lnbwd": (_i32, [_i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i64, _vp, _vp, _vp]),
     "kasf_op_attention_fwd": (_i32, [_i32, _vp, _i64, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _vp]),
     "kasf_op_attention_bwd": (_i32, [_i32, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
+    "kasf_op_attention_bwd_fused_do": (_i32, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
     "kasf_op_cast": (_i32, [_i32, _vp, _vp, _i64, _i32, _vp]),
 }
 # not in the public header: host-only layout handle used by CPU tests / tooling

@@ -894,6 +894,15 @@ int kasf_op_attention_bwd(int32_t dtype, const void* q, int64_t ldq, const void*
     HIPCHK(hipGetLastError());
     return g_err.empty() ? 0 : 3;
 }
+int kasf_op_attention_bwd_fused_do(const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, const void* g_mid, const void* wproj_t_scaled, void* dq,
+                                   int64_t lddq, void* dk, void* dv, int64_t lddkv, int32_t batch, int32_t n_frames, int32_t mode, int32_t form, void* stream) {
+    g_err.clear();
+    if (form < 0 || form > 1) return kasf_set_error(2, "form: 0 (persistent) or 1 (one group per workgroup)");
+    if (!kasf_launch_attn_bwd_fused_do((hipStream_t)stream, q, ldq, k, v, ldkv, g_mid, wproj_t_scaled, dq, lddq, dk, dv, lddkv, batch, n_frames, mode, form))
+        return kasf_set_error(2, "fused-d_o attention backward: groups of at most 32 positions (bf16, 8 heads)");
+    HIPCHK(hipGetLastError());
+    return g_err.empty() ? 0 : 3;
+}
 int kasf_op_cast(int32_t dtype, const void* src, void* dst, int64_t n, int32_t to_f32, void* stream) {
     OP_DT_CHECK(dtype);
     if (to_f32) kasf_launch_cast_to_f32(dtype, (hipStream_t)stream, src, (float*)dst, n);

@@ -411,6 +411,169 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_long(const bf16* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Persistent form of k_attn_bwd_mfma<1, true> (groups of <= 32 positions, d_o formed in-kernel): the same arithmetic, bit for bit, but
+//   * a workgroup walks a contiguous range of groups: the 16 rows of the packed projection weight a wave needs stay in registers for the
+//     whole launch (the one-group-per-workgroup form re-read 32 KB of weights per group: 221 MB of L2 traffic per launch, more than the
+//     kernel's HBM bytes), and the next group's q | k | v fragments and g_mid rows are in flight while this group computes;
+//   * g_mid rows travel through registers (one coalesced 16-byte load per thread, a full 256-byte row per 16 lanes) into a double-buffered
+//     LDS tile: hipcc counts these loads itself, there is no hand-counted wait in this kernel; ONE workgroup barrier per group;
+//   * dq / dk / dv leave as 16-byte stores: the two lane halves exchange a dword pair (v_permlane32_swap) so that each lane holds 8
+//     consecutive head channels of its position instead of two 4-channel pieces.
+// Two workgroups per CU (<= 128 VGPRs, 72 KB of LDS): one group's barrier and LDS round trips are covered by the other's work.
+// ---------------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+    const bf16x2_t t = {(bf16)a, (bf16)b};
+    return __builtin_bit_cast(unsigned, t);
+}
+// lane = position, registers 0..7 of t = channels {4hh..4hh+3, 8+4hh..8+4hh+3}  ->  after the swap lane hh holds channels 8hh .. 8hh+7
+__device__ __forceinline__ u32x4_t swap_t16(const f32x16& t) {
+    const auto s0 = __builtin_amdgcn_permlane32_swap(pack2(t[0], t[1]), pack2(t[4], t[5]), false, false);
+    const auto s1 = __builtin_amdgcn_permlane32_swap(pack2(t[2], t[3]), pack2(t[6], t[7]), false, false);
+    return u32x4_t{s0[0], s1[0], s0[1], s1[1]};
+}
+
+// NR: score registers that can hold a live key (register g holds keys (g & 3) + 8 (g >> 2) + 4 hh: 9 for groups of <= 17 positions, the spatial
+// blocks): the softmax / dS arithmetic and the P / dS tile stores skip the registers past NR, which are identically zero.
+template <int NR>
+__global__ __launch_bounds__(512, 4) void k_attn_bwd_pers(const bf16* __restrict__ Q, int64_t ldq, const bf16* __restrict__ K, const bf16* __restrict__ V,
+                                                          int64_t ldkv, bf16* __restrict__ dQ, int64_t lddq, bf16* __restrict__ dK, bf16* __restrict__ dV,
+                                                          int64_t lddkv, int L, int Tn, int mode, int groups, const bf16* __restrict__ Gmid,
+                                                          const bf16* __restrict__ Wp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TILE = 32 * 16;
+    constexpr int WAVE_BYTES = 3 * TILE * 2 + 2 * 32 * 32 * 2;      // K, Q, d_o tiles + P and dS tiles
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5, h = wave;
+    const int per = (groups + gridDim.x - 1) / gridDim.x;
+    const int g0 = blockIdx.x * per;
+    int ng = groups - g0;
+    if (ng > per) ng = per;
+    if (ng <= 0) return;                                             // workgroup-uniform
+    bf16* sK = reinterpret_cast<bf16*>(smem + wave * WAVE_BYTES);
+    bf16* sQ = sK + TILE;
+    bf16* sD = sQ + TILE;
+    bf16* sP = sD + TILE;
+    bf16* sdS = sP + 32 * 32;
+    bf16* sG = reinterpret_cast<bf16*>(smem + 8 * WAVE_BYTES);      // [2][32][128] g_mid rows (swizzled tiles)
+    const int li = lane & 15, lg = lane >> 4;
+    const int grow = threadIdx.x >> 4, gch = threadIdx.x & 15;
+    bf16x8 wp[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) wp[ks] = *reinterpret_cast<const bf16x8*>(Wp + (int64_t)(16 * h + li) * 128 + 32 * ks + 8 * lg);
+    bf16x8 kfN, vfN, qfN, gcN;
+    const int stride = mode == 0 ? 1 : KASF_J;                      // tokens between consecutive positions of a group (32-bit indices: M * 384 < 2^31)
+    auto base_of = [&](int G) { return mode == 0 ? G * KASF_J : (G / KASF_J) * Tn * KASF_J + (G % KASF_J); };
+    const int rc = r < L ? r : L - 1, growc = grow < L ? grow : L - 1;
+    const unsigned okv = (unsigned)(rc * stride) * (unsigned)ldkv + h * 16 + 8 * hh, oq = (unsigned)(rc * stride) * (unsigned)ldq + h * 16 + 8 * hh;
+    const unsigned og = (unsigned)(growc * stride) * 128u + gch * 8;
+    auto fetch = [&](int t) {
+        const unsigned b = (unsigned)base_of(g0 + t);              // wave-uniform
+        kfN = *reinterpret_cast<const bf16x8*>(K + (size_t)(b * (unsigned)ldkv + okv));
+        vfN = *reinterpret_cast<const bf16x8*>(V + (size_t)(b * (unsigned)ldkv + okv));
+        qfN = *reinterpret_cast<const bf16x8*>(Q + (size_t)(b * (unsigned)ldq + oq));
+        gcN = *reinterpret_cast<const bf16x8*>(Gmid + (size_t)(b * 128u + og));
+    };                                                               // (rows past L are clamped here and zeroed at the point of use: a select
+                                                                     //  right behind the load would make hipcc wait for it before the group's work)
+    u32x4_t pq, pv, pk;
+    const unsigned sq = (unsigned)(rc * stride) * (unsigned)lddq + h * 16 + 8 * hh, skv = (unsigned)(rc * stride) * (unsigned)lddkv + h * 16 + 8 * hh;
+    auto flush = [&](int G) {                                        // dq | dk | dv of group G: 16 bytes per lane, 32 contiguous bytes per position and head
+        const unsigned b = (unsigned)base_of(G);
+        if (r < L) {
+            *reinterpret_cast<u32x4_t*>(dQ + (size_t)(b * (unsigned)lddq + sq)) = pq;
+            *reinterpret_cast<u32x4_t*>(dV + (size_t)(b * (unsigned)lddkv + skv)) = pv;
+            *reinterpret_cast<u32x4_t*>(dK + (size_t)(b * (unsigned)lddkv + skv)) = pk;
+        }
+    };
+    constexpr int NA4 = (NR + 3) / 4;                                // 4-register (8-byte) pieces of a P / dS row that are ever non-zero
+    if (NA4 < 4) {                                                   // the rest of both tiles stays zero for the whole launch
+#pragma unroll
+        for (int a4 = NA4; a4 < 4; ++a4) {
+            float z4[4] = {0.f, 0.f, 0.f, 0.f};
+            store4(sP + r * 32 + 8 * a4 + 4 * hh, z4);
+            store4(sdS + r * 32 + 8 * a4 + 4 * hh, z4);
+        }
+    }
+    fetch(0);
+    for (int t = 0; t < ng; ++t) {
+        const bf16x8 kf = r < L ? kfN : zero8(), vf = r < L ? vfN : zero8(), qf = r < L ? qfN : zero8();
+        bf16* sGt = sG + (t & 1) * (32 * 128);
+        *reinterpret_cast<bf16x8*>(sGt + Tile<bf16>::chunk_off(grow, gch)) = grow < L ? gcN : zero8();
+        *reinterpret_cast<bf16x8*>(sK + r * 16 + 8 * hh) = kf;
+        *reinterpret_cast<bf16x8*>(sQ + r * 16 + 8 * hh) = qf;
+        if (t > 0) flush(g0 + t - 1);
+        if (t + 1 < ng) fetch(t + 1);
+        __syncthreads();          // g_mid rows of group t visible; every wave is past its reads of the other buffer (group t-1)
+        bf16x8 df;
+        {   // d_o of this head: [32 positions][16 channels] = g_mid . (ls1 . Wproj)^T rows 16h .. 16h+15
+            f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[ks], *reinterpret_cast<const bf16x8*>(sGt + Tile<bf16>::chunk_off(li, 4 * ks + lg)), acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[ks], *reinterpret_cast<const bf16x8*>(sGt + Tile<bf16>::chunk_off(16 + li, 4 * ks + lg)), acc[1], 0, 0, 0);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const float live = 16 * mt + li < L ? 1.0f : 0.0f;
+                float v[4] = {acc[mt][0] * live, acc[mt][1] * live, acc[mt][2] * live, acc[mt][3] * live};
+                store4(sD + (16 * mt + li) * 16 + 4 * lg, v);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            df = *reinterpret_cast<const bf16x8*>(sD + r * 16 + 8 * hh);
+        }
+        // ---------------- pass 1: lane = query ----------------
+        f32x16 st = mfma32(kf, qf, zero16());                    // S^T[key][query]
+        f32x16 dp = mfma32(vf, df, zero16());                    // dP^T[key][query]
+        float mx = -INFINITY;
+#pragma unroll
+        for (int g = 0; g < NR; ++g) {
+            const float s = (pos_of(g, hh) < L) ? st[g] * 0.25f : -INFINITY;
+            st[g] = s;
+            mx = fmaxf(mx, s);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int g = 0; g < NR; ++g) { st[g] = __expf(st[g] - mx); sum += st[g]; }
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.0f / sum;
+        float delta = 0.f;
+#pragma unroll
+        for (int g = 0; g < NR; ++g) { st[g] *= inv; delta += st[g] * dp[g]; }
+#pragma unroll
+        for (int g = NR; g < 16; ++g) st[g] = 0.f;
+        delta += __shfl_xor(delta, 32);
+#pragma unroll
+        for (int a4 = 0; a4 < NA4; ++a4) {
+            float v4[4] = {st[4 * a4], st[4 * a4 + 1], st[4 * a4 + 2], st[4 * a4 + 3]};
+            store4(sP + r * 32 + 8 * a4 + 4 * hh, v4);
+        }
+#pragma unroll
+        for (int g = 0; g < NR; ++g) st[g] = st[g] * (dp[g] - delta) * 0.25f;       // dS^T (scale folded)
+        f32x16 dq = mfma32(tr_frag(sK, 0), pack8(st, 0), zero16());                  // dQ^T[d][query] = K^T . dS^T
+        dq = mfma32(tr_frag(sK, 1), pack8(st, 1), dq);
+#pragma unroll
+        for (int a4 = 0; a4 < NA4; ++a4) {
+            float v4[4] = {st[4 * a4], st[4 * a4 + 1], st[4 * a4 + 2], st[4 * a4 + 3]};
+            store4(sdS + r * 32 + 8 * a4 + 4 * hh, v4);
+        }
+        // ---------------- pass 2: dV^T = dO^T . P, dK^T = Q^T . dS with P / dS read back transposed (lane = key) ----------------
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the tiles were written by other lanes of this wave (LDS is in order per wave)
+        f32x16 dv = zero16(), dk = zero16();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            dv = mfma32(tr_frag(sD, ks), tr_frag32(sP, ks), dv);
+            dk = mfma32(tr_frag(sQ, ks), tr_frag32(sdS, ks), dk);
+        }
+        pq = swap_t16(dq);       // stored at the top of the next group, in FRONT of that group's look-ahead loads: the wait for those loads then
+        pv = swap_t16(dv);       // never has this group's stores (issued a moment ago) ahead of it in the in-order vmcnt queue
+        pk = swap_t16(dk);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's LDS reads are done before the next group's tile writes
+    }
+    flush(g0 + ng - 1);
+}
+
 template <typename K> void set_smem(K k, size_t bytes) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
@@ -459,10 +622,27 @@ bool kasf_launch_attn_bwd_mfma(hipStream_t s, const void* q, int64_t ldq, const 
 // Attention backward with the projection's data gradient fused in (bf16, groups of <= 32 positions): d_o = g_mid . WprojTs^T is formed per head
 // inside the kernel.  false: shape not covered (the caller computes d_o with a linear and calls kasf_launch_attn_bwd).
 bool kasf_launch_attn_bwd_fused_do(hipStream_t s, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, const void* g_mid,
-                                   const void* WprojTs, void* dq, int64_t lddq, void* dk, void* dv, int64_t lddkv, int B, int Tn, int mode) {
+                                   const void* WprojTs, void* dq, int64_t lddq, void* dk, void* dv, int64_t lddkv, int B, int Tn, int mode, int form) {
     const int L = mode == 0 ? KASF_J : Tn, groups = mode == 0 ? B * Tn : B * KASF_J;
     if (L > 32) return false;
     if (groups <= 0) return true;
+    static const bool env_one_group = getenv("KASF_ATTN_BWD_ONE_GROUP") != nullptr;        // measurement / parity switch: the round-1 form
+    const bool one_group_per_wg = form < 0 ? env_one_group : form == 1;
+    if (!one_group_per_wg) {
+        const size_t shp = 8 * (3 * 32 * 16 * 2 + 2 * 32 * 32 * 2) + 2 * 32 * 128 * 2;
+        static const int cap = getenv("KASF_ATTN_BWD_WGS") ? atoi(getenv("KASF_ATTN_BWD_WGS")) : 512;
+        const dim3 grid(groups < cap ? groups : cap);
+        if (L <= 17) {
+            set_smem(k_attn_bwd_pers<9>, shp);
+            hipLaunchKernelGGL(k_attn_bwd_pers<9>, grid, dim3(512), shp, s, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldkv, (bf16*)dq, lddq, (bf16*)dk,
+                               (bf16*)dv, lddkv, L, Tn, mode, groups, (const bf16*)g_mid, (const bf16*)WprojTs);
+        } else {
+            set_smem(k_attn_bwd_pers<16>, shp);
+            hipLaunchKernelGGL(k_attn_bwd_pers<16>, grid, dim3(512), shp, s, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldkv, (bf16*)dq, lddq, (bf16*)dk,
+                               (bf16*)dv, lddkv, L, Tn, mode, groups, (const bf16*)g_mid, (const bf16*)WprojTs);
+        }
+        return true;
+    }
     const size_t sh = 8 * (3 * 32 * 16 * 2 + 32 * 16 + 2 * 32 * 32 * 2) + 32 * 128 * 2;
     set_smem(k_attn_bwd_mfma<1, true>, sh);
     hipLaunchKernelGGL((k_attn_bwd_mfma<1, true>), dim3(groups), dim3(512), sh, s, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldkv,

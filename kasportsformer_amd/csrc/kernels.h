@@ -166,4 +166,4 @@ bool kasf_launch_wgrad_jobs(hipStream_t s, int njobs, const void* const* G, cons
                             int fin_job, const float* fin_W, const float* fin_bias, const float* fin_ls, float* fin_dls, int64_t M, float* partial,
                             int64_t partial_floats);
 bool kasf_launch_attn_bwd_fused_do(hipStream_t s, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, const void* g_mid,
-                                   const void* WprojTs, void* dq, int64_t lddq, void* dk, void* dv, int64_t lddkv, int B, int Tn, int mode);
+                                   const void* WprojTs, void* dq, int64_t lddq, void* dk, void* dv, int64_t lddkv, int B, int Tn, int mode, int form = -1 /* -1: default (persistent), 0: persistent, 1: one group per workgroup (round-1 form) */);

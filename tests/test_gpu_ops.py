@@ -258,6 +258,46 @@ def test_attention_core(lib, cd, mode, T):
     assert rel_err(_back(dqkv), qr.grad) < TOL[cd]
 
 
+@pytest.mark.parametrize("bone", [False, True])
+@pytest.mark.parametrize("mode,T,B", [(0, 27, 2), (1, 27, 3), (1, 9, 2), (0, 27, 41), (1, 32, 67), (0, 4, 1)])     # 41 x 27 = 1,107 groups: three per persistent
+def test_attention_backward_fused_do(lib, bone, mode, T, B):                                                     # workgroup, last range short; 67 x 17 = 1,139
+    """The training step's attention backward: d_o = g_mid . (ls1 . Wproj) formed inside the kernel (attention.py's proj + layer-scale data gradient
+    folded in).  Persistent form against the oracle's attention core, and bit for bit against the one-group-per-workgroup form it replaced."""
+    from kasportsformer_amd import _lib
+    from oracle.kasf_oracle import attention_core, _heads
+    qkv = _rand(B, T, 17, 384, seed=24)
+    g_mid = _rand(B, T, 17, 128, seed=25)
+    W = _rand(128, 128, seed=26) * 0.2
+    ls1 = _rand(128, seed=27)
+    wts = (ls1[:, None] * W).t().contiguous()                     # [c][n] = ls1[n] W[n][c]
+    qd, gd, wd = _dev(qkv, "bf16"), _dev(g_mid, "bf16"), _dev(wts, "bf16")
+    if bone:                                                      # q in its own [M,128] tensor, k|v in a [M,256] one (bone_crossattention.py)
+        qsep, kv = qd[..., :128].contiguous(), qd[..., 128:].contiguous()
+        args = (qsep.data_ptr(), 128, kv.data_ptr(), kv.data_ptr() + 256, 256)
+    else:
+        args = (qd.data_ptr(), 384, qd.data_ptr() + 256, qd.data_ptr() + 512, 384)
+    outs = []
+    for form in (0, 1):
+        torch.manual_seed(0)
+        if bone:
+            dq = torch.full((B, T, 17, 128), float("nan"), device="cuda", dtype=torch.bfloat16)
+            dkv = torch.full((B, T, 17, 256), float("nan"), device="cuda", dtype=torch.bfloat16)
+            oargs = (dq.data_ptr(), 128, dkv.data_ptr(), dkv.data_ptr() + 256, 256)
+        else:
+            dqkv = torch.full((B, T, 17, 384), float("nan"), device="cuda", dtype=torch.bfloat16)
+            oargs = (dqkv.data_ptr(), 384, dqkv.data_ptr() + 256, dqkv.data_ptr() + 512, 384)
+        _lib.check(lib.kasf_op_attention_bwd_fused_do(*args, ptr(gd), ptr(wd), *oargs, B, T, mode, form, stream()))
+        torch.cuda.synchronize()
+        outs.append(torch.cat((dq, dkv), dim=-1).float().cpu() if bone else dqkv.float().cpu())
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1])
+    d_o = (_back(gd) @ _back(wd).t()).to(torch.bfloat16).float()
+    qr = _back(qd).requires_grad_(True)
+    q, k, v = _heads(qr, 3, 8)
+    attention_core(q, k, v, "spatial" if mode == 0 else "temporal", 0.25).backward(d_o)
+    assert rel_err(outs[0], qr.grad) < TOL["bf16"]
+
+
 def test_loss3_and_adamw(lib):
     import kasportsformer_amd as K
     from oracle import kasf_oracle as O
