@@ -633,6 +633,8 @@ int kasf_forward(const kasf_model* m, const float* params, const void* packed, f
     if (check_model(m)) return 2;
     if (!params || !packed || !buffers || !x || !out || !workspace) return kasf_set_error(2, "null pointer argument");
     if (m->d_pro == nullptr) return kasf_set_error(4, "layout-only model cannot run");
+    if (batch < 1 || (int64_t)batch * m->cfg.n_frames * 17 * 384 >= ((int64_t)1 << 31))
+        return kasf_set_error(2, "batch: 1 <= batch and batch * n_frames * 17 * 384 < 2^31 (32-bit element offsets in the kernels)");
     const bool bn_train = (flags & KASF_FLAG_TRAIN) != 0;
     const bool train = bn_train || (flags & KASF_FLAG_KEEP) != 0;        // keep every layer's activations
     Plan p;

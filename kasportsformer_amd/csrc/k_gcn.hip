@@ -31,7 +31,8 @@ __device__ __forceinline__ double stat_sum(const double* stats, int idx) {
 }
 __device__ __forceinline__ double* stat_slot(double* stats) { return stats + (blockIdx.x % KASF_STAT_SLOTS) * KASF_STAT_LD; }
 
-__device__ __forceinline__ int node_of(int64_t tok, int T, int mode) { return mode == 0 ? (int)(tok % KASF_J) : (int)((tok / KASF_J) % T); }
+// 32-bit token arithmetic (the engine bounds M * 16 below 2^31): a 64-bit divide by 17 is ~40 instructions per lane, paid by all 16 lanes of a token
+__device__ __forceinline__ int node_of(int tok, int T, int mode) { return mode == 0 ? tok % KASF_J : (tok / KASF_J) % T; }
 
 // ------------------------------------------------------------------ spatial aggregate (elementwise + 4-neighbour gather)
 template <typename T>
@@ -40,9 +41,11 @@ __global__ __launch_bounds__(256) void k_gcn_agg_spatial(const T* __restrict__ u
     if (threadIdx.x < KASF_J * 2) sStat[threadIdx.x] = 0.f;
     __syncthreads();
     const int sub = threadIdx.x & 15;
-    for (int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x; item < M * 16; item += (int64_t)gridDim.x * 256) {
-        const int64_t tok = item >> 4, frame0 = (tok / KASF_J) * KASF_J;
-        const int i = (int)(tok - frame0);
+    const int n_items = (int)(M * 16);
+    for (int item = blockIdx.x * 256 + threadIdx.x; item < n_items; item += gridDim.x * 256) {
+        const int tk = item >> 4, fr = (tk / KASF_J) * KASF_J;
+        const int64_t tok = tk, frame0 = fr;
+        const int i = tk - fr;
         float acc[8];
         load8(uv + tok * 256 + sub * 8, acc);                        // U
 #pragma unroll
@@ -226,9 +229,10 @@ __global__ __launch_bounds__(256) void k_gcn_apply(const T* __restrict__ x_in, c
     float ls[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) ls[e] = ls1[sub * 8 + e];
-    for (int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x; item < M * 16; item += (int64_t)gridDim.x * 256) {
+    const int n_items = (int)(M * 16);
+    for (int item = blockIdx.x * 256 + threadIdx.x; item < n_items; item += gridDim.x * 256) {
         const int64_t tok = item >> 4;
-        const int node = node_of(tok, Tn, mode);
+        const int node = node_of(item >> 4, Tn, mode);
         const float sc = sC[node][0], sh = sC[node][1];
         float a[8], b[8], c[8];
         load8(x_in + tok * 128 + sub * 8, a);
@@ -253,27 +257,42 @@ __global__ __launch_bounds__(256) void k_gcn_bwd1(const T* __restrict__ g, const
     float ls[8], dls[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { ls[e] = ls1[sub * 8 + e]; dls[e] = 0.f; }
-    for (int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x; item < M * 16; item += (int64_t)gridDim.x * 256) {
-        const int64_t tok = item >> 4;
-        const int node = node_of(tok, Tn, mode);
-        const float sc = coef[node * COEF_LD], sh = coef[node * COEF_LD + 1], mean = coef[node * COEF_LD + 2], rstd = coef[node * COEF_LD + 3];
-        float gg[8], b[8], c[8], r[8];
-        load8(g + tok * 128 + sub * 8, gg);
-        load8(xn + tok * 128 + sub * 8, b);
-        load8(y + tok * 128 + sub * 8, c);
-        float s1 = 0.f, s2 = 0.f;
+    // two items per pass, all six loads issued before the first use: at 512 workgroups (the block-end atomics are same-address) one item per pass
+    // leaves only 3 x 16 bytes per lane in flight, 3.1 TB/s
+    const int n_items = (int)(M * 16), stride = gridDim.x * 256;
+    for (int item0 = blockIdx.x * 256 + threadIdx.x; item0 < n_items; item0 += 2 * stride) {
+        const int item1 = item0 + stride;
+        const bool has1 = item1 < n_items;
+        const int tk[2] = {item0 >> 4, has1 ? item1 >> 4 : item0 >> 4};
+        float gg[2][8], b[2][8], c[2][8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float z = b[e] + c[e] * sc + sh;
-            dls[e] += gg[e] * fmaxf(z, 0.f);
-            r[e] = z > 0.f ? ls[e] * gg[e] : 0.f;
-            s1 += r[e];
-            s2 += r[e] * (c[e] - mean) * rstd;
+        for (int u = 0; u < 2; ++u) {
+            const int64_t tok = tk[u];
+            load8(g + tok * 128 + sub * 8, gg[u]);
+            load8(xn + tok * 128 + sub * 8, b[u]);
+            load8(y + tok * 128 + sub * 8, c[u]);
         }
-        store8(rbuf + tok * 128 + sub * 8, r);
-        s1 = reduce16(s1);
-        s2 = reduce16(s2);
-        if (sub == 0) { atomicAdd(&sStat[node * 2], s1); atomicAdd(&sStat[node * 2 + 1], s2); }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (u == 1 && !has1) break;
+            const int64_t tok = tk[u];
+            const int node = node_of(tk[u], Tn, mode);
+            const float sc = coef[node * COEF_LD], sh = coef[node * COEF_LD + 1], mean = coef[node * COEF_LD + 2], rstd = coef[node * COEF_LD + 3];
+            float r[8];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float z = b[u][e] + c[u][e] * sc + sh;
+                dls[e] += gg[u][e] * fmaxf(z, 0.f);
+                r[e] = z > 0.f ? ls[e] * gg[u][e] : 0.f;
+                s1 += r[e];
+                s2 += r[e] * (c[u][e] - mean) * rstd;
+            }
+            store8(rbuf + tok * 128 + sub * 8, r);
+            s1 = reduce16(s1);
+            s2 = reduce16(s2);
+            if (sub == 0) { atomicAdd(&sStat[node * 2], s1); atomicAdd(&sStat[node * 2 + 1], s2); }
+        }
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) sRed[rl * 128 + sub * 8 + e] = dls[e];
@@ -327,9 +346,11 @@ __global__ __launch_bounds__(256) void k_gcn_bwd2_spatial(const T* __restrict__ 
     __shared__ float coef[KASF_MAX_NODES * C2_LD];
     bwd2_prologue(coef, coefg, bstats, d_w, d_b, nodes, count, training);
     const int sub = threadIdx.x & 15;
-    for (int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x; item < M * 16; item += (int64_t)gridDim.x * 256) {
-        const int64_t tok = item >> 4, frame0 = (tok / KASF_J) * KASF_J;
-        const int i = (int)(tok - frame0);
+    const int n_items = (int)(M * 16);
+    for (int item = blockIdx.x * 256 + threadIdx.x; item < n_items; item += gridDim.x * 256) {
+        const int tk = item >> 4, fr = (tk / KASF_J) * KASF_J;
+        const int64_t tok = tk, frame0 = fr;
+        const int i = tk - fr;
         float dy[8], dv[8];
         dy_chunk(rbuf, y, coef, tok, i, sub, dy);
         store8(duv + tok * 256 + sub * 8, dy);                       // dU = dy

@@ -99,33 +99,54 @@ __global__ __launch_bounds__(256) void k_embed_bwd(const T* __restrict__ g, cons
 #pragma unroll
         for (int d = 0; d < 3; ++d) { w[e][d] = W[(sub * 8 + e) * 3 + d]; aw[e][d] = 0.f; }
     }
-    for (int64_t f = blockIdx.x; f < frames; f += gridDim.x) {
+    // Few workgroups (every one ends in 2.7 K same-address atomics: at 512 workgroups those, not the 30 MB stream, were the launch's 198 us), so
+    // each keeps EU frames in flight: all loads of a pass are issued before the first use.
+    constexpr int EU = 4;
+    auto accumulate = [&](const float (&gv)[8], float a0, float a1, float a2, int64_t tok, bool second) {
+        float d0 = 0.f, d1 = 0.f, d2 = 0.f;
 #pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-            const int j = pass == 0 ? rl : 16;
-            if (pass == 1 && rl != 0) break;
-            const int64_t tok = f * KASF_J + j;
-            float gv[8];
-            load8(g + tok * 128 + sub * 8, gv);
-            const float a0 = in3[tok * 3], a1 = in3[tok * 3 + 1], a2 = in3[tok * 3 + 2];
-            float d0 = 0.f, d1 = 0.f, d2 = 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                aw[e][0] += gv[e] * a0; aw[e][1] += gv[e] * a1; aw[e][2] += gv[e] * a2;
-                ab[e] += gv[e];
-                if (pass == 0) apA[e] += gv[e]; else apB[e] += gv[e];
-                d0 += gv[e] * w[e][0]; d1 += gv[e] * w[e][1]; d2 += gv[e] * w[e][2];
-            }
-            if (din3 != nullptr) {
-                d0 = reduce16(d0); d1 = reduce16(d1); d2 = reduce16(d2);
-                if (sub == 0) { din3[tok * 3] = d0; din3[tok * 3 + 1] = d1; din3[tok * 3 + 2] = d2; }
-            }
+        for (int e = 0; e < 8; ++e) {
+            aw[e][0] += gv[e] * a0; aw[e][1] += gv[e] * a1; aw[e][2] += gv[e] * a2;
+            ab[e] += gv[e];
+            if (!second) apA[e] += gv[e]; else apB[e] += gv[e];
+            d0 += gv[e] * w[e][0]; d1 += gv[e] * w[e][1]; d2 += gv[e] * w[e][2];
         }
+        if (din3 != nullptr) {
+            d0 = reduce16(d0); d1 = reduce16(d1); d2 = reduce16(d2);
+            if (sub == 0) { din3[tok * 3] = d0; din3[tok * 3 + 1] = d1; din3[tok * 3 + 2] = d2; }
+        }
+    };
+    for (int64_t f0 = blockIdx.x; f0 < frames; f0 += (int64_t)EU * gridDim.x) {
+        float gv[EU][8], a[EU][3], gw[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, aq[3] = {0.f, 0.f, 0.f};
+        // joints 0..15 of EU frames: row rl of each; joint 16 of those frames: row rl < EU takes frame rl's
+#pragma unroll
+        for (int u = 0; u < EU; ++u) {
+            const int64_t f = f0 + (int64_t)u * gridDim.x;
+            const int64_t tok = (f < frames ? f : f0) * KASF_J + rl;
+            load8(g + tok * 128 + sub * 8, gv[u]);
+            a[u][0] = in3[tok * 3]; a[u][1] = in3[tok * 3 + 1]; a[u][2] = in3[tok * 3 + 2];
+        }
+        const int64_t f16 = f0 + (int64_t)rl * gridDim.x;
+        const bool has16 = rl < EU && f16 < frames;
+        if (has16) {
+            const int64_t tok = f16 * KASF_J + 16;
+            load8(g + tok * 128 + sub * 8, gw);
+            aq[0] = in3[tok * 3]; aq[1] = in3[tok * 3 + 1]; aq[2] = in3[tok * 3 + 2];
+        }
+#pragma unroll
+        for (int u = 0; u < EU; ++u) {
+            const int64_t f = f0 + (int64_t)u * gridDim.x;
+            if (f < frames) accumulate(gv[u], a[u][0], a[u][1], a[u][2], f * KASF_J + rl, false);
+        }
+        if (has16) accumulate(gw, aq[0], aq[1], aq[2], f16 * KASF_J + 16, true);
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         atomicAdd(dpos + rl * 128 + sub * 8 + e, apA[e]);
-        if (rl == 0) atomicAdd(dpos + 16 * 128 + sub * 8 + e, apB[e]);
+        float b16 = apB[e];                          // joint 16: rows rl < EU hold a share each (lanes 16 rl + sub of the first waves)
+        b16 += __shfl_xor(b16, 16);
+        b16 += __shfl_xor(b16, 32);
+        if (threadIdx.x < 16) atomicAdd(dpos + 16 * 128 + sub * 8 + e, b16);
     }
     for (int q = 0; q < 4; ++q) {               // q<3: dW[:, q], q==3: db
         __syncthreads();
@@ -597,7 +618,7 @@ void kasf_launch_prologue_fwd(int dt, hipStream_t s, const float* x, const float
 }
 void kasf_launch_embed_bwd(int dt, hipStream_t s, const void* g, const float* in3, const float* W, float* dW, float* db, float* dpos, float* din3,
                            int64_t frames) {
-    const unsigned grid = (unsigned)(frames < 512 ? frames : 512);
+    const unsigned grid = (unsigned)(frames < 128 ? frames : 128);
     if (dt == KASF_F32) hipLaunchKernelGGL(k_embed_bwd<float>, dim3(grid), dim3(256), 0, s, (const float*)g, in3, W, dW, db, dpos, din3, frames);
     else hipLaunchKernelGGL(k_embed_bwd<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)g, in3, W, dW, db, dpos, din3, frames);
 }

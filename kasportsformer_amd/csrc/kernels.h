@@ -159,7 +159,7 @@ void kasf_launch_linear_res_r(hipStream_t s, const void* A, const void* W, const
 // q_save / kv_save / o_save: what the backward pass reads (nullptr in evaluation: nothing but x_mid is written).  false: shape not covered.
 bool kasf_launch_attn_block_fwd(hipStream_t s, int bone, const void* x, const void* x_limb, const float* ln_g, const float* ln_b, const float* lnl_g,
                                 const float* lnl_b, const void* Wq, const void* Wkv, const void* Wproj, const float* bproj, const float* ls1, void* q_save,
-                                void* kv_save, void* o_save, void* out, int B, int T, int mode);
+                                void* kv_save, void* o_save, void* out, int B, int T, int mode, int form = -1 /* -1: default, 0: LDS-direct ring, 1: register prefetch */);
 
 // ---- k_gemm.hip: several bf16 weight gradients dW_j[N_j][128] += G_j^T X_j in one streaming launch + one finishing launch ----
 bool kasf_launch_wgrad_jobs(hipStream_t s, int njobs, const void* const* G, const void* const* X, const int* N, float* const* dW, float* const* dbias,
