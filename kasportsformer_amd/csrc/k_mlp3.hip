@@ -30,6 +30,13 @@ __device__ long long g_prof[32];
 #define TSTART() do {} while (0)
 #endif
 
+#ifndef KASF_FWD_SGB            // vector instructions scheduled behind each MFMA of the next slice
+#define KASF_FWD_SGB 9
+#endif
+#ifndef KASF_FWD_GELU_POLY      // measurement switch (-DKASF_FWD_GELU_POLY=0): the exponential form in the forward pass as well
+#define KASF_FWD_GELU_POLY 1
+#endif
+
 namespace {
 
 constexpr int S_BM = 32, S_THR = 512, TL = S_BM * 128;
@@ -111,7 +118,7 @@ __global__ __launch_bounds__(S_THR) void k_mlp_fwd_s(const bf16* __restrict__ X,
                         y[2 * mt] = f32x2{acc[nt & 1][mt][0], acc[nt & 1][mt][1]};
                         y[2 * mt + 1] = f32x2{acc[nt & 1][mt][2], acc[nt & 1][mt][3]};
                     }
-                    gelu_pairs_fast(y);
+                    if (KASF_FWD_GELU_POLY) gelu_pairs_poly(y); else gelu_pairs_fast(y);
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt) {
                         const float h[4] = {y[2 * mt][0], y[2 * mt][1], y[2 * mt + 1][0], y[2 * mt + 1][1]};
@@ -121,7 +128,7 @@ __global__ __launch_bounds__(S_THR) void k_mlp_fwd_s(const bf16* __restrict__ X,
 #pragma unroll
                         for (int k = 0; k < 8; ++k) {
                             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                            __builtin_amdgcn_sched_group_barrier(0x002, 9, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x002, KASF_FWD_SGB, 0);
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
