@@ -154,15 +154,23 @@ __global__ __launch_bounds__(S_THR) void k_mlp_fwd_s(const bf16* __restrict__ X,
 #endif
         bf16x8 w2f[2][16];
 
-        auto issue = [&](int64_t t) {                    // two LDS-direct loads per consumer wave: rows [8c, 8c + 8) of tile t, the rows it will normalise
-            const int64_t tt = t < ntiles ? t : ntiles - 1;
-            const int64_t row0 = (tile0 + tt) * S_BM;
-            const int nvalid = (int)((M - row0) < S_BM ? (M - row0) : S_BM);
-            const unsigned base = __builtin_amdgcn_readfirstlane(lds_addr(sXr + (int)(t & 3) * TL));
-            const void* ub = uniform_ptr(X + row0 * 128);
+        // two LDS-direct loads per consumer wave: rows [8c, 8c + 8) of tile t, the rows it will normalise.  Tile-invariant parts once (see k_mlp_bwd_s).
+        const int nt32 = (int)ntiles;
+        const int64_t rows_here = M - tile0 * S_BM;
+        const int rows_in_range = (int)(rows_here < (int64_t)nt32 * S_BM ? rows_here : (int64_t)nt32 * S_BM);
+        const void* uxb = uniform_ptr(X + tile0 * S_BM * 128);
+        const unsigned ldsX = __builtin_amdgcn_readfirstlane(lds_addr(sXr));
+        auto issue = [&](int t) {
+            const int tt = t < nt32 ? t : nt32 - 1;
+            int nvalid = rows_in_range - tt * S_BM;
+            nvalid = nvalid < S_BM ? nvalid : S_BM;
+            const void* ub = (const char*)uxb + (unsigned)tt * (S_BM * 256u);
+            const unsigned base = ldsX + (unsigned)(t & 3) * (TL * 2u);
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                const int inst = 2 * c + k, row = inst * 4 + (lane >> 4), pc = lane & 15, ch = pc ^ (row & 15);
+                const int inst = 2 * c + k, row = inst * 4 + (ln >> 4), ch = (ln & 15) ^ (row & 15);
                 const int srow = row < nvalid ? row : nvalid - 1;
                 glds16_s(ub, (unsigned)srow * 256u + (unsigned)ch * 16u, base + (unsigned)inst * 1024u);
             }
@@ -203,7 +211,7 @@ __global__ __launch_bounds__(S_THR) void k_mlp_fwd_s(const bf16* __restrict__ X,
         barrier_keep_async();
         TSTART();
         for (int64_t t = 0; t <= ntiles; ++t) {
-            issue(t + 2);
+            issue((int)t + 2);
             TMARK(8);                                // into the slot of x(t-2)
             f32x4 acc2[2][2];
             if (t >= 1) {                                // GEMM2 of tile t-1 over all 512 hidden units
@@ -582,21 +590,34 @@ __global__ __launch_bounds__(S_THR) void k_mlp_bwd_s(const bf16* __restrict__ XN
         f32x4 accW1[4][4], accW2[4][4];
         zero_acc(accW1);
         zero_acc(accW2);
-        auto issue = [&](int64_t t, int slot) {          // four LDS-direct loads per consumer wave: rows [8c, 8c + 8) of g and LN(x) of tile t
-            const int64_t tt = t < ntiles ? t : 0;       // past the range: harmless re-read that keeps the per-issue load count constant
-            const int64_t row0 = (tile0 + tt) * S_BM;
-            const int nvalid = t < ntiles ? (int)((M - row0) < S_BM ? (M - row0) : S_BM) : 1;
-            const unsigned baseG = __builtin_amdgcn_readfirstlane(lds_addr(sG + slot * TL));
-            const unsigned baseA = __builtin_amdgcn_readfirstlane(lds_addr(sA + slot * TL));
-            const void* ug = uniform_ptr(G + row0 * 128);
-            const void* ua = uniform_ptr(XN + row0 * 128);
+        // four LDS-direct loads per consumer wave: rows [8c, 8c + 8) of g and LN(x) of tile t.  Everything that does not change from tile to tile is
+        // computed once: the two wave-uniform bases of this range (SGPR pairs), the per-lane byte offset inside a tile and the LDS offset of the lane
+        // group; per tile a 32-bit tile offset is added (a range is far below 4 GB).  (The first form rebuilt 64-bit addresses, row counts and selects
+        // from t every time: ~45 scalar instructions in a dependent chain per tile on the wave that bounds the kernel.)
+        const int nt32 = (int)ntiles;
+        const int64_t rows_here = M - tile0 * S_BM;
+        const int rows_in_range = (int)(rows_here < (int64_t)nt32 * S_BM ? rows_here : (int64_t)nt32 * S_BM);
+        const void* ugb = uniform_ptr(G + tile0 * S_BM * 128);
+        const void* uab = uniform_ptr(XN + tile0 * S_BM * 128);
+        const unsigned ldsG = __builtin_amdgcn_readfirstlane(lds_addr(sG)), ldsA = __builtin_amdgcn_readfirstlane(lds_addr(sA));
+        auto issue = [&](int t, int slot) {
+            const int tt = t < nt32 ? t : 0;             // past the range: harmless re-read that keeps the per-issue load count constant
+            int nvalid = rows_in_range - tt * S_BM;
+            nvalid = t < nt32 ? (nvalid < S_BM ? nvalid : S_BM) : 1;
+            const unsigned tile_off = (unsigned)tt * (S_BM * 256u), slot_off = (unsigned)slot * (TL * 2u);
+            const void* ug = (const char*)ugb + tile_off;             // two scalar adds each
+            const void* ua = (const char*)uab + tile_off;
+            int ln = lane;
+            asm volatile("" : "+v"(ln));                 // re-derive the lane's row / chunk here (six vector instructions) instead of holding four more
+                                                         // registers across the loop: the kernel sits at the 256-VGPR cap and would spill a prologue iteration
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                const int inst = 2 * c + k, row = inst * 4 + (lane >> 4), pc = lane & 15, chn = pc ^ (row & 15);
+                const int row = (2 * c + k) * 4 + (ln >> 4);
                 const int srow = row < nvalid ? row : nvalid - 1;
-                const unsigned off = (unsigned)srow * 256u + (unsigned)chn * 16u;
-                glds16_s(ug, off, baseG + (unsigned)inst * 1024u);
-                glds16_s(ua, off, baseA + (unsigned)inst * 1024u);
+                const unsigned off = (unsigned)srow * 256u + (unsigned)(((ln & 15) ^ (row & 15)) * 16);
+                const unsigned lo = slot_off + (unsigned)(2 * c + k) * 1024u;
+                glds16_s(ug, off, ldsG + lo);
+                glds16_s(ua, off, ldsA + lo);
             }
         };
         issue(0, 0);                                     // the first tiles are in flight while the weights arrive from L2
@@ -612,7 +633,7 @@ __global__ __launch_bounds__(S_THR) void k_mlp_bwd_s(const bf16* __restrict__ XN
         TSTART();
         int si = 3, sc = 4;                              // ring slots of tile t+3 (issued) and tile t-1 (consumed), rolling mod 5
         for (int64_t t = 0; t <= ntiles; ++t, si = si == 4 ? 0 : si + 1, sc = sc == 4 ? 0 : sc + 1) {
-            issue(t + 3, si);                            // into the slot of tile t-2: three tiles of HBM latency cover
+            issue((int)t + 3, si);                            // into the slot of tile t-2: three tiles of HBM latency cover
             TMARK(24);
             f32x4 accA[2][2];
             if (t >= 1) {
