@@ -11,6 +11,7 @@
 // HBM traffic per token: 256 B in (512 B for the bone form), 256 B out, plus -- in training only -- q|k|v and the attention output,
 // which the backward pass needs (written once).  The unfused path moved 2.8 KB per token.
 #include <cstdlib>
+#include <type_traits>
 #include "common.h"
 #include "kernels.h"
 #include "tile_ops.h"
@@ -472,6 +473,242 @@ __global__ __launch_bounds__(AB_THR, BONE ? KASF_RP_BONE_WAVES : 4) void k_attn_
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same block for groups of 33..96 positions (temporal attention at T = 81): three 32-position tiles per group, one workgroup per CU
+// (147 KB of LDS: raw x, ONE LayerNorm tile, head outputs, 72 KB of wave-private q | k | v tiles).  What differs from the one-tile form:
+//   * the LayerNorm tile is used twice per group in the bone form (LN(x) for q, then LN_limb(x_limb) for k | v: two more barriers, negligible
+//     against a group this long) and a third time as the x_mid staging tile of the copy-out;
+//   * the core is k_attn_fwd_mfma<3>'s: per 32-query tile three score tiles, lane-local softmax over 96 keys, six PV products.
+// Replaces three launches (LN + QKV linear, attention core, proj + residual linear; four in the bone form) and the round trips of q | k | v
+// and the head outputs through HBM between them.
+// ---------------------------------------------------------------------------------------------------------------
+template <bool BONE>
+__global__ __launch_bounds__(AB_THR, 2) void k_attn_blk_fwd_rp3(const AttnBlkArgs a) {
+    constexpr int NKT = 3, R = 32 * NKT, RT = R * 128, HT = R * 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* sX = reinterpret_cast<bf16*>(smem);           // [96][128] raw x (the residual's operand)
+    bf16* sA = sX + RT;                                 // [96][128] LN(x), then (bone) LN_limb(x_limb), then x_mid
+    bf16* sO = sA + RT;                                 // [96][128] attention output of the 8 heads
+    bf16* sHead = sO + RT;                              // [8 waves][q | k | v][96][16] wave-private operand tiles
+    float* sLn = reinterpret_cast<float*>(sHead + 8 * 3 * HT);       // [6][128]
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4, sub = lane & 15, rl = threadIdx.x >> 4;
+    const int r32 = lane & 31, hh = lane >> 5;
+    const int L = a.L;
+    const int per = (a.groups + gridDim.x - 1) / gridDim.x;
+    const int g0 = blockIdx.x * per;
+    int ng = a.groups - g0;
+    if (ng > per) ng = per;
+    if (ng <= 0) return;
+    bf16* sQh = sHead + w * 3 * HT;
+    bf16* sKh = sQh + HT;
+    bf16* sVh = sKh + HT;
+    bf16x8 wq[3][4], wp[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        if (BONE) {
+            wq[0][ks] = *reinterpret_cast<const bf16x8*>(a.Wq + (int64_t)(16 * w + i) * 128 + 32 * ks + 8 * g);
+            wq[1][ks] = *reinterpret_cast<const bf16x8*>(a.Wkv + (int64_t)(16 * w + i) * 128 + 32 * ks + 8 * g);
+            wq[2][ks] = *reinterpret_cast<const bf16x8*>(a.Wkv + (int64_t)(128 + 16 * w + i) * 128 + 32 * ks + 8 * g);
+        } else {
+#pragma unroll
+            for (int nt = 0; nt < 3; ++nt) wq[nt][ks] = *reinterpret_cast<const bf16x8*>(a.Wq + (int64_t)(128 * nt + 16 * w + i) * 128 + 32 * ks + 8 * g);
+        }
+        wp[ks] = *reinterpret_cast<const bf16x8*>(a.Wproj + (int64_t)(16 * w + i) * 128 + 32 * ks + 8 * g);
+    }
+    if (threadIdx.x < 128) {
+        sLn[threadIdx.x] = a.ln_g[threadIdx.x];
+        sLn[128 + threadIdx.x] = a.ln_b[threadIdx.x];
+        if (BONE) { sLn[256 + threadIdx.x] = a.lnl_g[threadIdx.x]; sLn[384 + threadIdx.x] = a.lnl_b[threadIdx.x]; }
+        sLn[512 + threadIdx.x] = a.bproj[threadIdx.x];
+        sLn[640 + threadIdx.x] = a.ls1[threadIdx.x];
+    }
+    const int stride = a.mode == 0 ? 1 : KASF_J;
+    auto base_of = [&](int G) { return a.mode == 0 ? G * KASF_J : (G / KASF_J) * a.T * KASF_J + (G % KASF_J); };
+    unsigned ox[NKT];
+#pragma unroll
+    for (int j = 0; j < NKT; ++j) {
+        const int row = rl + 32 * j, rc = row < L ? row : L - 1;
+        ox[j] = (unsigned)(rc * stride) * 128u + sub * 8;
+    }
+    bf16x8 xN[NKT], lN[NKT];
+    auto fetch = [&](int t) {
+        const unsigned b = (unsigned)base_of(g0 + t) * 128u;
+#pragma unroll
+        for (int j = 0; j < NKT; ++j) {
+            xN[j] = *reinterpret_cast<const bf16x8*>(a.X + (size_t)(b + ox[j]));
+            if (BONE) lN[j] = *reinterpret_cast<const bf16x8*>(a.XL + (size_t)(b + ox[j]));
+        }
+    };
+    auto layernorm = [&](const bf16x8 raw, int row, const float* gp, const float* bp) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (float)raw[e];
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[e];
+        const float mean = reduce16(s) * (1.0f / 128.0f);
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { v[e] -= mean; q += v[e] * v[e]; }
+        const float rstd = rsqrtf(reduce16(q) * (1.0f / 128.0f) + KASF_LN_EPS);
+        const f32x4 g0v = *reinterpret_cast<const f32x4*>(gp + sub * 8), g1v = *reinterpret_cast<const f32x4*>(gp + sub * 8 + 4);
+        const f32x4 b0v = *reinterpret_cast<const f32x4*>(bp + sub * 8), b1v = *reinterpret_cast<const f32x4*>(bp + sub * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = v[e] * rstd * g0v[e] + b0v[e]; v[4 + e] = v[4 + e] * rstd * g1v[e] + b1v[e]; }
+        tile_store8(sA, row, sub * 8, v);
+    };
+    // feature tiles [nt0, nt0 + NN) of this head out of the rows in sA -> the wave-private tiles
+    auto project = [&](auto NT0, auto NNc) {
+        constexpr int nt0 = decltype(NT0)::value, NN = decltype(NNc)::value;
+#pragma unroll
+        for (int jb = 0; jb < NKT; ++jb) {
+            f32x4 acc[NN][2];
+            zero_acc(acc);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 f0 = tok_frag(sA, 32 * jb + i, ks), f1 = tok_frag(sA, 32 * jb + 16 + i, ks);
+#pragma unroll
+                for (int nt = 0; nt < NN; ++nt) {
+                    acc[nt][0] = mfma16(wq[nt0 + nt][ks], f0, acc[nt][0]);
+                    acc[nt][1] = mfma16(wq[nt0 + nt][ks], f1, acc[nt][1]);
+                }
+            }
+#pragma unroll
+            for (int nt = 0; nt < NN; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    float v[4] = {acc[nt][mt][0], acc[nt][mt][1], acc[nt][mt][2], acc[nt][mt][3]};
+                    store4(sQh + (nt0 + nt) * HT + (32 * jb + 16 * mt + i) * 16 + 4 * g, v);
+                }
+        }
+    };
+    fetch(0);
+    __syncthreads();                                     // sLn
+    for (int t = 0; t < ng; ++t) {
+        const int G = g0 + t;
+        const bf16x8 zero = {};
+        bf16x8 lc[NKT];
+#pragma unroll
+        for (int j = 0; j < NKT; ++j) {
+            const int row = rl + 32 * j;
+            const bf16x8 xc = row < L ? xN[j] : zero;
+            lc[j] = row < L ? lN[j] : zero;
+            *reinterpret_cast<bf16x8*>(sX + Tile<bf16>::chunk_off(row, sub)) = xc;
+            layernorm(xc, row, sLn, sLn + 128);
+        }
+        if (t + 1 < ng) fetch(t + 1);
+        __syncthreads();                                 // B1: raw and LN(x) tiles complete; every wave finished the copy-out of the previous group
+        if (BONE) {
+            project(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});          // q_h from LN(x)
+            __syncthreads();                             // every wave is done with LN(x)
+#pragma unroll
+            for (int j = 0; j < NKT; ++j) layernorm(lc[j], rl + 32 * j, sLn + 256, sLn + 384);
+            __syncthreads();                             // LN_limb(x_limb) complete
+            project(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});          // k_h, v_h
+        } else {
+            project(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{});
+        }
+        lds_fence();
+        if (a.Qs != nullptr) {   // training: the backward pass reads q | k | v
+#pragma unroll
+            for (int jb = 0; jb < NKT; ++jb) {
+                const int pos = 32 * jb + r32;
+                if (pos < L) {
+                    const unsigned tok = (unsigned)(base_of(G) + pos * stride);
+                    const bf16x8 qv = *reinterpret_cast<const bf16x8*>(sQh + pos * 16 + 8 * hh), kv = *reinterpret_cast<const bf16x8*>(sKh + pos * 16 + 8 * hh),
+                                 vv = *reinterpret_cast<const bf16x8*>(sVh + pos * 16 + 8 * hh);
+                    if (BONE) {
+                        *reinterpret_cast<bf16x8*>(a.Qs + (size_t)(tok * 128u + 16 * w + 8 * hh)) = qv;
+                        *reinterpret_cast<bf16x8*>(a.KVs + (size_t)(tok * 256u + 16 * w + 8 * hh)) = kv;
+                        *reinterpret_cast<bf16x8*>(a.KVs + (size_t)(tok * 256u + 128 + 16 * w + 8 * hh)) = vv;
+                    } else {
+                        *reinterpret_cast<bf16x8*>(a.Qs + (size_t)(tok * 384u + 16 * w + 8 * hh)) = qv;
+                        *reinterpret_cast<bf16x8*>(a.Qs + (size_t)(tok * 384u + 128 + 16 * w + 8 * hh)) = kv;
+                        *reinterpret_cast<bf16x8*>(a.Qs + (size_t)(tok * 384u + 256 + 16 * w + 8 * hh)) = vv;
+                    }
+                }
+            }
+        }
+        {   // ---- attention core of head w (k_attn_fwd_mfma<3>) ----
+            bf16x8 kf[NKT];
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) kf[kt] = *reinterpret_cast<const bf16x8*>(sKh + (32 * kt + r32) * 16 + 8 * hh);
+            f32x16 z;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) z[e] = 0.f;
+#pragma unroll
+            for (int qt = 0; qt < NKT; ++qt) {
+                if (32 * qt >= L) break;
+                const bf16x8 qf = *reinterpret_cast<const bf16x8*>(sQh + (32 * qt + r32) * 16 + 8 * hh);
+                f32x16 st[NKT];
+                float mx = -INFINITY;
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt) {
+                    st[kt] = mfma32(kf[kt], qf, z);
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const float sv = (32 * kt + pos_of(e, hh) < L) ? st[kt][e] * 0.25f : -INFINITY;
+                        st[kt][e] = sv;
+                        mx = fmaxf(mx, sv);
+                    }
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                float sum = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) { st[kt][e] = __expf(st[kt][e] - mx); sum += st[kt][e]; }
+                sum += __shfl_xor(sum, 32);
+                const float inv = 1.0f / sum;
+                f32x16 ot = z;
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) st[kt][e] *= inv;
+                    ot = mfma32(tr_frag(sVh, 2 * kt), pack8(st[kt], 0), ot);
+                    ot = mfma32(tr_frag(sVh, 2 * kt + 1), pack8(st[kt], 1), ot);
+                }
+                float o0[4] = {ot[0], ot[1], ot[2], ot[3]}, o1[4] = {ot[4], ot[5], ot[6], ot[7]};
+                store4(sO + Tile<bf16>::off4(32 * qt + r32, 16 * w + 4 * hh), o0);
+                store4(sO + Tile<bf16>::off4(32 * qt + r32, 16 * w + 8 + 4 * hh), o1);
+            }
+        }
+        __syncthreads();                                 // B2: all heads in sO; sA has no readers left
+        {   // ---- output projection + layer-scale + residual: 16 channels x 96 positions per wave, x_mid staged in sA ----
+            const f32x4 bpv = *reinterpret_cast<const f32x4*>(sLn + 512 + 16 * w + 4 * g), lsv = *reinterpret_cast<const f32x4*>(sLn + 640 + 16 * w + 4 * g);
+#pragma unroll
+            for (int jb = 0; jb < NKT; ++jb) {
+                f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    acc[0] = mfma16(wp[ks], tok_frag(sO, 32 * jb + i, ks), acc[0]);
+                    acc[1] = mfma16(wp[ks], tok_frag(sO, 32 * jb + 16 + i, ks), acc[1]);
+                }
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    float x[4], v[4];
+                    load4(sX + Tile<bf16>::off4(32 * jb + 16 * mt + i, 16 * w + 4 * g), x);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = x[r] + lsv[r] * (acc[mt][r] + bpv[r]);
+                    store4(sA + Tile<bf16>::off4(32 * jb + 16 * mt + i, 16 * w + 4 * g), v);
+                }
+            }
+        }
+        __syncthreads();                                 // B3: x_mid tile complete
+#pragma unroll
+        for (int j = 0; j < NKT; ++j) {   // ---- full-row stores: x_mid always; o only when the backward pass will need it ----
+            const int row = rl + 32 * j;
+            if (row < L) {
+                const unsigned tok = (unsigned)(base_of(G) + row * stride);
+                const int co = Tile<bf16>::chunk_off(row, sub);
+                *reinterpret_cast<f32x4*>(a.OUT + (size_t)(tok * 128u + sub * 8)) = *reinterpret_cast<const f32x4*>(sA + co);
+                if (a.Qs != nullptr) *reinterpret_cast<f32x4*>(a.Os + (size_t)(tok * 128u + sub * 8)) = *reinterpret_cast<const f32x4*>(sO + co);
+            }
+        }
+        __syncthreads();                                 // B4: the next group's LayerNorm overwrites sA
+    }
+}
+
 }  // namespace
 
 // Returns false when the shape is outside the fused kernel's range (groups longer than 32 positions): the caller runs the unfused sequence.
@@ -479,13 +716,26 @@ bool kasf_launch_attn_block_fwd(hipStream_t s, int bone, const void* x, const vo
                                 const float* lnl_b, const void* Wq, const void* Wkv, const void* Wproj, const float* bproj, const float* ls1, void* q_save,
                                 void* kv_save, void* o_save, void* out, int B, int T, int mode, int form) {
     const int L = mode == 0 ? KASF_J : T;
-    if (L > 32) return false;
+    static const bool no_long = getenv("KASF_NO_ATTN_BLOCK_LONG") != nullptr;       // measurement switch: groups of 33..96 positions run unfused
+    if (L > 96 || (L > 32 && no_long)) return false;
     AttnBlkArgs a;
     a.X = (const bf16*)x; a.XL = (const bf16*)x_limb; a.ln_g = ln_g; a.ln_b = ln_b; a.lnl_g = lnl_g; a.lnl_b = lnl_b;
     a.Wq = (const bf16*)Wq; a.Wkv = (const bf16*)Wkv; a.Wproj = (const bf16*)Wproj; a.bproj = bproj; a.ls1 = ls1;
     a.Qs = (bf16*)q_save; a.KVs = (bf16*)kv_save; a.Os = (bf16*)o_save; a.OUT = (bf16*)out;
     a.L = L; a.T = T; a.mode = mode; a.groups = mode == 0 ? B * T : B * KASF_J;
     if (a.groups <= 0) return true;
+    if (L > 32) {                                       // three-tile groups: one workgroup per CU
+        const unsigned grid = (unsigned)(a.groups < 256 ? a.groups : 256);
+        const size_t sh = (size_t)3 * 96 * 128 * 2 + (size_t)8 * 3 * 96 * 16 * 2 + 6 * 128 * 4;
+        if (bone) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_blk_fwd_rp3<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+            hipLaunchKernelGGL(k_attn_blk_fwd_rp3<true>, dim3(grid), dim3(AB_THR), sh, s, a);
+        } else {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_blk_fwd_rp3<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+            hipLaunchKernelGGL(k_attn_blk_fwd_rp3<false>, dim3(grid), dim3(AB_THR), sh, s, a);
+        }
+        return true;
+    }
     // form: 0 = LDS-direct ring (round 1), 1 = register prefetch (default); KASF_ATTN_FWD_FORM=0/1: measurement switch.
     static const int env_form = getenv("KASF_ATTN_FWD_FORM") ? atoi(getenv("KASF_ATTN_FWD_FORM")) : -1;
     const int use_rp = form >= 0 ? form : (env_form >= 0 ? env_form : 1);

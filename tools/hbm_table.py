@@ -1,16 +1,18 @@
 """Achieved HBM bandwidth of the memory-bound kernels against their ALGORITHMIC bytes, from a rocprofv3 kernel trace.
 
-    python tools/hbm_table.py gpurun_out/prof27/t27_kernel_stats.csv [B T] > profiles/r2_op_hbm.json
+    python tools/hbm_table.py <single-stream kernel_stats.csv> [B T [three-stream kernel_stats.csv]] > profiles/r2_op_hbm.json
 
-Duration = the MINIMUM over the launches of the trace (three training steps on three concurrent streams: the minimum is the launch that ran
-closest to alone; the averages in the same file are inflated by the overlap).  Bytes = the external inputs and outputs of the fused op per
-token x M tokens (s = 2 bytes in bf16 mode), as listed in DESIGN §4: re-reads from L2 are not counted, so the figure is a lower bound of what
-moved; peak = 8 TB/s (MI355X_MICROARCH.md).
+Duration = the AVERAGE over the launches of a trace taken with KASF_SINGLE_STREAM=1 (tools/prof27.sh: the three branches serialised, every kernel
+alone on the chip: isolated durations).  If the three-stream trace of the same workload is given, its averages are listed beside them (what a
+launch takes while two other kernels share the chip).  Bytes = the external inputs and outputs of the fused op per token x M tokens (s = 2 bytes in
+bf16 mode), as listed in DESIGN §4: re-reads from L2 are not counted, so the figure is a lower bound of what moved; peak = 8 TB/s
+(MI355X_MICROARCH.md).
 """
 import csv, json, re, sys
 
 stats = sys.argv[1]
 B, T = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (256, 27)
+stats3 = sys.argv[4] if len(sys.argv) > 4 else None
 M, s = B * T * 17, 2
 # bytes per token (bf16): reads + writes of the kernel's external operands
 ALG = {
@@ -31,25 +33,40 @@ ALG = {
     "k_gcn_bwd2_temporal": ("BatchNorm backward + transposed masked aggregate: r, y, masks in, dU|dV out", (2 * 128 + 256) * s + 12),
     "k_gate_fwd": ("3-way softmax gate: 3 streams in, 1 out (+alpha)", 4 * 128 * s + 16),
     "k_gate_bwd": ("gate backward: g (+2 addends), 3 streams, alpha in; 3 gradients out", 9 * 128 * s + 16),
-    "k_attn_blk_fwd<false>": ("fused attention block fwd: x in; q|k|v, o, x_mid out", (128 + 384 + 128 + 128) * s),
-    "k_attn_blk_fwd<true>": ("fused bone block fwd: x, x_limb in; q, k|v, o, x_mid out", (256 + 384 + 128 + 128) * s),
-    "k_attn_bwd_mfma<1, true>": ("attention backward cores + d_o: q|k|v, g_mid in; dq|dk|dv out", (384 + 128 + 384) * s),
+    "k_attn_blk_fwd_rp<false>": ("fused attention block fwd: x in; q|k|v, o, x_mid out", (128 + 384 + 128 + 128) * s),
+    "k_attn_blk_fwd_rp<true>": ("fused bone block fwd: x, x_limb in; q, k|v, o, x_mid out", (256 + 384 + 128 + 128) * s),
+    "k_attn_blk_fwd<false>": ("fused attention block fwd, ring form: x in; q|k|v, o, x_mid out", (128 + 384 + 128 + 128) * s),
+    "k_attn_blk_fwd<true>": ("fused bone block fwd, ring form: x, x_limb in; q, k|v, o, x_mid out", (256 + 384 + 128 + 128) * s),
+    "k_attn_bwd_pers<9>": ("attention backward cores + d_o, 17-position groups: q|k|v, g_mid in; dq|dk|dv out", (384 + 128 + 384) * s),
+    "k_attn_bwd_pers<16>": ("attention backward cores + d_o, groups of 18..32 positions: q|k|v, g_mid in; dq|dk|dv out", (384 + 128 + 384) * s),
+    "k_attn_bwd_mfma<1, true>": ("attention backward cores + d_o, one group per workgroup: q|k|v, g_mid in; dq|dk|dv out", (384 + 128 + 384) * s),
+    "k_attn_bwd_long<3>": ("attention backward cores, 33..96-position groups: q|k|v, d_o in; dq|dk|dv out", (384 + 128 + 384) * s),
+    "k_attn_fwd_mfma<3>": ("attention forward core, 33..96-position groups: q|k|v in, o out", (384 + 128) * s),
     "k_wgrad_ring_jobs": ("all weight gradients of an attention block: g_mid, o, dqkv, LN(x) streamed once", (128 + 128 + 384 + 128) * s),
     "k_mlp_fwd_s": ("fused MLP fwd: x in; x_out, LN(x) out", 3 * 128 * s),
     "k_mlp_bwd_s<false>": ("fused MLP bwd: LN(x), g in; 4 dA partials out", (2 * 128 + 4 * 128) * s),
 }
-rows = {}
-for r in csv.DictReader(open(stats)):
-    m = re.search(r"(k_[a-z0-9_]+(<[^>]*>)?)", r["Name"])
-    if m:
-        rows[m.group(1)] = r
-out = {"workload": f"B={B}, T={T}: M = {M} tokens, bf16; one training step trace (three streams)", "peak_GBps": 8000, "kernels": {}}
+def load(path):
+    rows = {}
+    for r in csv.DictReader(open(path)):
+        m = re.search(r"(k_[a-z0-9_]+(<[^>]*>)?)", r["Name"])
+        if m:
+            rows[m.group(1)] = r
+    return rows
+
+
+rows, rows3 = load(stats), (load(stats3) if stats3 else {})
+out = {"workload": f"B={B}, T={T}: M = {M} tokens, bf16 training step; durations from a single-stream trace (isolated launches)", "peak_GBps": 8000, "kernels": {}}
 for k, (what, bpt) in ALG.items():
     hit = next((v for n, v in rows.items() if n.startswith(k)), None)
     if hit is None:
         continue
     nbytes, tmin, tavg = bpt * M, float(hit["MinNs"]) * 1e-9, float(hit["AverageNs"]) * 1e-9
-    out["kernels"][k] = {"what": what, "algorithmic_bytes_per_token": bpt, "algorithmic_MB_per_launch": round(nbytes / 1e6, 1), "calls": int(hit["Calls"]),
-                         "min_us": round(tmin * 1e6, 1), "in_step_avg_us": round(tavg * 1e6, 1), "achieved_GBps_at_min": round(nbytes / tmin / 1e9),
-                         "frac_of_8TBps": round(nbytes / tmin / 8e12, 3)}
+    e = {"what": what, "algorithmic_bytes_per_token": bpt, "algorithmic_MB_per_launch": round(nbytes / 1e6, 1), "launches_per_step": round(int(hit["Calls"]) / 3, 1),
+         "isolated_avg_us": round(tavg * 1e6, 1), "isolated_min_us": round(tmin * 1e6, 1), "achieved_GBps": round(nbytes / tavg / 1e9),
+         "frac_of_8TBps": round(nbytes / tavg / 8e12, 3)}
+    h3 = next((v for n, v in rows3.items() if n.startswith(k)), None)
+    if h3 is not None:
+        e["three_stream_avg_us"] = round(float(h3["AverageNs"]) * 1e-3, 1)
+    out["kernels"][k] = e
 print(json.dumps(out, indent=1))
