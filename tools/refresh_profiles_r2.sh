@@ -1,22 +1,44 @@
 #!/bin/bash
-# One GPU-box pass that regenerates the round-2 evidence under gpurun_out/ (copy into profiles/ afterwards).
-set -o pipefail
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
+# One GPU-box pass that regenerates the round-2 evidence under gpurun_out/r2/ (copy into profiles/ afterwards: the names match).
+# Order matters: the traces and counter passes come first and are copied into the box's profiles/ so that the bench line at the end quotes them.
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r2; P=$R/profiles
+mkdir -p $O; cd $R
+say() { echo "== $(date +%T) $*"; }
+say "three-stream traces"; cd /tmp; export TMPDIR=/tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/prof27 -o t --output-format csv -- python3 $R/tools/train_once.py 27 256 > $O/prof27.log 2>&1 || echo "prof27 failed"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/prof81 -o t --output-format csv -- python3 $R/tools/train_once.py 81 128 > $O/prof81.log 2>&1 || echo "prof81 failed"
+cp $O/prof27/t_kernel_stats.csv $O/r2_train_kernel_stats.csv; cp $O/prof81/t_kernel_stats.csv $O/r2_train81_kernel_stats.csv
+say "single-stream traces (isolated launches)"
+export KASF_SINGLE_STREAM=1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/prof27s -o t --output-format csv -- python3 $R/tools/train_once.py 27 256 > $O/prof27s.log 2>&1 || echo "prof27s failed"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/prof81s -o t --output-format csv -- python3 $R/tools/train_once.py 81 128 > $O/prof81s.log 2>&1 || echo "prof81s failed"
+unset KASF_SINGLE_STREAM
+cp $O/prof27s/t_kernel_stats.csv $O/r2_single_stream_kernel_stats.csv; cp $O/prof81s/t_kernel_stats.csv $O/r2_single_stream81_kernel_stats.csv
 cd $R
-timeout -k 10 300 python -m pytest tests/test_gpu_model.py -q -m gpu -k "head_counts or bare_constructor or arbitrary" > $O/r2_heads.log 2>&1; echo "heads/T tests rc=$?"; tail -2 $O/r2_heads.log
-timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/r2_smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $O/r2_smoke.log
-timeout -k 10 500 python bench.py > $O/r2_bench.json 2> $O/r2_bench.err; echo "bench rc=$?"
-timeout -k 10 200 python tools/op_bench.py > $O/r2_op_bench.txt 2>&1; echo "op_bench rc=$?"
-bash tools/prof_steps.sh
-python tools/hbm_table.py $O/prof27/t27_kernel_stats.csv 256 27 > $O/r2_op_hbm.json
-python tools/hbm_table.py $O/prof81/t81_kernel_stats.csv 128 81 > $O/r2_op_hbm_t81.json
-cd /tmp && export TMPDIR=/tmp
-for v in "" "KASF_MLP_BWD_XCHG=1"; do
-  tag=${v:+_xchg}
-  env $v timeout -k 10 150 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_f$tag -- python3 $R/tools/mlp_bench.py > $O/pmc_f$tag.log 2>&1 || echo "fetch failed"
-  env $v timeout -k 10 150 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_w$tag -- python3 $R/tools/mlp_bench.py > $O/pmc_w$tag.log 2>&1 || echo "write failed"
-  (cd $R && python tools/pmc_traffic.py gpurun_out/pmc_f$tag gpurun_out/pmc_w$tag gpurun_out/r2_pmc_traffic$tag.json > /dev/null)
-done
-env KASF_MLP_BWD_XCHG=1 timeout -k 10 150 rocprofv3 --kernel-trace --stats -d $O/profm_x -o m --output-format csv -- python3 $R/tools/mlp_bench.py > $O/profm_x.log 2>&1
-timeout -k 10 150 rocprofv3 --kernel-trace --stats -d $O/profm -o m --output-format csv -- python3 $R/tools/mlp_bench.py > $O/profm.log 2>&1
-echo done
+python tools/hbm_table.py $O/r2_single_stream_kernel_stats.csv 256 27 $O/r2_train_kernel_stats.csv > $O/r2_op_hbm.json
+python tools/hbm_table.py $O/r2_single_stream81_kernel_stats.csv 128 81 $O/r2_train81_kernel_stats.csv > $O/r2_op_hbm_t81.json
+say "whole-step HBM bytes"
+bash tools/pmc_step.sh > $O/pmc_step.log 2>&1; cp gpurun_out/pmc_step.json $O/r2_pmc_step.json; tail -1 $O/pmc_step.log
+say "MLP micro-benchmark: per-launch HBM bytes and durations"
+cd /tmp
+timeout -k 10 150 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_f -- python3 $R/tools/mlp_bench.py > $O/pmc_f.log 2>&1 || echo "fetch failed"
+timeout -k 10 150 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_w -- python3 $R/tools/mlp_bench.py > $O/pmc_w.log 2>&1 || echo "write failed"
+timeout -k 10 150 rocprofv3 --kernel-trace --stats -d $O/profm -o m --output-format csv -- python3 $R/tools/mlp_bench.py > $O/profm.log 2>&1 || echo "profm failed"
+cd $R; python tools/pmc_traffic.py gpurun_out/r2/pmc_f gpurun_out/r2/pmc_w gpurun_out/r2/r2_pmc_traffic.json > /dev/null; cp $O/profm/m_kernel_stats.csv $O/r2_mlp_microbench_kernel_stats.csv
+say "operator benches"
+timeout -k 10 200 python tools/op_bench.py > $O/r2_op_bench.txt 2>&1
+timeout -k 10 200 python tools/attn_bwd_bench.py 2>/dev/null > $O/r2_attn_bwd_bench.txt
+timeout -k 10 100 python tools/attn81_bench.py 2>/dev/null >> $O/r2_attn_bwd_bench.txt
+say "other configurations"
+: > $O/r2_configs.jsonl
+for c in train27fp32 train81 train243 eval; do timeout -k 10 300 python tools/bench_configs.py $c 2>/dev/null | grep '^{' >> $O/r2_configs.jsonl; done
+KASF_SINGLE_STREAM=1 timeout -k 10 200 python tools/bench_configs.py train27 2>/dev/null | grep '^{' | sed 's/"config": "train/"config": "KASF_SINGLE_STREAM=1 train/' >> $O/r2_configs.jsonl
+KASF_NO_ATTN_BLOCK_LONG=1 timeout -k 10 200 python tools/bench_configs.py train81 2>/dev/null | grep '^{' | sed 's/"config": "train/"config": "KASF_NO_ATTN_BLOCK_LONG=1 train/' >> $O/r2_configs.jsonl
+say "bench line (quotes the files above)"
+cp $O/r2_train_kernel_stats.csv $O/r2_pmc_step.json $O/r2_pmc_traffic.json $P/
+timeout -k 10 500 python bench.py > $O/r2_bench_b256.json 2> $O/bench.err; echo "bench rc=$?"
+say "segment timers (probe build: last, it replaces the library)"
+touch kasportsformer_amd/csrc/k_mlp3.hip && make -C kasportsformer_amd/csrc EXTRA="-DKASF_PROBE_TIMERS" 2>&1 | grep -E "error"
+timeout -k 10 120 python tools/mlp_timers.py 2>/dev/null > $O/r2_mlp_segment_timers.txt
+rm -rf $O/prof27 $O/prof81 $O/prof27s $O/prof81s $O/pmc_f $O/pmc_w $O/profm $R/gpurun_out/pmcs_f $R/gpurun_out/pmcs_w
+say done; ls $O
