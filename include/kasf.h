@@ -79,7 +79,8 @@ int kasf_pack_weights(const kasf_model* m, const float* params, void* packed, vo
 int64_t kasf_workspace_bytes(const kasf_model* m, int32_t batch, int32_t flags);
 
 /* x [B,T,17,3] fp32 -> out [B,T,17,3] fp32 (or [B,T,17,512] with KASF_FLAG_RETURN_REP).
- * `buffers` (BN running stats) is updated when KASF_FLAG_TRAIN is set.  x and out must not alias. */
+ * `buffers` (BN running stats) is updated when KASF_FLAG_TRAIN is set.  x and out must not alias.
+ * batch >= 1 and batch * n_frames * 17 * 384 < 2^31 (the kernels address activations with 32-bit element offsets): error 2 otherwise. */
 int kasf_forward(const kasf_model* m, const float* params, const void* packed, float* buffers, const float* x, float* out, void* workspace,
                  int64_t workspace_bytes, int32_t batch, int32_t flags, void* stream);
 
