@@ -120,25 +120,56 @@ __global__ __launch_bounds__(256) void k_gcn_agg_temporal(const T* __restrict__ 
             }
         }
         __syncthreads();
-        // k-th largest per row -> adjacency bits and degree (graph.py:104-112: ties kept)
-        for (int r = threadIdx.x; r < L; r += 256) {
+        // k-th largest per row -> adjacency bits and degree (graph.py:104-112: ties kept).  FOUR lanes per row, columns interleaved (c = j mod 4): each keeps
+        // the four largest of its columns (with multiplicity), two butterfly merges leave the row's four largest in every lane of the quad, each lane then
+        // sets the mask bits of its own columns and the words are OR-ed across the quad.  (One lane per row left 81 of 256 threads scanning 81 columns
+        // twice -- a fifth of the launch at T = 81 -- and the rest idle.)
+        for (int r0 = 0; r0 < L; r0 += 64) {
+            const int r = r0 + (threadIdx.x >> 2), j = threadIdx.x & 3;
+            const bool live = r < L;
             float top[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-            for (int c = 0; c < L; ++c) {
-                float v = sS[r * (LP + 1) + c];
+            if (live) {
+                for (int c = j; c < L; c += 4) {
+                    float v = sS[r * (LP + 1) + c];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (v > top[e]) { const float t = top[e]; top[e] = v; v = t; }
+                    for (int e = 0; e < 4; ++e) {
+                        if (v > top[e]) { const float t = top[e]; top[e] = v; v = t; }
+                    }
+                }
+            }
+#pragma unroll
+            for (int m = 1; m <= 2; m <<= 1) {               // merge with the partner's sorted four (all lanes of the wave take part in the shuffles)
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = __shfl_xor(top[e], m);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v = o[q];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (v > top[e]) { const float t = top[e]; top[e] = v; v = t; }
+                    }
                 }
             }
             const float thr = kth <= 1 ? top[0] : (kth == 2 ? top[1] : (kth == 3 ? top[2] : top[3]));
             uint32_t wd[MASK_W] = {0u, 0u, 0u};
             int deg = 0;
-            for (int c = 0; c < L; ++c) {
-                if (sS[r * (LP + 1) + c] >= thr) { wd[c >> 5] |= 1u << (c & 31); ++deg; }
+            if (live) {
+                for (int c = j; c < L; c += 4) {
+                    if (sS[r * (LP + 1) + c] >= thr) { wd[c >> 5] |= 1u << (c & 31); ++deg; }
+                }
             }
 #pragma unroll
-            for (int e = 0; e < MASK_W; ++e) { sMask[r * MASK_W + e] = wd[e]; mask[((int64_t)G * L + r) * MASK_W + e] = wd[e]; }
-            sDinv[r] = 1.0f / sqrtf((float)deg);
+            for (int m = 1; m <= 2; m <<= 1) {
+#pragma unroll
+                for (int e = 0; e < MASK_W; ++e) wd[e] |= (uint32_t)__shfl_xor((int)wd[e], m);
+                deg += __shfl_xor(deg, m);
+            }
+            if (live && j == 0) {
+#pragma unroll
+                for (int e = 0; e < MASK_W; ++e) { sMask[r * MASK_W + e] = wd[e]; mask[((int64_t)G * L + r) * MASK_W + e] = wd[e]; }
+                sDinv[r] = 1.0f / sqrtf((float)deg);
+            }
         }
         __syncthreads();
         for (int idx = threadIdx.x; idx < L * 16; idx += 256) {
@@ -398,14 +429,39 @@ __global__ __launch_bounds__(256) void k_gcn_bwd2_temporal(const T* __restrict__
         sDinv[r] = 1.0f / sqrtf((float)deg);
     }
     __syncthreads();
+    // The transposed aggregate needs, per column c, the rows r whose mask has bit c.  Testing all L rows per (column, chunk) item was the launch (81 x 81
+    // bit tests with an LDS read each, 116 us at T = 81): transpose the bit matrix once per track with wave ballots (lane = row, one ballot per column and
+    // 64-row half) and then visit set bits only, in ascending row order as before (same summation order: bit-identical results).
+    uint32_t* sMaskT = sMask + L * MASK_W;              // [L][MASK_W]: bit r of column c's words
+    {
+        const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        for (int c = w; c < L; c += 4) {
+#pragma unroll
+            for (int h = 0; h < (L + 63) / 64; ++h) {
+                const int r = 64 * h + lane;
+                const bool bit = r < L && ((sMask[r * MASK_W + (c >> 5)] >> (c & 31)) & 1u);
+                const unsigned long long bal = __ballot(bit);
+                if (lane == 0) {
+                    sMaskT[c * MASK_W + 2 * h] = (uint32_t)bal;
+                    if (2 * h + 1 < MASK_W) sMaskT[c * MASK_W + 2 * h + 1] = (uint32_t)(bal >> 32);
+                }
+            }
+        }
+    }
+    __syncthreads();
     for (int idx = threadIdx.x; idx < L * 16; idx += 256) {
         const int c = idx >> 4, sub = idx & 15;
         float acc[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-        for (int r = 0; r < L; ++r) {
-            if ((sMask[r * MASK_W + (c >> 5)] >> (c & 31)) & 1u) {
-                const float w = sDinv[r] * sDinv[c];
+        const float dc = sDinv[c];
+#pragma unroll
+        for (int wi = 0; wi < (L + 31) / 32; ++wi) {
+            uint32_t bits = sMaskT[c * MASK_W + wi];
+            while (bits) {
+                const int r = wi * 32 + __builtin_ctz(bits);
+                bits &= bits - 1;
+                const float w = sDinv[r] * dc;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) acc[e] += w * sDy[r * SX_LD + sub * 8 + e];
             }
@@ -567,7 +623,7 @@ template <typename K> void set_smem(K k, size_t bytes) {
 template <typename T, int L> constexpr size_t agg_smem() {
     return (size_t)(agg_lp<L>() + L) * 128 * sizeof(T) + (L * (agg_lp<L>() + 1) + L + 2 * L) * sizeof(float) + L * MASK_W * sizeof(uint32_t);
 }
-template <int L> constexpr size_t bwd2_smem() { return (L * SX_LD + L) * sizeof(float) + L * MASK_W * sizeof(uint32_t); }
+template <int L> constexpr size_t bwd2_smem() { return (L * SX_LD + L) * sizeof(float) + 2 * L * MASK_W * sizeof(uint32_t); }
 
 template <typename T, int L>
 void agg_temporal_TL(hipStream_t s, const void* uv, const void* xn, void* y, uint32_t* mask, double* stats, int B, int Tn) {
