@@ -98,11 +98,35 @@ __global__ __launch_bounds__(256) void k_gcn_agg_temporal(const T* __restrict__ 
     for (int G = blockIdx.x; G < n_tracks; G += gridDim.x) {
         const int b = G / KASF_J, j = G % KASF_J;
         auto tok = [&](int r) { return ((int64_t)b * Tn + r) * KASF_J + j; };
+        // ALL global reads of the track are issued here, before anything waits: the LN(x) and V chunks (raw 16-byte copies, no conversion on the way in)
+        // and the U chunks the aggregation adds at the very end.  (A load-store loop and a U load behind each item's gather made up to a dozen
+        // dependent HBM round trips per track.)
+        constexpr int NI = (L * CPR + 255) / 256, NI4 = (L * 16 + 255) / 256;
+        f32x4 rx[NI], rv[NI];
+        float ru[NI4][8];
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            const int idx = threadIdx.x + 256 * k;
+            if (idx < L * CPR) {
+                const int r = idx / CPR, ch = idx % CPR;
+                rx[k] = *reinterpret_cast<const f32x4*>(xn + tok(r) * 128 + ch * EPC);
+                rv[k] = *reinterpret_cast<const f32x4*>(uv + tok(r) * 256 + 128 + ch * EPC);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NI4; ++k) {
+            const int idx = threadIdx.x + 256 * k;
+            if (idx < L * 16) load8(uv + tok(idx >> 4) * 256 + (idx & 15) * 8, ru[k]);
+        }
         __syncthreads();                                // previous track fully consumed (and the zero fill / sStat init visible)
-        for (int idx = threadIdx.x; idx < L * CPR; idx += 256) {     // raw 16-byte copies: no conversion on the way in
-            const int r = idx / CPR, ch = idx % CPR;
-            *reinterpret_cast<f32x4*>(sX + Tile<T>::chunk_off(r, ch)) = *reinterpret_cast<const f32x4*>(xn + tok(r) * 128 + ch * EPC);
-            *reinterpret_cast<f32x4*>(sV + r * 128 + ch * EPC) = *reinterpret_cast<const f32x4*>(uv + tok(r) * 256 + 128 + ch * EPC);
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            const int idx = threadIdx.x + 256 * k;
+            if (idx < L * CPR) {
+                const int r = idx / CPR, ch = idx % CPR;
+                *reinterpret_cast<f32x4*>(sX + Tile<T>::chunk_off(r, ch)) = rx[k];
+                *reinterpret_cast<f32x4*>(sV + r * 128 + ch * EPC) = rv[k];
+            }
         }
         __syncthreads();
         for (int t = w; t < NTL * NTL; t += 4) {        // 16x16 tiles of S over the 4 waves
@@ -132,8 +156,10 @@ __global__ __launch_bounds__(256) void k_gcn_agg_temporal(const T* __restrict__ 
                 for (int c = j; c < L; c += 4) {
                     float v = sS[r * (LP + 1) + c];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (v > top[e]) { const float t = top[e]; top[e] = v; v = t; }
+                    for (int e = 0; e < 4; ++e) {          // compare-exchange as max / min (S is finite): two instructions per level
+                        const float hi = fmaxf(top[e], v);
+                        v = fminf(top[e], v);
+                        top[e] = hi;
                     }
                 }
             }
@@ -147,7 +173,9 @@ __global__ __launch_bounds__(256) void k_gcn_agg_temporal(const T* __restrict__ 
                     float v = o[q];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        if (v > top[e]) { const float t = top[e]; top[e] = v; v = t; }
+                        const float hi = fmaxf(top[e], v);
+                        v = fminf(top[e], v);
+                        top[e] = hi;
                     }
                 }
             }
@@ -172,7 +200,10 @@ __global__ __launch_bounds__(256) void k_gcn_agg_temporal(const T* __restrict__ 
             }
         }
         __syncthreads();
-        for (int idx = threadIdx.x; idx < L * 16; idx += 256) {
+#pragma unroll
+        for (int k4 = 0; k4 < NI4; ++k4) {
+            const int idx = threadIdx.x + 256 * k4;
+            if (idx >= L * 16) break;
             const int r = idx >> 4, sub = idx & 15;
             float acc[8];
 #pragma unroll
@@ -191,11 +222,9 @@ __global__ __launch_bounds__(256) void k_gcn_agg_temporal(const T* __restrict__ 
                     for (int e = 0; e < 8; ++e) acc[e] += wgt * v[e];
                 }
             }
-            float u[8];
-            load8(uv + tok(r) * 256 + sub * 8, u);
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { acc[e] += u[e]; const float q = to_f(from_f<T>(acc[e])); s1 += q; s2 += q * q; }
+            for (int e = 0; e < 8; ++e) { acc[e] += ru[k4][e]; const float q = to_f(from_f<T>(acc[e])); s1 += q; s2 += q * q; }
             store8(y + tok(r) * 128 + sub * 8, acc);
             s1 = reduce16(s1);
             s2 = reduce16(s2);
@@ -629,7 +658,11 @@ template <typename T, int L>
 void agg_temporal_TL(hipStream_t s, const void* uv, const void* xn, void* y, uint32_t* mask, double* stats, int B, int Tn) {
     const size_t sh = agg_smem<T, L>();
     set_smem(k_gcn_agg_temporal<T, L>, sh);
-    const int tracks = B * KASF_J, per = (tracks + 1023) / 1024;         // <= 1024 persistent workgroups, equal track counts
+    // persistent workgroups, equal track counts, ONE round: never more workgroups than fit on the chip at once (LDS bound; T = 81: 2 per CU -- 726
+    // workgroups of 3 tracks ran as a full round and a 42 % round, six track-times where five do)
+    int per_cu = (int)(160 * 1024 / sh);
+    per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
+    const int tracks = B * KASF_J, resident = 256 * per_cu, per = (tracks + resident - 1) / resident;
     hipLaunchKernelGGL((k_gcn_agg_temporal<T, L>), dim3((tracks + per - 1) / per), dim3(256), sh, s, (const T*)uv, (const T*)xn, (T*)y, mask,
                        stats, Tn, 4, tracks);
 }
