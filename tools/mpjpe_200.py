@@ -62,6 +62,11 @@ def hip_run(cd):
     return res_at
 
 
+if os.environ.get("HIP_BF16_REPEATS"):      # run-to-run spread of the bf16 leg alone (its gradients end in fp32 atomics): MPJPE at every checkpoint, N runs
+    for _ in range(int(os.environ["HIP_BF16_REPEATS"])):
+        r = hip_run("bf16")
+        print(json.dumps({str(c): round(r[c]["mpjpe_mm"], 3) for c in CHECK}), flush=True)
+    sys.exit(0)
 cores = max(1, min(16, os.cpu_count() or 1))
 t0 = time.time()
 ref = oracle_run(cores)
@@ -70,6 +75,10 @@ ref2 = oracle_run(max(1, cores // 4))            # the oracle against ITSELF wit
 out = {"steps": STEPS, "layers": L, "batch": B, "n_frames": T, "init": "reference default init, seed 114514", "oracle_seconds": round(t_ref, 1),
        "oracle_threads": [cores, max(1, cores // 4)], "checkpoints": {}}
 runs = {"fp32": hip_run("fp32"), "bf16": hip_run("bf16")}
+# the bf16 leg three more times: its gradients end in fp32 atomics, so every run is another trajectory of a chaotic system -- the spread is the
+# resolution of this comparison
+extra = [hip_run("bf16") for _ in range(3)]
+out["bf16_mpjpe_mm_of_4_runs"] = {str(c): [round(r[c]["mpjpe_mm"], 3) for r in [runs["bf16"]] + extra] for c in CHECK}
 for c in CHECK:
     row = {"oracle_mpjpe_mm": ref[c]["mpjpe_mm"], "oracle_vs_oracle_other_thread_count_abs_delta_mm": abs(ref[c]["mpjpe_mm"] - ref2[c]["mpjpe_mm"])}
     for cd, r in runs.items():
