@@ -507,6 +507,16 @@ __global__ __launch_bounds__(256) void k_mlp_wfinish(const float* __restrict__ p
     const int64_t e = (int64_t)blk * 512 + lane * 4;
     f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
     int z = half;
+    for (; z + 6 < splits; z += 8) {                    // four partial tiles in flight per thread; the order of the additions is the two-at-a-time loop's
+        const f32x4 u0 = *reinterpret_cast<const f32x4*>(part + (int64_t)z * 65536 + e);
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(part + (int64_t)(z + 2) * 65536 + e);
+        const f32x4 u1 = *reinterpret_cast<const f32x4*>(part + (int64_t)(z + 4) * 65536 + e);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(part + (int64_t)(z + 6) * 65536 + e);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { a[q] += u0[q]; b[q] += v0[q]; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { a[q] += u1[q]; b[q] += v1[q]; }
+    }
     for (; z + 2 < splits; z += 4) {
         const f32x4 u = *reinterpret_cast<const f32x4*>(part + (int64_t)z * 65536 + e);
         const f32x4 v = *reinterpret_cast<const f32x4*>(part + (int64_t)(z + 2) * 65536 + e);
