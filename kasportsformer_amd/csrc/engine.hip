@@ -702,7 +702,7 @@ int kasf_backward(const kasf_model* m, const float* params, const void* packed, 
         // the running gradient w.r.t. the current layer's output alternates between two buffers
         auto gbuf = [&](int k) { return c.w((k & 1) ? p.g_prev : p.g_layer); };
         if (st == 0) {
-            for (int br = 0; br < 3 && kasf_mlp_bwd_xchg_enabled(); ++br)      // hand-off flags of the experimental fused MLP backward: zero once per pass (every finishing kernel re-zeroes them)
+            for (int br = 0; br < 3; ++br)      // flag words behind the partial tiles (ticket of k_lnbwd_sum4_fin, hand-off flags of the experimental in-kernel reduction): zero once per pass, every launch leaves them zero
                 HIPCHK(hipMemsetAsync((char*)c.w(p.sc[br].wg_part) + (size_t)KASF_MLP_PARTIAL_FLOATS * 4, 0, (size_t)KASF_MLP_FLAG_WORDS * 4, c.s));
             HIPCHK(hipMemsetAsync(c.w(p.bstats_begin), 0, p.bstats_bytes, c.s));
             HIPCHK(hipMemsetAsync(c.w(p.g_limb), 0, c.M * 128 * c.es, c.s));
@@ -854,8 +854,7 @@ int kasf_op_mlp_bwd_fused(const void* x, const void* xn, const void* g, const fl
                           const void* w1t, void* dapart, float* partial, float* dw1, float* dw2_unscaled, float* db1, float* gsum, void* g_in,
                           float* dgamma, float* dbeta, int64_t M, void* stream) {
     if (!x || !xn || !g || !dapart || !partial || !dw1 || !dw2_unscaled || !db1 || !gsum || !g_in) return kasf_set_error(2, "null pointer argument");
-    if (kasf_mlp_bwd_xchg_enabled())
-        HIPCHK(hipMemsetAsync(partial + KASF_MLP_PARTIAL_FLOATS, 0, (size_t)KASF_MLP_FLAG_WORDS * 4, (hipStream_t)stream));     // hand-off flags + timeout word
+    HIPCHK(hipMemsetAsync(partial + KASF_MLP_PARTIAL_FLOATS, 0, (size_t)KASF_MLP_FLAG_WORDS * 4, (hipStream_t)stream));     // ticket, hand-off flags, timeout word
     kasf_launch_mlp_bwd_q((hipStream_t)stream, x, xn, g, ln_g, w1, b1, w2t_scaled, w1t, dapart, partial, dw1, dw2_unscaled, db1, gsum, g_in, dgamma,
                           dbeta, M);
     HIPCHK(hipGetLastError());

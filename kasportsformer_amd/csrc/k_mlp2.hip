@@ -268,15 +268,15 @@ __global__ __launch_bounds__(NW * 64) void k_mlp_bwd_q(const bf16* __restrict__ 
 // pull (5.5 TB/s): RPT rows per thread are now loaded back to back before any of them is consumed, which doubles the bytes in flight at the
 // same number of workgroups (the grid stays capped: every workgroup ends with 384 same-address atomics).
 template <int RPT>
-__global__ __launch_bounds__(256) void k_lnbwd_sum4(const bf16* __restrict__ dApart, const bf16* __restrict__ X, const bf16* __restrict__ G,
-                                                    const float* __restrict__ gamma, bf16* __restrict__ g_in, float* __restrict__ dgamma,
-                                                    float* __restrict__ dbeta, float* __restrict__ gsum, int64_t M) {
+__device__ __forceinline__ void lnbwd_sum4_body(const bf16* __restrict__ dApart, const bf16* __restrict__ X, const bf16* __restrict__ G,
+                                                const float* __restrict__ gamma, bf16* __restrict__ g_in, float* __restrict__ dgamma,
+                                                float* __restrict__ dbeta, float* __restrict__ gsum, int64_t M, int bid, int nblk) {
     __shared__ float red[3][16][128];
     const int sub = threadIdx.x & 15, rl = threadIdx.x >> 4;
     float gm[8], dg[8], db[8], gsv[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { gm[e] = gamma[sub * 8 + e]; dg[e] = 0.f; db[e] = 0.f; gsv[e] = 0.f; }
-    for (int64_t row0 = ((int64_t)blockIdx.x * RPT) * 16 + rl; row0 < M; row0 += (int64_t)gridDim.x * 16 * RPT) {
+    for (int64_t row0 = ((int64_t)bid * RPT) * 16 + rl; row0 < M; row0 += (int64_t)nblk * 16 * RPT) {
         bf16x8 pq[RPT][4], xr[RPT], gr[RPT];
 #pragma unroll
         for (int u = 0; u < RPT; ++u) {
@@ -334,6 +334,12 @@ __global__ __launch_bounds__(256) void k_lnbwd_sum4(const bf16* __restrict__ dAp
         for (int k = 0; k < 16; ++k) s += red[which][k][c];
         atomicAdd((which == 0 ? dgamma : (which == 1 ? dbeta : gsum)) + c, s);
     }
+}
+template <int RPT>
+__global__ __launch_bounds__(256) void k_lnbwd_sum4(const bf16* __restrict__ dApart, const bf16* __restrict__ X, const bf16* __restrict__ G,
+                                                    const float* __restrict__ gamma, bf16* __restrict__ g_in, float* __restrict__ dgamma,
+                                                    float* __restrict__ dbeta, float* __restrict__ gsum, int64_t M) {
+    lnbwd_sum4_body<RPT>(dApart, X, G, gamma, g_in, dgamma, dbeta, gsum, M, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -492,17 +498,16 @@ __global__ __launch_bounds__(F_THR) void k_mlp_fwd_r(const bf16* __restrict__ X,
 // Workgroups 0..127 own 4 rows of dW1 each, workgroups 128..255 one row of dW2 each (512 floats per workgroup); the two
 // halves of a workgroup take the even / odd splits.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_mlp_wfinish(const float* __restrict__ p1, const float* __restrict__ p2, float* __restrict__ dW1,
-                                                     float* __restrict__ dW2, int splits, const float* __restrict__ W2, const float* __restrict__ b2,
-                                                     const float* __restrict__ ls, float* __restrict__ gsum_db2, float* __restrict__ dls,
-                                                     unsigned* __restrict__ zero_words, int n_zero) {
+// DEFER: the column sums of g are not complete yet (the launch shares k_lnbwd_sum4's grid): leave their terms to that kernel's last workgroup
+template <bool DEFER>
+__device__ __forceinline__ void mlp_wfinish_body(const float* __restrict__ p1, const float* __restrict__ p2, float* __restrict__ dW1,
+                                                 float* __restrict__ dW2, int splits, const float* __restrict__ W2, const float* __restrict__ b2,
+                                                 const float* __restrict__ ls, float* __restrict__ gsum_db2, float* __restrict__ dls, int bid) {
     __shared__ f32x4 sHalf[128];
-    if (blockIdx.x == 255)         // the hand-off flags of k_mlp_bwd_s<true> (complete by stream order) are cleared for the next launch on this scratch
-        for (int k = threadIdx.x; k < n_zero; k += 256) zero_words[k] = 0u;
     __shared__ float sDot[2];
     const int lane = threadIdx.x & 127, half = threadIdx.x >> 7;
-    const bool second = blockIdx.x >= 128;
-    const int blk = second ? blockIdx.x - 128 : blockIdx.x;
+    const bool second = bid >= 128;
+    const int blk = second ? bid - 128 : bid;
     const float* part = second ? p2 : p1;
     const int64_t e = (int64_t)blk * 512 + lane * 4;
     f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
@@ -557,10 +562,63 @@ __global__ __launch_bounds__(256) void k_mlp_wfinish(const float* __restrict__ p
         if (half == 0 && (threadIdx.x & 63) == 0) sDot[threadIdx.x >> 6] = dot;
         __syncthreads();
         if (threadIdx.x == 0) {
-            const float gs = gsum_db2[blk];
-            dls[blk] += sDot[0] + sDot[1] + b2[blk] * gs;
-            gsum_db2[blk] = gs * ls[blk];
+            if (DEFER) atomicAdd(dls + blk, sDot[0] + sDot[1]);       // (the b2 . gsum term arrives by a second atomic add)
+            else {
+                const float gs = gsum_db2[blk];
+                dls[blk] += sDot[0] + sDot[1] + b2[blk] * gs;
+                gsum_db2[blk] = gs * ls[blk];
+            }
         }
+    }
+}
+__global__ __launch_bounds__(256) void k_mlp_wfinish(const float* __restrict__ p1, const float* __restrict__ p2, float* __restrict__ dW1,
+                                                     float* __restrict__ dW2, int splits, const float* __restrict__ W2, const float* __restrict__ b2,
+                                                     const float* __restrict__ ls, float* __restrict__ gsum_db2, float* __restrict__ dls,
+                                                     unsigned* __restrict__ zero_words, int n_zero) {
+    if (blockIdx.x == 255)         // the hand-off flags of k_mlp_bwd_s<true> (complete by stream order) are cleared for the next launch on this scratch
+        for (int k = threadIdx.x; k < n_zero; k += 256) zero_words[k] = 0u;
+    mlp_wfinish_body<false>(p1, p2, dW1, dW2, splits, W2, b2, ls, gsum_db2, dls, (int)blockIdx.x);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_lnbwd_sum4 and k_mlp_wfinish in ONE launch: workgroups 0..255 reduce the weight-gradient partial tiles (they only read what k_mlp_bwd_s left),
+// the others stream the dA partials; the two terms of the finish that need colsum(g) -- complete only when the LAST streaming workgroup has
+// added its share -- are applied by that workgroup (ticket counter; every workgroup waits for the acknowledgement of its atomic adds before it
+// takes its ticket, the reader takes the sums with agent-scope loads).  One launch and ~8 us of dependent latency less per MLP block, 156 times per step.
+// ---------------------------------------------------------------------------------------------------------------
+struct MlpFinArgs {
+    const float *p1, *p2;
+    float *dW1, *dW2;
+    int splits;
+    const float *W2, *b2, *ls;
+    float *gsum_db2, *dls;
+    unsigned* ticket;              // zero before the launch; the last workgroup leaves it zero again
+};
+template <int RPT>
+__global__ __launch_bounds__(256) void k_lnbwd_sum4_fin(const bf16* __restrict__ dApart, const bf16* __restrict__ X, const bf16* __restrict__ G,
+                                                        const float* __restrict__ gamma, bf16* __restrict__ g_in, float* __restrict__ dgamma,
+                                                        float* __restrict__ dbeta, float* __restrict__ gsum, int64_t M, const MlpFinArgs fa) {
+    if (blockIdx.x < 256) {
+        mlp_wfinish_body<true>(fa.p1, fa.p2, fa.dW1, fa.dW2, fa.splits, fa.W2, fa.b2, fa.ls, fa.gsum_db2, fa.dls, (int)blockIdx.x);
+        return;
+    }
+    const int nblk = (int)gridDim.x - 256;
+    lnbwd_sum4_body<RPT>(dApart, X, G, gamma, g_in, dgamma, dbeta, gsum, M, (int)blockIdx.x - 256, nblk);
+    __shared__ int sLast;
+    // this workgroup's atomic adds (device scope, performed at the memory side) have been acknowledged before its ticket is taken.  NOT __threadfence():
+    // that also writes back the XCD's dirty L2 lines -- the g_in rows just stored -- from every thread of every workgroup (measured: +14 ms per step)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) sLast = atomicAdd(fa.ticket, 1u) == (unsigned)(nblk - 1);
+    __syncthreads();
+    if (sLast) {
+        if (fa.W2 != nullptr && threadIdx.x < 128) {
+            const int c = threadIdx.x;
+            const float gs = __hip_atomic_load(fa.gsum_db2 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            atomicAdd(fa.dls + c, fa.b2[c] * gs);
+            fa.gsum_db2[c] = gs * fa.ls[c];
+        }
+        if (threadIdx.x == 0) atomicExch(fa.ticket, 0u);
     }
 }
 
@@ -608,8 +666,17 @@ void kasf_launch_mlp_bwd_q(hipStream_t s, const void* x, const void* xn, const v
     }
     static const int rpt = getenv("KASF_SUM4_RPT") ? atoi(getenv("KASF_SUM4_RPT")) : 2;               // measurement switches
     static const int cap = getenv("KASF_SUM4_BLOCKS") ? atoi(getenv("KASF_SUM4_BLOCKS")) : 512;
+    static const bool two_launches = getenv("KASF_MLP_FINISH_SEPARATE") != nullptr;                   // k_lnbwd_sum4, then k_mlp_wfinish (round-1 form)
     int64_t blocks = (M + 16 * rpt - 1) / (16 * rpt);
     if (blocks > cap) blocks = cap;                     // few blocks: every block ends with 384 same-address atomics (contended atomics serialise)
+    if (!two_launches && rpt == 2) {
+        // gsum doubles as the fc2 bias gradient slot; the ticket word lives behind the hand-off flags of the scratch (zeroed by the engine at the start
+        // of a backward pass / by the op entry point, left zero by every launch)
+        const MlpFinArgs fa{p1, p2, dW1, dW2, used, W2, b2, ls2, gsum, dls2, flags + KASF_MLP_TICKET_WORD};
+        hipLaunchKernelGGL(k_lnbwd_sum4_fin<2>, dim3((unsigned)blocks + 256), dim3(256), 0, s, (const bf16*)dApart, (const bf16*)x, (const bf16*)g, ln_g,
+                           (bf16*)g_in, dgamma, dbeta, gsum, M, fa);
+        return;
+    }
     if (rpt == 1) hipLaunchKernelGGL(k_lnbwd_sum4<1>, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16*)dApart, (const bf16*)x, (const bf16*)g, ln_g, (bf16*)g_in,
                                      dgamma, dbeta, gsum, M);
     else if (rpt == 2) hipLaunchKernelGGL(k_lnbwd_sum4<2>, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16*)dApart, (const bf16*)x, (const bf16*)g, ln_g,

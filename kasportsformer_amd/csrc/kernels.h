@@ -61,6 +61,7 @@ void kasf_launch_mlp_bwd(int dt, hipStream_t s, const void* x, const void* g, co
 #define KASF_MLP_PARTIAL_FLOATS (2 * 64 * 65536)
 #define KASF_MLP_FLAG_WORDS 2048
 #define KASF_MLP_ERR_WORD 1024
+#define KASF_MLP_TICKET_WORD 1536      // ticket counter of k_lnbwd_sum4_fin: zero at launch, left zero (the words must be zeroed once per scratch buffer)
 void kasf_launch_mlp_bwd_q(hipStream_t s, const void* x, const void* xn, const void* g, const float* ln_g, const void* W1, const float* b1,
                            const void* W2ts, const void* W1t, void* dApart, float* partial, float* dW1, float* dW2, float* db1, float* gsum, void* g_in,
                            float* dgamma, float* dbeta, int64_t M, const float* W2 = nullptr, const float* b2 = nullptr, const float* ls2 = nullptr,
