@@ -73,14 +73,14 @@ def kernel_rooflines(M):
     fwd = lambda: lib.kasf_op_mlp_fwd(1, p(x), p(gam), p(bet), p(w1), p(b1), p(w2), p(b2), p(ls), p(out), M, p(xn), st())    # training-mode forward: also stores LN(x)
     dap = torch.empty(4 * M * 128, device=dev, dtype=bf)
     part2 = torch.empty(2 * 64 * 65536 + 2048, device=dev)
-    # the engine's bf16 backward: data gradient + both weight gradients + LayerNorm backward in k_mlp_bwd_s / k_lnbwd_sum4 / k_mlp_wfinish
+    # the engine's bf16 backward: data gradient + both weight gradients + LayerNorm backward in k_mlp_bwd_s / k_lnbwd_sum4_fin (the dA-partial stream and the weight-gradient finish in one launch)
     bwd = lambda: lib.kasf_op_mlp_bwd_fused(p(x), p(xn), p(gout), p(gam), p(w1), p(b1), p(w2ts), p(w1t), p(dap), p(part2), p(dW1), p(dW2), p(db1),
                                             p(gs), p(gin), p(dg), p(db), M, st())
     wg1 = lambda: lib.kasf_op_wgrad(1, p(dZ), 512, p(x), 128, None, None, p(dW1), p(db1), M, p(part), part.numel(), st())   # engine path: X = LN(x) emitted by k_mlp_bwd
     wg2 = lambda: lib.kasf_op_wgrad(1, p(gout), 128, p(H), 512, None, None, p(dW2), p(gs), M, p(part), part.numel(), st())
     res = {}
     # algorithmic FLOP: forward 2 GEMMs; fused backward = dgrad (2 GEMMs) + wgrad (2 GEMMs) = 2x forward (the Z recompute is not counted)
-    for name, fn, flop in (("k_mlp_fwd_s", fwd, MLP_FLOP_PER_TOKEN_FWD * M), ("k_mlp_bwd_s(+lnbwd_sum4+wfinish)", bwd, 2 * MLP_FLOP_PER_TOKEN_FWD * M),
+    for name, fn, flop in (("k_mlp_fwd_s", fwd, MLP_FLOP_PER_TOKEN_FWD * M), ("k_mlp_bwd_s(+lnbwd_sum4_fin)", bwd, 2 * MLP_FLOP_PER_TOKEN_FWD * M),
                            ("k_wgrad_ring[512x128]", wg1, MLP_FLOP_PER_TOKEN_FWD // 2 * M), ("k_wgrad_ring[128x512]", wg2, MLP_FLOP_PER_TOKEN_FWD // 2 * M)):
         t = time_kernel(fn)
         res[name] = {"seconds": t, "achieved_tflops": flop / t / 1e12, "algorithmic_flop": flop}
@@ -91,7 +91,7 @@ PROFILES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
 TRAFFIC_FILE = os.path.join(PROFILES, "r2_pmc_traffic.json")            # tools/pmc_all.sh + tools/pmc_traffic.py (two --pmc passes over tools/mlp_bench.py)
 IN_STEP_STATS = os.path.join(PROFILES, "r2_train_kernel_stats.csv")      # rocprofv3 --kernel-trace --stats of tools/train_once.py 27 256 (three streams overlap)
 STEP_TRAFFIC_FILE = os.path.join(PROFILES, "r2_pmc_step.json")           # tools/pmc_step.sh: FETCH_SIZE / WRITE_SIZE summed over whole training steps
-TRAFFIC_PARTS = {"k_mlp_fwd_s": {"k_mlp_fwd_s": 1}, "k_mlp_bwd_s(+lnbwd_sum4+wfinish)": {"k_mlp_bwd_s": 1, "k_lnbwd_sum4": 1, "k_mlp_wfinish": 1}}
+TRAFFIC_PARTS = {"k_mlp_fwd_s": {"k_mlp_fwd_s": 1}, "k_mlp_bwd_s(+lnbwd_sum4_fin)": {"k_mlp_bwd_s": 1, "k_lnbwd_sum4_fin": 1}}
 
 
 def pmc_traffic(entry, M):

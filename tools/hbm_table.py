@@ -24,7 +24,7 @@ ALG = {
     "k_dgrad_r<2, true, true, false, false, 3>": ("GCN: duv.W + LN backward + residual + direct LN(x) gradient", (256 + 4 * 128) * s),
     "k_dgrad_r<2, false, false, true, true, 3>": ("bone: dkv.W + LN backward, accumulates into g_limb, emits LN(x_limb)", (256 + 4 * 128) * s),
     "k_dgrad_r<1, true, false, false, true, 3>": ("bone: dq.W + LN backward + residual, emits LN(x)", (128 + 4 * 128) * s),
-    "k_lnbwd_sum4": ("sum of 4 dA partials + LN backward + residual", (4 * 128 + 3 * 128) * s),
+    "k_lnbwd_sum4": ("sum of 4 dA partials + LN backward + residual, and (k_lnbwd_sum4_fin) the 33.5 MB of weight-gradient partial tiles", (4 * 128 + 3 * 128) * s + 2 * 64 * 65536 * 4 / M),
     "k_gcn_agg_spatial": ("skeleton aggregate: U|V in, y out", (256 + 128) * s),
     "k_gcn_agg_temporal": ("top-4 similarity aggregate: U|V, LN(x) in, y + masks out", (256 + 128 + 128) * s + 12),
     "k_gcn_apply": ("BatchNorm + ReLU + layer-scale + residual: x, LN(x), y in, x_mid out", 4 * 128 * s),
@@ -62,7 +62,7 @@ for k, (what, bpt) in ALG.items():
     if hit is None:
         continue
     nbytes, tmin, tavg = bpt * M, float(hit["MinNs"]) * 1e-9, float(hit["AverageNs"]) * 1e-9
-    e = {"what": what, "algorithmic_bytes_per_token": bpt, "algorithmic_MB_per_launch": round(nbytes / 1e6, 1), "launches_per_step": round(int(hit["Calls"]) / 3, 1),
+    e = {"what": what, "algorithmic_bytes_per_token": round(bpt, 1), "algorithmic_MB_per_launch": round(nbytes / 1e6, 1), "launches_per_step": round(int(hit["Calls"]) / 3, 1),
          "isolated_avg_us": round(tavg * 1e6, 1), "isolated_min_us": round(tmin * 1e6, 1), "achieved_GBps": round(nbytes / tavg / 1e9),
          "frac_of_8TBps": round(nbytes / tavg / 8e12, 3)}
     h3 = next((v for n, v in rows3.items() if n.startswith(k)), None)
