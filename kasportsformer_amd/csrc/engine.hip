@@ -899,6 +899,7 @@ int kasf_op_attention_bwd_fused_do(const void* q, int64_t ldq, const void* k, co
                                    int64_t lddq, void* dk, void* dv, int64_t lddkv, int32_t batch, int32_t n_frames, int32_t mode, int32_t form, void* stream) {
     g_err.clear();
     if (form < 0 || form > 1) return kasf_set_error(2, "form: 0 (persistent) or 1 (one group per workgroup)");
+    if (batch < 1 || n_frames < 1 || (int64_t)batch * n_frames * 17 * 384 >= ((int64_t)1 << 31)) return kasf_set_error(2, "batch * n_frames * 17 * 384 must stay below 2^31");
     if (!kasf_launch_attn_bwd_fused_do((hipStream_t)stream, q, ldq, k, v, ldkv, g_mid, wproj_t_scaled, dq, lddq, dk, dv, lddkv, batch, n_frames, mode, form))
         return kasf_set_error(2, "fused-d_o attention backward: groups of at most 32 positions (bf16, 8 heads)");
     HIPCHK(hipGetLastError());
