@@ -428,12 +428,20 @@ void block_backward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void*
     if (o.kind == KIND_ATT) {
         const char* q = (const char*)c.w(w.qkv);
         char* dq = (char*)c.w(sc.dqkv);
-        if (fdo) kasf_launch_attn_bwd_fused_do(c.s, q, 384, q + 128 * c.es, q + 256 * c.es, 384, g_mid, c.pk(o.p_projTs), dq, 384, dq + 128 * c.es,
-                                               dq + 256 * c.es, 384, c.B, c.T, o.mode);
-        else kasf_launch_attn_bwd(c.dt, c.s, q, 384, q + 128 * c.es, q + 256 * c.es, 384, c.w(sc.d_o), dq, 384, dq + 128 * c.es, dq + 256 * c.es, 384, c.B,
-                                  c.T, o.mode, heads);
-        kasf_launch_dgrad_lnbwd(c.dt, c.s, dq, 384, c.pk(o.p_mixT), nullptr, x_in, P + o.n1w, g_mid, dst, accumulate, G + o.n1w, G + o.n1b, c.M,
-                                c.w(sc.xn_a), P + o.n1b);
+        // KASF_ATTN_BLOCK_BWD=1: d_o, attention backward, QKV data gradient, LayerNorm backward + residual and LN(x) in ONE launch (k_attn_blk_bwd).
+        // Built, bit-compatible with the two-launch form -- and slower (121 / 101 us against 106 / 101 us): opt-in.
+        static const bool blk_bwd = getenv("KASF_ATTN_BLOCK_BWD") != nullptr;
+        const bool fused_bwd = fdo && blk_bwd && !accumulate &&
+                               kasf_launch_attn_block_bwd(c.s, q, g_mid, x_in, c.pk(o.p_projTs), c.pk(o.p_mixT), P + o.n1w, P + o.n1b, dq, dst, c.w(sc.xn_a),
+                                                          G + o.n1w, G + o.n1b, c.B, c.T, o.mode);
+        if (!fused_bwd) {
+            if (fdo) kasf_launch_attn_bwd_fused_do(c.s, q, 384, q + 128 * c.es, q + 256 * c.es, 384, g_mid, c.pk(o.p_projTs), dq, 384, dq + 128 * c.es,
+                                                   dq + 256 * c.es, 384, c.B, c.T, o.mode);
+            else kasf_launch_attn_bwd(c.dt, c.s, q, 384, q + 128 * c.es, q + 256 * c.es, 384, c.w(sc.d_o), dq, 384, dq + 128 * c.es, dq + 256 * c.es, 384, c.B,
+                                      c.T, o.mode, heads);
+            kasf_launch_dgrad_lnbwd(c.dt, c.s, dq, 384, c.pk(o.p_mixT), nullptr, x_in, P + o.n1w, g_mid, dst, accumulate, G + o.n1w, G + o.n1b, c.M,
+                                    c.w(sc.xn_a), P + o.n1b);
+        }
         bool done = false;
         if (jobs) {
             const void* Gs[2] = {g_mid, dq};

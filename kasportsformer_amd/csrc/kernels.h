@@ -166,5 +166,8 @@ bool kasf_launch_attn_block_fwd(hipStream_t s, int bone, const void* x, const vo
 bool kasf_launch_wgrad_jobs(hipStream_t s, int njobs, const void* const* G, const void* const* X, const int* N, float* const* dW, float* const* dbias,
                             int fin_job, const float* fin_W, const float* fin_bias, const float* fin_ls, float* fin_dls, int64_t M, float* partial,
                             int64_t partial_floats);
+// fused backward of a self-attention block: d_o, attention backward, QKV data gradient, LayerNorm backward + residual, LN(x) in one launch (bf16)
+bool kasf_launch_attn_block_bwd(hipStream_t s, const void* qkv, const void* g_mid, const void* x, const void* WprojTs, const void* WqkvT, const float* gamma,
+                                const float* beta, void* dqkv, void* g_in, void* xn, float* dgamma, float* dbeta, int B, int Tn, int mode);
 bool kasf_launch_attn_bwd_fused_do(hipStream_t s, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, const void* g_mid,
                                    const void* WprojTs, void* dq, int64_t lddq, void* dk, void* dv, int64_t lddkv, int B, int Tn, int mode, int form = -1 /* -1: default (persistent), 0: persistent, 1: one group per workgroup (round-1 form) */);

@@ -72,3 +72,13 @@ def test_merged_mlp_finish_equals_the_two_launch_form(tmp_path):
             worst = max(worst, d)
             assert d < 5e-5, (k, d)                      # (a lost share would be ~2e-3 in every channel)
     print("merged vs separate finish: worst relative difference of the colsum(g)-dependent gradients", worst)
+
+
+def test_fused_attention_block_backward_still_matches():
+    """k_attn_blk_bwd (KASF_ATTN_BLOCK_BWD=1: attention backward + QKV data gradient + LayerNorm backward in one role-specialised launch) is not the
+    default but stays in the library: the model's stage / gradient tests once more with the switch set."""
+    env = dict(os.environ, KASF_ATTN_BLOCK_BWD="1")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_model.py"), "-x", "-q", "-m", "gpu", "-k",
+                          "stage_by_stage or backward_matches_oracle or training_step_with_fused_adamw or single_clip"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert " passed" in out.stdout
