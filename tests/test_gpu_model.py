@@ -511,7 +511,7 @@ def test_full_depth_26_layers_against_oracle(cd):
         assert err < 0.2 and cosine > 0.92
 
 
-@pytest.mark.parametrize("T,B", [(243, 1), (100, 2), (33, 2), (5, 3), (4, 8)])
+@pytest.mark.parametrize("T,B", [(243, 1), (100, 2), (33, 2), (5, 3), (4, 8), (64, 2), (96, 2), (32, 2)])      # 64 / 96: the three-tile fused temporal forward with an empty / a full last tile; 32: the largest one-tile group
 @pytest.mark.parametrize("cd,tol", [("fp32", 2e-3), ("bf16", 0.5)])
 def test_arbitrary_clip_lengths(cd, tol, T, B):
     """The reference builds for any n_frames (KASportsFormer.py:291-295, README.md:59): 243 is the long configuration of this model family;
