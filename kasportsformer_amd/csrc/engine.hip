@@ -415,7 +415,9 @@ void block_backward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void*
     // d_o = g_mid . (ls1 . Wproj);  G_proj = g_mid^T o (unscaled) -> finalize: dWproj, dbproj, dls1
     static const bool no_fdo = getenv("KASF_NO_FUSED_DO") != nullptr;          // measurement switch
     const int heads = c.m->cfg.num_heads;
-    const bool fdo = c.dt == KASF_BF16 && !no_fdo && heads == 8 && (o.mode == 0 ? 17 : c.T) <= 32;   // d_o formed inside the attention backward kernel
+    static const bool no_fdo_long = getenv("KASF_NO_FUSED_DO_LONG") != nullptr;     // measurement switch: separate d_o linear for 33..96-position groups
+    const int Lg = o.mode == 0 ? 17 : c.T;
+    const bool fdo = c.dt == KASF_BF16 && !no_fdo && heads == 8 && (Lg <= 32 || (Lg <= 96 && !no_fdo_long));   // d_o formed inside the attention backward kernel
     if (!fdo) kasf_launch_linear(c.dt, c.s, g_mid, 128, c.pk(o.p_projTs), 128, nullptr, c.w(sc.d_o), 128, c.M, 128, nullptr, nullptr, nullptr, 0);
     // bf16: every weight gradient of the block (proj, qkv | q, kv) goes into ONE streaming launch + one finishing launch at the end of the block
     static const bool no_jobs = getenv("KASF_NO_WGRAD_JOBS") != nullptr;       // measurement switch

@@ -308,16 +308,22 @@ __global__ __launch_bounds__(FDO ? 512 : 256) void k_attn_bwd_mfma(const bf16* _
 // (ds_read_b64_tr_b16) as the operand of the dV / dK products (lane = key), which accumulate in registers across the query tiles.
 // K and V fragments are re-read from LDS instead of living in registers.
 // ---------------------------------------------------------------------------------------------------------------
-template <int NKT>
-__global__ __launch_bounds__(256, 2) void k_attn_bwd_long(const bf16* __restrict__ Q, int64_t ldq, const bf16* __restrict__ K, const bf16* __restrict__ V,
-                                                          int64_t ldkv, const bf16* __restrict__ dO, bf16* __restrict__ dQ, int64_t lddq,
-                                                          bf16* __restrict__ dK, bf16* __restrict__ dV, int64_t lddkv, int L, int Tn, int mode, int units) {
+// FDO (as in the one-tile kernels): d_o = g_mid . (ls1 . Wproj)^T is formed here instead of being read -- the workgroup is then the 8 heads of ONE group
+// (8 waves, 152 KB of LDS, the same two waves per SIMD), the group's g_mid rows are staged once and each wave runs 24 MFMAs against its 16 rows of the
+// packed weight.  Saves the d_o linear (a launch, 45 MB written and read back) at T = 81.
+template <int NKT, bool FDO>
+__global__ __launch_bounds__(FDO ? 512 : 256, 2) void k_attn_bwd_long(const bf16* __restrict__ Q, int64_t ldq, const bf16* __restrict__ K,
+                                                                        const bf16* __restrict__ V, int64_t ldkv, const bf16* __restrict__ dO,
+                                                                        bf16* __restrict__ dQ, int64_t lddq, bf16* __restrict__ dK, bf16* __restrict__ dV,
+                                                                        int64_t lddkv, int L, int Tn, int mode, int units, const bf16* __restrict__ Gmid,
+                                                                        const bf16* __restrict__ Wp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TILE = NKT * 32 * 16;                           // [positions][16] operand tile
     constexpr int WAVE_BYTES = (4 * TILE + 2 * 32 * 32) * 2;
+    constexpr int NWAVE = FDO ? 8 : 4;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
-    const int unit = blockIdx.x * 4 + wave;
-    if (unit >= units) return;                                    // wave-uniform; no workgroup barrier below
+    const int unit = blockIdx.x * NWAVE + wave;
+    if (!FDO && unit >= units) return;                            // wave-uniform; no workgroup barrier below (FDO: the grid is one workgroup per group)
     const int G = unit >> 3, h = unit & 7;
     bf16* sK = reinterpret_cast<bf16*>(smem + wave * WAVE_BYTES);
     bf16* sV = sK + TILE;
@@ -331,7 +337,30 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_long(const bf16* __restrict
         row_frag(K, ldkv, G, pos, L, Tn, mode, h, hh, sK);
         row_frag(V, ldkv, G, pos, L, Tn, mode, h, hh, sV);
         row_frag(Q, ldq, G, pos, L, Tn, mode, h, hh, sQ);
-        row_frag(dO, 128, G, pos, L, Tn, mode, h, hh, sD);
+        if (!FDO) row_frag(dO, 128, G, pos, L, Tn, mode, h, hh, sD);
+    }
+    if (FDO) {
+        bf16* sG = reinterpret_cast<bf16*>(smem + NWAVE * WAVE_BYTES);          // [32 NKT][128] g_mid rows of the group (swizzled tile; rows past L zero)
+        for (int c = threadIdx.x; c < NKT * 32 * 16; c += 512) {
+            const int row = c >> 4, ch = c & 15;
+            bf16x8 v = zero8();
+            if (row < L) v = *reinterpret_cast<const bf16x8*>(Gmid + tok_of(G, row, Tn, mode) * 128 + ch * 8);
+            *reinterpret_cast<bf16x8*>(sG + Tile<bf16>::chunk_off(row, ch)) = v;
+        }
+        const int li = lane & 15, lg = lane >> 4;
+        bf16x8 wp[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) wp[ks] = *reinterpret_cast<const bf16x8*>(Wp + (int64_t)(16 * h + li) * 128 + 32 * ks + 8 * lg);
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < 2 * NKT; ++mt) {          // d_o[pos = 16 mt + li][channel 4 lg .. 4 lg + 3] of this head
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[ks], *reinterpret_cast<const bf16x8*>(sG + Tile<bf16>::chunk_off(16 * mt + li, 4 * ks + lg)), acc, 0, 0, 0);
+            float v[4] = {acc[0], acc[1], acc[2], acc[3]};
+            store4(sD + (16 * mt + li) * 16 + 4 * lg, v);
+        }
     }
     f32x16 dv[NKT], dk[NKT];
 #pragma unroll
@@ -863,9 +892,9 @@ bool kasf_launch_attn_bwd_mfma(hipStream_t s, const void* q, int64_t ldq, const 
         static const bool two_pass = getenv("KASF_ATTN_BWD_TWO_PASS") != nullptr;     // measurement switch: the recomputing two-pass form
         if (!two_pass) {
             const size_t shl = 4 * (size_t)(4 * 96 * 16 + 2 * 32 * 32) * 2;
-            set_smem(k_attn_bwd_long<3>, shl);
-            hipLaunchKernelGGL(k_attn_bwd_long<3>, grid, dim3(256), shl, s, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldkv, (const bf16*)d_o,
-                               (bf16*)dq, lddq, (bf16*)dk, (bf16*)dv, lddkv, L, Tn, mode, units);
+            set_smem(k_attn_bwd_long<3, false>, shl);
+            hipLaunchKernelGGL((k_attn_bwd_long<3, false>), grid, dim3(256), shl, s, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldkv, (const bf16*)d_o,
+                               (bf16*)dq, lddq, (bf16*)dk, (bf16*)dv, lddkv, L, Tn, mode, units, (const bf16*)nullptr, (const bf16*)nullptr);
             return true;
         }
         const size_t sh = 4 * (3 * 96 * 16 * 2 + 96 * 16);
@@ -880,8 +909,16 @@ bool kasf_launch_attn_bwd_mfma(hipStream_t s, const void* q, int64_t ldq, const 
 bool kasf_launch_attn_bwd_fused_do(hipStream_t s, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, const void* g_mid,
                                    const void* WprojTs, void* dq, int64_t lddq, void* dk, void* dv, int64_t lddkv, int B, int Tn, int mode, int form) {
     const int L = mode == 0 ? KASF_J : Tn, groups = mode == 0 ? B * Tn : B * KASF_J;
-    if (L > 32) return false;
+    if (L > 96) return false;
     if (groups <= 0) return true;
+    if (L > 32) {                                       // three-tile groups (temporal attention at T = 81): one workgroup = the 8 heads of one group
+        if (form == 1) return false;                    // (the one-group-per-workgroup comparison form exists for one-tile groups only)
+        const size_t shl = 8 * (size_t)(4 * 96 * 16 + 2 * 32 * 32) * 2 + (size_t)96 * 128 * 2;
+        set_smem(k_attn_bwd_long<3, true>, shl);
+        hipLaunchKernelGGL((k_attn_bwd_long<3, true>), dim3(groups), dim3(512), shl, s, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldkv, (const bf16*)nullptr,
+                           (bf16*)dq, lddq, (bf16*)dk, (bf16*)dv, lddkv, L, Tn, mode, groups * 8, (const bf16*)g_mid, (const bf16*)WprojTs);
+        return true;
+    }
     static const bool env_one_group = getenv("KASF_ATTN_BWD_ONE_GROUP") != nullptr;        // measurement / parity switch: the round-1 form
     const bool one_group_per_wg = form < 0 ? env_one_group : form == 1;
     if (!one_group_per_wg) {
