@@ -24,10 +24,10 @@ from .checkpoint import checkpoint_save, checkpoint_load, strip_module_prefix, a
 from .loop import train_one_epoch
 from .schedule import warmup_lr, apply_warmup, ReduceLROnPlateau
 from .evaluate import joint_flip, predict_flip_tta, clip_metrics, Evaluator, evaluate_one_epoch
-from .synthetic import synthetic_clips, synthetic_test_extras
+from .synthetic import synthetic_clips, synthetic_test_extras, teacher_labels, teacher_clips
 from .slicing import slice_source, split_clips, mysplit_clips, resample
 
 __all__ = ["KASportsFormer", "load_model", "loss3", "FusedAdamW", "DataParallel", "joint_flip", "predict_flip_tta", "clip_metrics", "Evaluator",
            "evaluate_one_epoch", "PackedClips", "DeviceClipLoader", "pack_clip_directory", "read_clip_file", "shard_indices",
            "checkpoint_save", "checkpoint_load", "strip_module_prefix", "adamw_state_dict", "load_adamw_state_dict", "warmup_lr", "apply_warmup", "ReduceLROnPlateau", "train_one_epoch",
-           "synthetic_clips", "synthetic_test_extras", "slice_source", "split_clips", "mysplit_clips", "resample"]
+           "synthetic_clips", "synthetic_test_extras", "teacher_labels", "teacher_clips", "slice_source", "split_clips", "mysplit_clips", "resample"]

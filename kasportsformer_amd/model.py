@@ -270,10 +270,20 @@ class KASportsFormer(nn.Module):
     def _launch_backward(self, ws, dout, B, flags):
         h = self._device_handle()
         dout = dout.contiguous().float()
-        # Gradient accumulation (a second backward before the optimizer step) follows torch: p.grad -- and the flat array FusedAdamW reads --
-        # hold the SUM.  The engine's finishing kernels scale weight gradients in place, so every backward runs into a zeroed array of its own
-        # and is added to the running one afterwards (one extra pass over 117 MB, only in the accumulating case).
-        fresh = self.flat_grad is None or (self.attach_param_grads and self._live[0][0].grad is None)    # the latter: optimizer.zero_grad(set_to_none=True)
+        # Gradient accumulation (a second backward before the optimizer step) follows torch PER PARAMETER: a tensor whose .grad is None (never
+        # touched, or zeroed by an optimizer that owns only a subset of the parameters -- e.g. fine-tuning `head` alone) restarts from this
+        # pass's gradient, every other one holds the SUM -- in p.grad and in the flat array FusedAdamW reads.  The engine's finishing kernels
+        # scale weight gradients in place, so every backward runs into a zeroed array of its own and is added to the running one afterwards
+        # (one extra pass over 117 MB, only in the accumulating case).  With attach_param_grads=False the flat array accumulates until
+        # zero_grad() of this module or of FusedAdamW.
+        restart = []                                   # (offset, numel) of live tensors that restart although others accumulate
+        if self.flat_grad is None:
+            fresh = True
+        elif not self.attach_param_grads:
+            fresh = False
+        else:
+            restart = sorted((off, n) for p, off, n, _ in self._live if p.grad is None)
+            fresh = len(restart) == len(self._live)
         if not fresh and self.grad_stage_hook is not None:
             raise NotImplementedError("gradient accumulation with the overlapped (stage-hooked) all-reduce is not built: zero_grad() between backward "
                                       "passes, or DataParallel(overlap=False)")
@@ -305,20 +315,35 @@ class KASportsFormer(nn.Module):
         if fresh:
             self.flat_grad = g
         else:
+            lo = hi = None
+            for off, n in restart:                     # zero what restarts (adjacent ranges merged), then add this pass everywhere
+                if hi is not None and off <= hi + 3:
+                    hi = off + n
+                    continue
+                if hi is not None:
+                    self.flat_grad[lo:hi].zero_()
+                lo, hi = off, off + n
+            if hi is not None:
+                self.flat_grad[lo:hi].zero_()
             self.flat_grad += g
-            g = self.flat_grad
         if self.attach_param_grads:
+            total = self.flat_grad
             untouched = (self.head.weight, self.head.bias) if flags & _lib.FLAG_RETURN_REP else ()
             for p, off, n, shape in self._live:
-                if any(p is q for q in untouched) and p.grad is None:
-                    continue                         # return_rep=True: the head took no part, its .grad stays None as in the reference
-                v = g[off:off + n].view(shape)
                 if p.grad is None:
-                    p.grad = v                   # a view of the flat array: later backward passes accumulate into it in place
-                elif p.grad.data_ptr() != v.data_ptr():
-                    if not fresh:
-                        raise RuntimeError("p.grad was replaced between two backward passes without zero_grad(); cannot accumulate")
-                    p.grad += v
+                    if any(p is q for q in untouched):
+                        continue                     # return_rep=True: the head took no part, its .grad stays None as in the reference
+                    p.grad = total[off:off + n].view(shape)      # a view of the flat array: later backward passes accumulate into it in place
+                elif p.grad.data_ptr() != total.data_ptr() + 4 * off:
+                    p.grad += g[off:off + n].view(shape)         # a tensor the caller put there: add this pass's gradient like autograd would
+
+    def zero_grad(self, set_to_none: bool = True):
+        """nn.Module.zero_grad, and the flat gradient array with it (it is what FusedAdamW and attach_param_grads=False callers read)."""
+        super().zero_grad(set_to_none=set_to_none)
+        if set_to_none:
+            self.flat_grad = None
+        elif self.flat_grad is not None:
+            self.flat_grad.zero_()
 
     # ------------------------------------------------------------------ reference interface
     def forward(self, x, return_rep=False):

@@ -168,3 +168,51 @@ def test_gradient_accumulation_over_two_backwards():
         O.loss_total(oracle(x), y)[0].backward()
     K.loss3(model(x.cuda()), y.cuda())[0].backward()
     _grads_close(model, oracle, 2e-3, 1e-3)
+
+
+def test_optimizer_over_a_parameter_subset_restarts_only_its_own_gradients():
+    """Fine-tuning `head` alone: torch.optim.AdamW([head.weight, head.bias]).zero_grad() sets only those two .grad to None.  Their gradient must
+    restart every step (not keep summing because some other tensor still carries a gradient), while the tensors outside the optimizer
+    accumulate exactly like torch's would (accumulate-vs-fresh was decided for the whole model from one layer-0 tensor)."""
+    import kasportsformer_amd as K
+    oracle, model = make_pair(1, 27, "fp32")
+    head_ref = [oracle.head.weight, oracle.head.bias]
+    head = [model.head.weight, model.head.bias]
+    opt_ref = torch.optim.AdamW(head_ref, lr=5e-3, weight_decay=0.01)
+    opt = torch.optim.AdamW(head, lr=5e-3, weight_decay=0.01)
+    oracle.train(); model.train()
+    for step in range(3):
+        x, y = O.synthetic_clips(2, 27, seed=300 + step)
+        with forced_adjacency(model, x):
+            pred_ref = oracle(x)
+            opt_ref.zero_grad()
+            O.loss_total(pred_ref, y)[0].backward()
+        pred = model(x.cuda())
+        opt.zero_grad()
+        K.loss3(pred, y.cuda())[0].backward()
+        torch.cuda.synchronize()
+        for a, b in zip(head, head_ref):                      # this step's gradient alone
+            assert float((a.grad.cpu() - b.grad).abs().max()) < 1e-3 * max(1e-6, float(b.grad.abs().max())), step
+        # a tensor outside the optimizer: the running sum over the steps so far, on both sides
+        a, b = model.rep_logit.fc.weight.grad.cpu(), oracle.rep_logit.fc.weight.grad
+        assert float((a - b).abs().max()) < 1e-3 * float(b.abs().max()), step
+        opt_ref.step(); opt.step()
+    for a, b in zip(head, head_ref):
+        assert float((a.detach().cpu() - b.detach()).abs().max()) < 1e-4
+
+
+def test_module_zero_grad_resets_the_flat_gradient():
+    """attach_param_grads=False (the FusedAdamW path): the flat array accumulates over backward passes and `model.zero_grad()` restarts it."""
+    import kasportsformer_amd as K
+    _, model = make_pair(1, 27, "fp32")
+    model.train()
+    model.attach_param_grads = False
+    x, y = (t.cuda() for t in O.synthetic_clips(2, 27, seed=310))
+    K.loss3(model(x), y)[0].backward()
+    g1 = model.flat_grad.clone()
+    K.loss3(model(x), y)[0].backward()
+    assert float((model.flat_grad - 2 * g1).abs().max()) < 1e-4 * float(g1.abs().max())          # accumulated (atomics: not bit-equal)
+    model.zero_grad()
+    assert model.flat_grad is None
+    K.loss3(model(x), y)[0].backward()
+    assert float((model.flat_grad - g1).abs().max()) < 1e-4 * float(g1.abs().max())

@@ -13,9 +13,10 @@ _ORACLE_RUNS = {}        # init -> (oracle state after STEPS, its evaluation): s
 
 
 def _data():
-    xs, ys = O.synthetic_clips(B * 4, T, seed=77)
-    xt, yt = O.synthetic_clips(6, T, seed=78)
-    label_scaled, factor, res, actions = O.synthetic_test_extras(yt, seed=79)
+    # learnable labels (a fixed seeded map of the 2-D pose): independent-noise labels keep MPJPE at the label scale whatever the model does
+    xs, ys = O.teacher_clips(B * 4, T, seed=77)
+    xt, yt = O.teacher_clips(6, T, seed=78)
+    label_scaled, factor, res, actions = O.synthetic_test_extras(yt, seed=79, noise_mm=2.0)
     return xs, ys, xt, (label_scaled, factor, res, actions)
 
 
@@ -45,11 +46,14 @@ def _default_init_pair(cd):
     return oracle, model.cuda()
 
 
-# fp32 from the reference's default init: the SURVEY §8(d) bar, |dMPJPE| <= 0.1 mm.  With de-identitied (fully random) weights the temporal
-# top-4 neighbour choice sits on near-ties, one flipped neighbour changes a gradient by O(1) and the two runs drift apart chaotically (the
-# reference on two different machines would too): that case gets 2 mm (observed 0.02-0.6 mm, depending on which near-tie the run-to-run noise
-# of the fp32 atomics flips).  bf16 deviations are reported; bars = observed (2.0 / 3.6 mm of 334-340 mm) x 2.
-@pytest.mark.parametrize("init,cd,tol_mm", [("default", "fp32", 0.1), ("seeded", "fp32", 2.0), ("default", "bf16", 4.0), ("seeded", "bf16", 7.0)])
+# Labels are LEARNABLE (teacher_labels), so MPJPE moves (208 -> 173 mm in these 16 steps) and a deviation shows; on the independent-noise labels of
+# rounds 1-2 it sat at the label scale whatever the model did.  fp32 from the reference's default init: the SURVEY §8(d) bar, |dMPJPE| <= 0.1 mm
+# (observed 1e-4).  With de-identitied (fully random, O(1) layer scales) weights the temporal top-4 neighbour choice sits on near-ties, one flipped
+# neighbour changes a token by O(1) and the runs drift apart chaotically (the reference on two machines would too): fp32 observed 0.43 mm of 207.
+# bf16 (bars = observed x 2..3): default init 0.55 mm of 173 -- the regime real training runs in; profiles/r3_train_fidelity.json follows it for
+# 1,000 steps at full depth: final MPJPE 27.9 mm against fp32's 28.0 -- ; de-identitied weights 20 mm of 207: a third of the temporal GCN rows pick
+# another 4th neighbour in bf16 (test_temporal_topk_adjacency_masks_bf16_agreement), which this untrained random network amplifies.
+@pytest.mark.parametrize("init,cd,tol_mm", [("default", "fp32", 0.1), ("seeded", "fp32", 1.0), ("default", "bf16", 1.5), ("seeded", "bf16", 40.0)])
 def test_training_then_evaluation_tracks_oracle(init, cd, tol_mm):
     import kasportsformer_amd as K
     oracle, model = make_pair(L, T, cd) if init == "seeded" else _default_init_pair(cd)
