@@ -43,8 +43,8 @@ typedef struct kasf_model kasf_model;
 typedef struct kasf_config {
     int32_t n_layers;            /* 26 in the shipped yaml (configs/sportspose-gt-kasportsformer.yaml:71) */
     int32_t n_frames;            /* T in [4, 256]: sizes the temporal BatchNorm1d; 9 / 27 / 81 have tuned temporal kernels, T <= 96 MFMA attention cores */
-    int32_t num_heads;           /* 8 in every yaml (:84; head dim 16: MFMA attention kernels); 2 / 4 / 16 run generic kernels (4 = the constructor's default) */
-    int32_t neighbour_num;       /* top-k of the temporal GCN adjacency, 1..4 (yaml :89: 4) */
+    int32_t num_heads;           /* 8 in every yaml (:84; head dim 16: MFMA attention kernels); 2 / 4 / 16 run generic kernels (4 = the constructor's default; 2: n_frames <= 157) */
+    int32_t neighbour_num;       /* top-k of the temporal GCN adjacency: must be 4 (yaml :89); other values are rejected */
     int32_t use_adaptive_fusion; /* 1: softmax gate, 0: plain mean (KASportsFormer.py:284) */
     int32_t dtype;               /* KASF_DTYPE_* */
 } kasf_config;
@@ -93,7 +93,8 @@ int kasf_forward(const kasf_model* m, const float* params, const void* packed, f
 int kasf_backward(const kasf_model* m, const float* params, const void* packed, const float* dout, float* grads, void* workspace,
                   int64_t workspace_bytes, int32_t batch, int32_t flags, int32_t stage_begin, int32_t stage_end, void* stream);
 
-/* losses[4] = {total, mpjpe, n_mpjpe, velocity}; dpred = grad_scale * dTotal/dpred */
+/* losses: 4 + 4 * batch floats; on return losses[0..3] = {total, mpjpe, n_mpjpe, velocity} (the rest is scratch: per-clip sums, added in a fixed order so
+ * that the result is bit-reproducible); dpred = grad_scale * dTotal/dpred */
 int kasf_loss3(const float* pred, const float* target, float* dpred, float* losses, int32_t batch, int32_t n_frames, float lambda_n_mpjpe,
                float lambda_velocity, float grad_scale, void* stream);
 

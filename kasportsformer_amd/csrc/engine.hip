@@ -38,17 +38,18 @@ static bool single_stream() {
     static const bool v = getenv("KASF_SINGLE_STREAM") != nullptr;
     return v;
 }
-constexpr int64_t WG_PARTIAL_FLOATS = KASF_MLP_PARTIAL_FLOATS + KASF_MLP_FLAG_WORDS;   // per-split weight-gradient tiles: 256 workgroups x 128x128, or 64 ranges x (dW1 + dW2) of the MLP; + its hand-off flags
+constexpr int64_t WG_PARTIAL_FLOATS = KASF_MLP_PARTIAL_FLOATS + 65536;   // per-split weight-gradient tiles (256 workgroups x 128x128, or 64 ranges x (dW1 + dW2) of the MLP) + the per-split rows of a bias gradient
 
 struct BlkWs { int64_t qkv, kv, o, xn, y, mask, x_mid, xn2, x_out, stats, bstats, coef; };
 struct LayerWs { BlkWs b[6]; int64_t gate_out, alpha; };
 struct WsEntry { std::string name; int64_t off, numel; int kind; };
-struct Scratch { int64_t uv, t1, t2, hbuf, dzbuf, d_o, dqkv, rbuf, duv, xn_a, xn_b, wg_part, g_in; };   // per-branch (att / graph / bone)
+struct Scratch { int64_t uv, t1, t2, hbuf, dzbuf, d_o, dqkv, rbuf, duv, xn_a, xn_b, wg_part, g_in, col; };   // per-branch (att / graph / bone); col: per-workgroup rows of the column reductions (k_reduce.hip)
 struct Plan {
     int64_t total = 0, stats_begin = 0, stats_bytes = 0, bstats_begin = 0, bstats_bytes = 0;
     int64_t x3, bone3, limb3, xj, xb, xl, rep, uv;
     std::vector<LayerWs> layers;
     int64_t g_layer, g_prev, ga, gg, gb, g_limb, g_bone, dlimb3;
+    int64_t col_cap = 0;     // floats per Scratch::col
     Scratch sc[3];
     std::vector<WsEntry> entries;
 };
@@ -297,6 +298,9 @@ void build_plan(const kasf_model* m, int B, bool train, bool names, Plan& p) {
     p.rep = take(M * 512, 0, "rep");
     for (int br = 0; br < 3; ++br) p.sc[br].uv = (br == 1) ? take(M * 256, 0, "scratch_uv") : -1;     // only the graph branch needs it
     if (train) {
+        // rows of per-workgroup column sums between a kernel and the stage's k_col_finish: the persistent bf16 kernels need ~1 M floats per layer and branch,
+        // the first-generation kernels (fp32 mode, the 512-wide top-level data gradient) one 256-float row per 32 / 64 tokens and launch
+        p.col_cap = (int64_t)3 * 1024 * 1024 + (es == 4 ? 56 : 8) * M;
         p.g_layer = take(M * 128, 0, "g_layer");
         p.g_prev = take(M * 128, 0, "g_prev");
         p.ga = take(M * 128, 0, "g_att");
@@ -316,6 +320,7 @@ void build_plan(const kasf_model* m, int B, bool train, bool names, Plan& p) {
             s.dzbuf = es == 4 ? take(M * 512, 0, nm("mlp_dz")) : -1;          // bf16 fuses the weight gradients: no dZ round trip
             s.xn_a = take(M * 128, 0, nm("scratch_xn_a"));
             s.wg_part = take(WG_PARTIAL_FLOATS, 1, nm("wgrad_partials"));
+            s.col = take(p.col_cap, 1, nm("column_partials"));
             s.d_o = br != 1 ? take(M * 128, 0, nm("d_o")) : -1;
             s.dqkv = br != 1 ? take(M * 384, 0, nm("dqkv")) : -1;
             s.xn_b = br == 2 ? take(M * 128, 0, nm("scratch_xn_b")) : -1;
@@ -339,16 +344,16 @@ struct Ctx {
     int64_t M;
     bool train;              // activations are kept for a backward pass
     bool bn_train;           // BatchNorm uses batch statistics and updates the running ones (KASF_FLAG_TRAIN)
+    KasfColSink* sink = nullptr;   // backward: where this stream's kernels leave their per-workgroup column sums
     const void* pk(int64_t elem_off) const { return A + elem_off * es; }
     void* w(int64_t byte_off) const { return ws + byte_off; }
 };
 
 void block_forward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void* x_in, const void* x_limb, const Plan& p, const Scratch& sc) {
     const float* P = c.P;
-    static const bool no_blk = getenv("KASF_NO_ATTN_BLOCK") != nullptr;       // measurement switch: unfused attention forward
-    bool mixer_done = false;     // bf16, groups of <= 32 positions: LN + QKV + attention + proj + residual in one kernel (csrc/k_attn_blk.hip)
+    bool mixer_done = false;     // bf16, 8 heads, groups of <= 96 positions: LN + QKV + attention + proj + residual in one kernel (csrc/k_attn_blk.hip)
     const int heads = c.m->cfg.num_heads;
-    if (c.dt == KASF_BF16 && !no_blk && o.kind != KIND_GRAPH && heads == 8) {
+    if (c.dt == KASF_BF16 && o.kind != KIND_GRAPH && heads == 8) {
         const bool bone = o.kind == KIND_BONE;
         mixer_done = kasf_launch_attn_block_fwd(c.s, bone ? 1 : 0, x_in, bone ? x_limb : nullptr, P + o.n1w, P + o.n1b, bone ? P + o.n1lw : nullptr,
                                                 bone ? P + o.n1lb : nullptr, c.pk(o.p_mix), bone ? c.pk(o.p_kv) : nullptr, c.pk(o.p_proj), P + o.proj_b,
@@ -379,50 +384,47 @@ void block_forward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void* 
                         w.xn2 >= 0 ? c.w(w.xn2) : nullptr);
 }
 
-// g_out: gradient w.r.t. the block output; writes (or accumulates) the gradient w.r.t. x_in into dst
+// g_out: gradient w.r.t. the block output; writes (or accumulates) the gradient w.r.t. x_in into dst.
+// Every per-channel gradient (LayerNorm gamma / beta, biases, layer scales) leaves its kernel as per-workgroup rows in c.sink and is complete only
+// after the stage's kasf_col_flush.
 void block_backward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void* x_in, const void* x_limb, const void* g_out, void* dst, int accumulate,
                     const Plan& p, const Scratch& sc) {
     const float* P = c.P;
     float* G = c.G;
     void* g_mid = c.w(sc.t2);
+    float* part = (float*)c.w(sc.wg_part);
     // ---- MLP half ----
     if (c.dt == KASF_BF16) {
-        // hidden-quarter kernel: dgrad + both weight gradients fused, then the 4-way partial sum + LayerNorm backward
+        // hidden-quarter kernel: dgrad + both weight gradients fused, then the 4-way partial sum + LayerNorm backward + the fc2 layer-scale algebra
         kasf_launch_mlp_bwd_q(c.s, c.w(w.x_mid), c.w(w.xn2), g_out, P + o.n2w, c.pk(o.p_fc1), P + o.fc1b, c.pk(o.p_fc2Ts), c.pk(o.p_fc1T), c.w(sc.hbuf),
-                              (float*)c.w(sc.wg_part), G + o.fc1w, G + o.fc2w, G + o.fc1b, G + o.fc2b, g_mid, G + o.n2w, G + o.n2b, c.M, P + o.fc2w, P + o.fc2b,
-                              P + o.ls2, G + o.ls2, c.m->d_err);        // includes the fc2 layer-scale finish
+                              part, G + o.fc1w, G + o.fc2w, G + o.fc1b, G + o.fc2b, g_mid, G + o.n2w, G + o.n2b, c.M, P + o.fc2w, P + o.fc2b,
+                              P + o.ls2, G + o.ls2, c.sink);
     } else {
         kasf_launch_mlp_bwd(c.dt, c.s, c.w(w.x_mid), g_out, P + o.n2w, P + o.n2b, c.pk(o.p_fc1), P + o.fc1b, c.pk(o.p_fc2Ts), c.pk(o.p_fc1T), c.w(sc.hbuf),
-                            c.w(sc.dzbuf), c.w(sc.xn_a), g_mid, G + o.n2w, G + o.n2b, c.M);
-        kasf_launch_wgrad(c.dt, c.s, c.w(sc.dzbuf), 512, 512, c.w(sc.xn_a), 128, 128, nullptr, nullptr, G + o.fc1w, 128, G + o.fc1b, c.M,
-                          (float*)c.w(sc.wg_part), WG_PARTIAL_FLOATS);
-        kasf_launch_wgrad(c.dt, c.s, g_out, 128, 128, c.w(sc.hbuf), 512, 512, nullptr, nullptr, G + o.fc2w, 512, G + o.fc2b, c.M, (float*)c.w(sc.wg_part),
-                          WG_PARTIAL_FLOATS);
+                            c.w(sc.dzbuf), c.w(sc.xn_a), g_mid, G + o.n2w, G + o.n2b, c.M, c.sink);
+        kasf_launch_wgrad(c.dt, c.s, c.w(sc.dzbuf), 512, 512, c.w(sc.xn_a), 128, 128, nullptr, nullptr, G + o.fc1w, 128, G + o.fc1b, c.M, part, WG_PARTIAL_FLOATS);
+        kasf_launch_wgrad(c.dt, c.s, g_out, 128, 128, c.w(sc.hbuf), 512, 512, nullptr, nullptr, G + o.fc2w, 512, G + o.fc2b, c.M, part, WG_PARTIAL_FLOATS);
         kasf_launch_finalize_ls(c.s, G + o.fc2w, P + o.fc2w, P + o.fc2b, P + o.ls2, G + o.fc2b, G + o.ls2, 128, 512);
     }
     // ---- mixer half ----
     if (o.kind == KIND_GRAPH) {
         kasf_launch_gcn_bwd1(c.dt, c.s, g_mid, c.w(w.xn), c.w(w.y), (const float*)c.w(w.coef), P + o.ls1, c.w(sc.rbuf), G + o.ls1, (double*)c.w(w.bstats),
-                             c.B, c.T, o.mode);
+                             c.B, c.T, o.mode, c.sink);
         const double count = o.mode == 0 ? (double)c.B * c.T * 128 : (double)c.B * 17 * 128;
         kasf_launch_gcn_bwd2(c.dt, c.s, c.w(sc.rbuf), c.w(w.y), (const float*)c.w(w.coef), w.mask >= 0 ? (const uint32_t*)c.w(w.mask) : nullptr, c.w(sc.duv),
                              c.B, c.T, o.mode, (const double*)c.w(w.bstats), G + o.bn_w, G + o.bn_b, count, c.bn_train ? 1 : 0);
         kasf_launch_dgrad_lnbwd(c.dt, c.s, c.w(sc.duv), 256, c.pk(o.p_mixT), c.w(sc.rbuf), x_in, P + o.n1w, g_mid, dst, accumulate, G + o.n1w, G + o.n1b,
-                                c.M);
-        kasf_launch_wgrad(c.dt, c.s, c.w(sc.duv), 256, 256, c.w(w.xn), 128, 128, nullptr, nullptr, G + o.mix_w, 128, G + o.uv_b, c.M, (float*)c.w(sc.wg_part), WG_PARTIAL_FLOATS);
+                                c.M, nullptr, nullptr, c.sink);
+        kasf_launch_wgrad(c.dt, c.s, c.w(sc.duv), 256, 256, c.w(w.xn), 128, 128, nullptr, nullptr, G + o.mix_w, 128, G + o.uv_b, c.M, part, WG_PARTIAL_FLOATS);
         return;
     }
-    // d_o = g_mid . (ls1 . Wproj);  G_proj = g_mid^T o (unscaled) -> finalize: dWproj, dbproj, dls1
-    static const bool no_fdo = getenv("KASF_NO_FUSED_DO") != nullptr;          // measurement switch
+    // d_o = g_mid . (ls1 . Wproj);  G_proj = g_mid^T o (unscaled) -> finish: dWproj, dbproj, dls1
     const int heads = c.m->cfg.num_heads;
-    static const bool no_fdo_long = getenv("KASF_NO_FUSED_DO_LONG") != nullptr;     // measurement switch: separate d_o linear for 33..96-position groups
     const int Lg = o.mode == 0 ? 17 : c.T;
-    const bool fdo = c.dt == KASF_BF16 && !no_fdo && heads == 8 && (Lg <= 32 || (Lg <= 96 && !no_fdo_long));   // d_o formed inside the attention backward kernel
+    const bool fdo = c.dt == KASF_BF16 && heads == 8 && Lg <= 96;   // d_o formed inside the attention backward kernel
     if (!fdo) kasf_launch_linear(c.dt, c.s, g_mid, 128, c.pk(o.p_projTs), 128, nullptr, c.w(sc.d_o), 128, c.M, 128, nullptr, nullptr, nullptr, 0);
     // bf16: every weight gradient of the block (proj, qkv | q, kv) goes into ONE streaming launch + one finishing launch at the end of the block
-    static const bool no_jobs = getenv("KASF_NO_WGRAD_JOBS") != nullptr;       // measurement switch
-    const bool jobs = c.dt == KASF_BF16 && !no_jobs;
-    float* part = (float*)c.w(sc.wg_part);
+    const bool jobs = c.dt == KASF_BF16;
     if (!jobs) {
         kasf_launch_wgrad(c.dt, c.s, g_mid, 128, 128, c.w(w.o), 128, 128, nullptr, nullptr, G + o.proj_w, 128, G + o.proj_b, c.M, part, WG_PARTIAL_FLOATS);
         kasf_launch_finalize_ls(c.s, G + o.proj_w, P + o.proj_w, P + o.proj_b, P + o.ls1, G + o.proj_b, G + o.ls1, 128, 128);
@@ -430,20 +432,12 @@ void block_backward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void*
     if (o.kind == KIND_ATT) {
         const char* q = (const char*)c.w(w.qkv);
         char* dq = (char*)c.w(sc.dqkv);
-        // KASF_ATTN_BLOCK_BWD=1: d_o, attention backward, QKV data gradient, LayerNorm backward + residual and LN(x) in ONE launch (k_attn_blk_bwd).
-        // Built, bit-compatible with the two-launch form -- and slower (121 / 101 us against 106 / 101 us): opt-in.
-        static const bool blk_bwd = getenv("KASF_ATTN_BLOCK_BWD") != nullptr;
-        const bool fused_bwd = fdo && blk_bwd && !accumulate &&
-                               kasf_launch_attn_block_bwd(c.s, q, g_mid, x_in, c.pk(o.p_projTs), c.pk(o.p_mixT), P + o.n1w, P + o.n1b, dq, dst, c.w(sc.xn_a),
-                                                          G + o.n1w, G + o.n1b, c.B, c.T, o.mode);
-        if (!fused_bwd) {
-            if (fdo) kasf_launch_attn_bwd_fused_do(c.s, q, 384, q + 128 * c.es, q + 256 * c.es, 384, g_mid, c.pk(o.p_projTs), dq, 384, dq + 128 * c.es,
-                                                   dq + 256 * c.es, 384, c.B, c.T, o.mode);
-            else kasf_launch_attn_bwd(c.dt, c.s, q, 384, q + 128 * c.es, q + 256 * c.es, 384, c.w(sc.d_o), dq, 384, dq + 128 * c.es, dq + 256 * c.es, 384, c.B,
-                                      c.T, o.mode, heads);
-            kasf_launch_dgrad_lnbwd(c.dt, c.s, dq, 384, c.pk(o.p_mixT), nullptr, x_in, P + o.n1w, g_mid, dst, accumulate, G + o.n1w, G + o.n1b, c.M,
-                                    c.w(sc.xn_a), P + o.n1b);
-        }
+        if (fdo) kasf_launch_attn_bwd_fused_do(c.s, q, 384, q + 128 * c.es, q + 256 * c.es, 384, g_mid, c.pk(o.p_projTs), dq, 384, dq + 128 * c.es,
+                                               dq + 256 * c.es, 384, c.B, c.T, o.mode);
+        else kasf_launch_attn_bwd(c.dt, c.s, q, 384, q + 128 * c.es, q + 256 * c.es, 384, c.w(sc.d_o), dq, 384, dq + 128 * c.es, dq + 256 * c.es, 384, c.B,
+                                  c.T, o.mode, heads);
+        kasf_launch_dgrad_lnbwd(c.dt, c.s, dq, 384, c.pk(o.p_mixT), nullptr, x_in, P + o.n1w, g_mid, dst, accumulate, G + o.n1w, G + o.n1b, c.M,
+                                c.w(sc.xn_a), P + o.n1b, c.sink);
         bool done = false;
         if (jobs) {
             const void* Gs[2] = {g_mid, dq};
@@ -468,9 +462,9 @@ void block_backward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void*
                                                c.T, o.mode);
         else kasf_launch_attn_bwd(c.dt, c.s, c.w(w.qkv), 128, kv, kv + 128 * c.es, 256, c.w(sc.d_o), dq, 128, dkv, dkv + 128 * c.es, 256, c.B, c.T, o.mode, heads);
         kasf_launch_dgrad_lnbwd(c.dt, c.s, dq, 128, c.pk(o.p_mixT), nullptr, x_in, P + o.n1w, g_mid, dst, accumulate, G + o.n1w, G + o.n1b, c.M,
-                                c.w(sc.xn_a), P + o.n1b);
+                                c.w(sc.xn_a), P + o.n1b, c.sink);
         kasf_launch_dgrad_lnbwd(c.dt, c.s, dkv, 256, c.pk(o.p_kvT), nullptr, x_limb, P + o.n1lw, nullptr, c.w(p.g_limb), 1, G + o.n1lw, G + o.n1lb, c.M,
-                                c.w(sc.xn_b), P + o.n1lb);
+                                c.w(sc.xn_b), P + o.n1lb, c.sink);
         bool done = false;
         if (jobs) {
             const void* Gs[3] = {g_mid, dq, dkv};
@@ -512,8 +506,11 @@ int kasf_model_create(const kasf_config* cfg, kasf_model** out) {
     // any clip length the reference can build (BatchNorm1d(n_frames), top-4 of T similarities needs T >= 4); 9 / 27 / 81 have tuned temporal
     // kernels (and T <= 96 the MFMA attention cores), other lengths run generic ones
     if (cfg->n_frames < 4 || cfg->n_frames > KASF_MAX_NODES) return kasf_set_error(3, "n_frames must be in [4, 256]");
-    if (cfg->neighbour_num < 1 || cfg->neighbour_num > 4) return kasf_set_error(3, "neighbour_num must be 1..4");
-    if (cfg->neighbour_num != 4) return kasf_set_error(3, "neighbour_num != 4 is not wired through yet");
+    if (cfg->neighbour_num != 4) return kasf_set_error(3, "neighbour_num must be 4 (every shipped yaml; the top-4 scan is what the temporal GCN kernels implement)");
+    // the generic attention backward (everything but 8 heads with n_frames <= 96 in bf16) keeps a track's q, k, v, d_o of one head in LDS:
+    // (4 T D + 4 T) floats <= 160 KB, i.e. T (D + 1) <= 10240 -- only num_heads = 2 (D = 64) beyond 157 frames exceeds it
+    if ((int64_t)cfg->n_frames * (128 / cfg->num_heads + 1) > 10240)
+        return kasf_set_error(3, "num_heads = 2 supports n_frames <= 157 (the attention backward keeps a head's track in LDS)");
     if (cfg->dtype != KASF_F32 && cfg->dtype != KASF_BF16) return kasf_set_error(3, "dtype must be KASF_DTYPE_F32 or KASF_DTYPE_BF16");
     kasf_model* m = new kasf_model();
     m->cfg = *cfg;
@@ -651,7 +648,7 @@ int kasf_forward(const kasf_model* m, const float* params, const void* packed, f
     build_plan(m, batch, train, false, p);
     if (workspace_bytes < p.total) return kasf_set_error(5, "workspace too small (see kasf_workspace_bytes)");
     Ctx c{m, params, (const char*)packed, buffers, nullptr, (char*)workspace, (hipStream_t)stream, batch, m->cfg.n_frames, m->cfg.dtype, esize(m),
-          (int64_t)batch * m->cfg.n_frames * 17, train, bn_train};
+          (int64_t)batch * m->cfg.n_frames * 17, train, bn_train, nullptr};
     g_err.clear();
     HIPCHK(hipMemsetAsync(c.w(p.stats_begin), 0, p.stats_bytes, c.s));
     if (train) HIPCHK(hipMemcpyAsync(c.w(p.x3), x, c.M * 3 * sizeof(float), hipMemcpyDeviceToDevice, c.s));
@@ -705,24 +702,27 @@ int kasf_backward(const kasf_model* m, const float* params, const void* packed, 
     build_plan(m, batch, true, false, p);
     if (workspace_bytes < p.total) return kasf_set_error(5, "workspace too small (see kasf_workspace_bytes)");
     Ctx c{m, params, (const char*)packed, nullptr, grads, (char*)workspace, (hipStream_t)stream, batch, m->cfg.n_frames, m->cfg.dtype, esize(m),
-          (int64_t)batch * m->cfg.n_frames * 17, true, (flags & KASF_FLAG_TRAIN) != 0};
+          (int64_t)batch * m->cfg.n_frames * 17, true, (flags & KASF_FLAG_TRAIN) != 0, nullptr};
     g_err.clear();
     const TopOff& t = m->top;
+    // one sink of per-workgroup column sums per branch stream; flushed (fixed-order finish, k_reduce.hip) on the caller's stream at the end of every stage
+    KasfColSink sinks[3];
+    KasfColSink* sink_ptrs[3] = {&sinks[0], &sinks[1], &sinks[2]};
+    for (int br = 0; br < 3; ++br) { sinks[br].scratch = (float*)c.w(p.sc[br].col); sinks[br].cap = p.col_cap; }
+    c.sink = &sinks[0];
     for (int st = stage_begin; st < stage_end; ++st) {
         // the running gradient w.r.t. the current layer's output alternates between two buffers
         auto gbuf = [&](int k) { return c.w((k & 1) ? p.g_prev : p.g_layer); };
         if (st == 0) {
-            for (int br = 0; br < 3; ++br)      // flag words behind the partial tiles (ticket of k_lnbwd_sum4_fin, hand-off flags of the experimental in-kernel reduction): zero once per pass, every launch leaves them zero
-                HIPCHK(hipMemsetAsync((char*)c.w(p.sc[br].wg_part) + (size_t)KASF_MLP_PARTIAL_FLOATS * 4, 0, (size_t)KASF_MLP_FLAG_WORDS * 4, c.s));
             HIPCHK(hipMemsetAsync(c.w(p.bstats_begin), 0, p.bstats_bytes, c.s));
             HIPCHK(hipMemsetAsync(c.w(p.g_limb), 0, c.M * 128 * c.es, c.s));
             const void* x_final = c.w(p.layers[L - 1].gate_out);
             if (flags & KASF_FLAG_RETURN_REP)      // the forward returned the tanh features: dout is [B,T,17,512], the head took no part
                 kasf_launch_rep_bwd(c.dt, c.s, dout, c.w(p.rep), c.w(p.sc[0].hbuf), c.M);
             else
-                kasf_launch_head_bwd(c.dt, c.s, dout, c.w(p.rep), params + t.head_w, c.w(p.sc[0].hbuf), grads + t.head_w, grads + t.head_b, c.M);
+                kasf_launch_head_bwd(c.dt, c.s, dout, c.w(p.rep), params + t.head_w, c.w(p.sc[0].hbuf), grads + t.head_w, grads + t.head_b, c.M, c.sink);
             kasf_launch_dgrad_lnbwd(c.dt, c.s, c.w(p.sc[0].hbuf), 512, c.pk(t.p_fcT), nullptr, x_final, params + t.norm_w, nullptr, gbuf(0), 0, grads + t.norm_w,
-                                    grads + t.norm_b, c.M, c.w(p.sc[0].xn_a), params + t.norm_b);
+                                    grads + t.norm_b, c.M, c.w(p.sc[0].xn_a), params + t.norm_b, c.sink);
             kasf_launch_wgrad(c.dt, c.s, c.w(p.sc[0].hbuf), 512, 512, c.w(p.sc[0].xn_a), 128, 128, nullptr, nullptr, grads + t.fc_w, 128, grads + t.fc_b, c.M,
                               (float*)c.w(p.sc[0].wg_part), WG_PARTIAL_FLOATS);
         } else if (st <= L) {
@@ -736,11 +736,12 @@ int kasf_backward(const kasf_model* m, const float* params, const void* packed, 
             const bool top = l == L - 1;
             kasf_launch_gate_bwd(c.dt, c.s, top ? g_out : c.w(p.sc[0].g_in), top ? nullptr : c.w(p.sc[1].g_in), top ? nullptr : c.w(p.sc[2].g_in),
                                  c.w(lw.b[1].x_out), c.w(lw.b[3].x_out), c.w(lw.b[5].x_out), params + lo.fus_w, (const float*)c.w(lw.alpha), c.w(p.ga), c.w(p.gg),
-                                 c.w(p.gb), grads + lo.fus_w, grads + lo.fus_b, c.M, m->cfg.use_adaptive_fusion, (float*)c.w(p.sc[0].wg_part), WG_PARTIAL_FLOATS);
+                                 c.w(p.gb), grads + lo.fus_w, grads + lo.fus_b, c.M, m->cfg.use_adaptive_fusion, c.sink);
             const int64_t gsrc[3] = {p.ga, p.gg, p.gb};
             HIPCHK(hipEventRecord(m->ev_fork, c.s));
             for (int br = 0; br < 3; ++br) {
                 Ctx cb = c;
+                cb.sink = &sinks[br];
                 if (br > 0) {
                     cb.s = single_stream() ? c.s : m->side[br - 1];
                     if (!single_stream()) HIPCHK(hipStreamWaitEvent(cb.s, m->ev_fork, 0));
@@ -773,13 +774,17 @@ int kasf_backward(const kasf_model* m, const float* params, const void* packed, 
                 hipStream_t st = (sidx == 2 || single_stream()) ? c.s : m->side[sidx];
                 if (st != c.s) HIPCHK(hipStreamWaitEvent(st, m->ev_fork, 0));
                 kasf_launch_embed_bwd(c.dt, st, gs[sidx], src[sidx], params + po.embed_w[sidx], grads + po.embed_w[sidx], grads + po.embed_b[sidx],
-                                      grads + po.pos[sidx], sidx == 2 ? (float*)c.w(p.dlimb3) : nullptr, frames);
+                                      grads + po.pos[sidx], sidx == 2 ? (float*)c.w(p.dlimb3) : nullptr, frames, &sinks[sidx]);
                 if (st != c.s) HIPCHK(hipEventRecord(m->ev_join[sidx], st));
             }
-            kasf_launch_refusion_bwd(c.s, (const float*)c.w(p.x3), (const float*)c.w(p.dlimb3), params, grads, m->d_pro, frames);
+            // the 204 limb-MLP tensors occupy one contiguous range of the gradient array (build_layout): a scratch row mirrors it
+            const int64_t rf_base = po.mlp[0][0], rf_end = po.mlp[50][3] + 1;
+            kasf_launch_refusion_bwd(c.s, (const float*)c.w(p.x3), (const float*)c.w(p.dlimb3), params, grads, m->d_pro, frames, &sinks[2], rf_base,
+                                     (int)(rf_end - rf_base));
             if (!single_stream())
                 for (int sidx = 0; sidx < 2; ++sidx) HIPCHK(hipStreamWaitEvent(c.s, m->ev_join[sidx], 0));
         }
+        kasf_col_flush(c.s, sink_ptrs, 3);          // every stream of the stage has joined the caller's: finish its per-channel gradients in a fixed order
     }
     HIPCHK(hipGetLastError());
     if (!g_err.empty()) return 3;
@@ -830,9 +835,10 @@ int kasf_eval_metrics(const float* pred, const float* label_scaled, const float*
     if (!pred || !label_scaled || !factor || !res || !mpjpe || !p_mpjpe || !accel || !jpe) return kasf_set_error(2, "null pointer argument");
     if (n_frames < 3 || n_frames > 256) return kasf_set_error(2, "eval_metrics: n_frames must be in [3,256]");
     if ((action == nullptr) != (action_sums == nullptr)) return kasf_set_error(2, "eval_metrics: action and action_sums go together");
+    g_err.clear();
     kasf_launch_eval_metrics((hipStream_t)stream, pred, label_scaled, factor, res, action, batch, n_frames, n_actions, mpjpe, p_mpjpe, accel, jpe, action_sums);
     HIPCHK(hipGetLastError());
-    return 0;
+    return g_err.empty() ? 0 : 3;
 }
 
 #define OP_DT_CHECK(dt) \
@@ -864,7 +870,6 @@ int kasf_op_mlp_bwd_fused(const void* x, const void* xn, const void* g, const fl
                           const void* w1t, void* dapart, float* partial, float* dw1, float* dw2_unscaled, float* db1, float* gsum, void* g_in,
                           float* dgamma, float* dbeta, int64_t M, void* stream) {
     if (!x || !xn || !g || !dapart || !partial || !dw1 || !dw2_unscaled || !db1 || !gsum || !g_in) return kasf_set_error(2, "null pointer argument");
-    HIPCHK(hipMemsetAsync(partial + KASF_MLP_PARTIAL_FLOATS, 0, (size_t)KASF_MLP_FLAG_WORDS * 4, (hipStream_t)stream));     // ticket, hand-off flags, timeout word
     kasf_launch_mlp_bwd_q((hipStream_t)stream, x, xn, g, ln_g, w1, b1, w2t_scaled, w1t, dapart, partial, dw1, dw2_unscaled, db1, gsum, g_in, dgamma,
                           dbeta, M);
     HIPCHK(hipGetLastError());

@@ -179,8 +179,10 @@ __global__ __launch_bounds__(256) void k_attn_bwd(const T* __restrict__ Q, int64
     }
 }
 
-template <typename K> void set_smem(K k, size_t bytes) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+template <typename K> bool set_smem(K k, size_t bytes) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) kasf_set_error(1000 + (int)e, "attention: cannot reserve the group's LDS tiles");
+    return e == hipSuccess;
 }
 
 template <typename T, int D>
@@ -193,7 +195,7 @@ void fwd_TD(hipStream_t s, const void* q, int64_t ldq, const void* k, const void
     if (bytes(HP) > 160 * 1024) { kasf_set_error(3, "attention: n_frames too large for the LDS-resident kernel"); return; }
     int threads = ((L * HP + 63) / 64) * 64;
     if (threads > 256) threads = 256;
-    set_smem(k_attn_fwd<T, D>, bytes(HP));
+    if (!set_smem(k_attn_fwd<T, D>, bytes(HP))) return;
     hipLaunchKernelGGL((k_attn_fwd<T, D>), dim3(groups), dim3(threads), bytes(HP), s, (const T*)q, ldq, (const T*)k, (const T*)v, ldkv, (T*)o, L, Tn, mode, HP);
 }
 template <typename T, int D>
@@ -207,7 +209,7 @@ void bwd_TD(hipStream_t s, const void* q, int64_t ldq, const void* k, const void
     if (bytes(HP) > 160 * 1024) { kasf_set_error(3, "attention backward: n_frames too large for the LDS-resident kernel"); return; }
     int threads = ((L * HP + 63) / 64) * 64;
     if (threads > 256) threads = 256;
-    set_smem(k_attn_bwd<T, D>, bytes(HP));
+    if (!set_smem(k_attn_bwd<T, D>, bytes(HP))) return;
     hipLaunchKernelGGL((k_attn_bwd<T, D>), dim3(groups), dim3(threads), bytes(HP), s, (const T*)q, ldq, (const T*)k, (const T*)v, ldkv, (const T*)d_o, (T*)dq,
                        lddq, (T*)dk, (T*)dv, lddkv, L, Tn, mode, HP);
 }

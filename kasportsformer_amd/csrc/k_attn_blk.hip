@@ -10,7 +10,6 @@
 //   * weights live in registers for the whole launch (64 VGPRs), groups arrive by LDS-direct loads two groups ahead.
 // HBM traffic per token: 256 B in (512 B for the bone form), 256 B out, plus -- in training only -- q|k|v and the attention output,
 // which the backward pass needs (written once).  The unfused path moved 2.8 KB per token.
-#include <cstdlib>
 #include <type_traits>
 #include "common.h"
 #include "kernels.h"
@@ -64,210 +63,18 @@ struct AttnBlkArgs {
     int L, T, mode, groups;
 };
 
-// Self-attention form: 72 KB of LDS and <= 128 VGPRs, so TWO workgroups share a CU and one group's barrier / LDS round-trip latencies are
-// covered by the other's work (a group is only 17-32 positions: the per-group dependency chain, not bandwidth, bounds a lone workgroup).
-template <bool BONE>
-__global__ __launch_bounds__(AB_THR, BONE ? 2 : 4) void k_attn_blk_fwd(const AttnBlkArgs a) {
-    constexpr int NS = BONE ? 2 : 1, SLOT = NS * AB_TILE;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16* sRing = reinterpret_cast<bf16*>(smem);        // [3][x tile (| x_limb tile)]
-    bf16* sA = sRing + 3 * SLOT;                        // [NS][32][128] LN(x) (| LN_limb(x_limb))
-    bf16* sO = sA + NS * AB_TILE;                       // [32][128] attention output of the 8 heads
-    bf16* sOut = sO + AB_TILE;                          // [32][128] x_mid
-    bf16* sHead = sOut + AB_TILE;                       // [8 waves][q | k | v][32][16] wave-private operand tiles
-    bf16* sQKV = sHead + 8 * 3 * 512 + 6 * 128 * 2;    // bone, training: [3][32][128] q | k | v rows for full-row stores (one workgroup per CU
-                                                        // cannot hide the acknowledgement latency of 32-byte scattered stores)
-    float* sLn = reinterpret_cast<float*>(sHead + 8 * 3 * 512);      // [6][128] gamma, beta, limb gamma, beta, proj bias, ls1: read through LDS so that
-                                                                     // they never sit in the vmcnt queue behind the look-ahead loads
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4, sub = lane & 15, rl = threadIdx.x >> 4;
-    const int r32 = lane & 31, hh = lane >> 5;
-    const int L = a.L;
-    const int per = (a.groups + gridDim.x - 1) / gridDim.x;
-    const int g0 = blockIdx.x * per;
-    int ng = a.groups - g0;
-    if (ng > per) ng = per;
-    if (ng <= 0) return;
-    bf16* sQh = sHead + w * 3 * 512;
-    bf16* sKh = sQh + 512;
-    bf16* sVh = sKh + 512;
-
-    // ---- weights of this wave: the q / k / v rows of head w, and 16 rows of the output projection ----
-    bf16x8 wq[3][4], wp[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        if (BONE) {
-            wq[0][ks] = *reinterpret_cast<const bf16x8*>(a.Wq + (int64_t)(16 * w + i) * 128 + 32 * ks + 8 * g);
-            wq[1][ks] = *reinterpret_cast<const bf16x8*>(a.Wkv + (int64_t)(16 * w + i) * 128 + 32 * ks + 8 * g);
-            wq[2][ks] = *reinterpret_cast<const bf16x8*>(a.Wkv + (int64_t)(128 + 16 * w + i) * 128 + 32 * ks + 8 * g);
-        } else {
-#pragma unroll
-            for (int nt = 0; nt < 3; ++nt) wq[nt][ks] = *reinterpret_cast<const bf16x8*>(a.Wq + (int64_t)(128 * nt + 16 * w + i) * 128 + 32 * ks + 8 * g);
-        }
-        wp[ks] = *reinterpret_cast<const bf16x8*>(a.Wproj + (int64_t)(16 * w + i) * 128 + 32 * ks + 8 * g);
-    }
-    if (threadIdx.x < 128) {
-        sLn[threadIdx.x] = a.ln_g[threadIdx.x];
-        sLn[128 + threadIdx.x] = a.ln_b[threadIdx.x];
-        if (BONE) { sLn[256 + threadIdx.x] = a.lnl_g[threadIdx.x]; sLn[384 + threadIdx.x] = a.lnl_b[threadIdx.x]; }
-        sLn[512 + threadIdx.x] = a.bproj[threadIdx.x];
-        sLn[640 + threadIdx.x] = a.ls1[threadIdx.x];
-    }
-    __syncthreads();
-    const int64_t ldrow = a.mode == 0 ? 128 : (int64_t)KASF_J * 128;
-
-    auto nx3 = [](int sl) { return sl == 2 ? 0 : sl + 1; };
-    auto issue = [&](int t, int sl) {                    // exactly NS LDS-direct loads per wave per call
-        const int G = g0 + (t < ng ? t : ng - 1);
-        const int64_t base = (int64_t)tok_of(G, 0, a.T, a.mode) * 128;
-        stage_tile_async<bf16, 32, AB_THR>(sRing + sl * SLOT, a.X + base, ldrow, L);
-        if (BONE) stage_tile_async<bf16, 32, AB_THR>(sRing + sl * SLOT + AB_TILE, a.XL + base, ldrow, L);
-    };
-    auto layernorm = [&](const bf16* raw, bf16* dst, const float* gp, const float* bp) {      // row rl: delivered by this wave's own load; gp/bp in LDS
-        float v[8];
-        tile_load8(raw, rl, sub * 8, v);
-        float s = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) s += v[e];
-        const float mean = reduce16(s) * (1.0f / 128.0f);
-        float q = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { v[e] -= mean; q += v[e] * v[e]; }
-        const float rstd = rsqrtf(reduce16(q) * (1.0f / 128.0f) + KASF_LN_EPS);
-        const f32x4 g0v = *reinterpret_cast<const f32x4*>(gp + sub * 8), g1v = *reinterpret_cast<const f32x4*>(gp + sub * 8 + 4);
-        const f32x4 b0v = *reinterpret_cast<const f32x4*>(bp + sub * 8), b1v = *reinterpret_cast<const f32x4*>(bp + sub * 8 + 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] = v[e] * rstd * g0v[e] + b0v[e]; v[4 + e] = v[4 + e] * rstd * g1v[e] + b1v[e]; }
-        tile_store8(dst, rl, sub * 8, v);
-    };
-    issue(0, 0);
-    issue(1, 1);
-    wait_async_le<NS>();
-    int sl = 0;
-    for (int t = 0; t < ng; ++t, sl = nx3(sl)) {
-        const int G = g0 + t;
-        const bf16* slot = sRing + sl * SLOT;
-        layernorm(slot, sA, sLn, sLn + 128);
-        if (BONE) layernorm(slot + AB_TILE, sA + AB_TILE, sLn + 256, sLn + 384);
-        barrier_keep_async();                            // B1: LN tiles complete; every wave finished the copy-out of the previous group
-        {   // ---- q_h, k_h, v_h of the 32 positions: 3 feature tiles x 2 position tiles ----
-            f32x4 acc[3][2];
-            zero_acc(acc);
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 f0 = tok_frag(sA, i, ks), f1 = tok_frag(sA, 16 + i, ks);
-                bf16x8 l0 = f0, l1 = f1;
-                if (BONE) { l0 = tok_frag(sA + AB_TILE, i, ks); l1 = tok_frag(sA + AB_TILE, 16 + i, ks); }
-                acc[0][0] = mfma16(wq[0][ks], f0, acc[0][0]);
-                acc[0][1] = mfma16(wq[0][ks], f1, acc[0][1]);
-#pragma unroll
-                for (int nt = 1; nt < 3; ++nt) {
-                    acc[nt][0] = mfma16(wq[nt][ks], l0, acc[nt][0]);
-                    acc[nt][1] = mfma16(wq[nt][ks], l1, acc[nt][1]);
-                }
-            }
-#pragma unroll
-            for (int nt = 0; nt < 3; ++nt)
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    float v[4] = {acc[nt][mt][0], acc[nt][mt][1], acc[nt][mt][2], acc[nt][mt][3]};
-                    store4(sQh + nt * 512 + (16 * mt + i) * 16 + 4 * g, v);                       // wave-private [pos][16]
-                    if (BONE && a.Qs != nullptr) store4(sQKV + nt * AB_TILE + Tile<bf16>::off4(16 * mt + i, 16 * w + 4 * g), v);
-                }
-        }
-        lds_fence();
-        if (!BONE && a.Qs != nullptr && r32 < L) {   // training: the backward pass reads q | k | v; each lane stores the 16 bytes it is about to use as an operand
-            const int64_t tok = tok_of(G, r32, a.T, a.mode);
-            const f32x4 vq = *reinterpret_cast<const f32x4*>(sQh + r32 * 16 + 8 * hh), vk = *reinterpret_cast<const f32x4*>(sKh + r32 * 16 + 8 * hh),
-                        vv = *reinterpret_cast<const f32x4*>(sVh + r32 * 16 + 8 * hh);
-            if (BONE) {
-                *reinterpret_cast<f32x4*>(a.Qs + tok * 128 + 16 * w + 8 * hh) = vq;
-                *reinterpret_cast<f32x4*>(a.KVs + tok * 256 + 16 * w + 8 * hh) = vk;
-                *reinterpret_cast<f32x4*>(a.KVs + tok * 256 + 128 + 16 * w + 8 * hh) = vv;
-            } else {
-                *reinterpret_cast<f32x4*>(a.Qs + tok * 384 + 16 * w + 8 * hh) = vq;
-                *reinterpret_cast<f32x4*>(a.Qs + tok * 384 + 128 + 16 * w + 8 * hh) = vk;
-                *reinterpret_cast<f32x4*>(a.Qs + tok * 384 + 256 + 16 * w + 8 * hh) = vv;
-            }
-        }
-        {   // ---- attention core of head w (k_attn_mfma.hip, one 32x32 score tile) ----
-            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sKh + r32 * 16 + 8 * hh);
-            const bf16x8 qf = *reinterpret_cast<const bf16x8*>(sQh + r32 * 16 + 8 * hh);
-            f32x16 z;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) z[e] = 0.f;
-            f32x16 st = mfma32(kf, qf, z);               // S^T[key][query]
-            float mx = -INFINITY;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float s = pos_of(e, hh) < L ? st[e] * 0.25f : -INFINITY;
-                st[e] = s;
-                mx = fmaxf(mx, s);
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            float sum = 0.f;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) { st[e] = __expf(st[e] - mx); sum += st[e]; }
-            sum += __shfl_xor(sum, 32);
-            const float inv = 1.0f / sum;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) st[e] *= inv;
-            f32x16 ot = mfma32(tr_frag(sVh, 0), pack8(st, 0), z);
-            ot = mfma32(tr_frag(sVh, 1), pack8(st, 1), ot);
-            // lane = query r32, registers 0..7 = channels {4hh..4hh+3, 8+4hh..8+4hh+3} of head w
-            float o0[4] = {ot[0], ot[1], ot[2], ot[3]}, o1[4] = {ot[4], ot[5], ot[6], ot[7]};
-            store4(sO + Tile<bf16>::off4(r32, 16 * w + 4 * hh), o0);
-            store4(sO + Tile<bf16>::off4(r32, 16 * w + 8 + 4 * hh), o1);
-        }
-        barrier_keep_async();                            // B2: all heads in sO (and q|k|v in sQKV)
-        {   // ---- output projection + layer-scale + residual: 16 channels x 32 positions per wave ----
-            f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                acc[0] = mfma16(wp[ks], tok_frag(sO, i, ks), acc[0]);
-                acc[1] = mfma16(wp[ks], tok_frag(sO, 16 + i, ks), acc[1]);
-            }
-            const f32x4 bpv = *reinterpret_cast<const f32x4*>(sLn + 512 + 16 * w + 4 * g), lsv = *reinterpret_cast<const f32x4*>(sLn + 640 + 16 * w + 4 * g);
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                float x[4], v[4];
-                load4(slot + Tile<bf16>::off4(16 * mt + i, 16 * w + 4 * g), x);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = x[r] + lsv[r] * (acc[mt][r] + bpv[r]);
-                store4(sOut + Tile<bf16>::off4(16 * mt + i, 16 * w + 4 * g), v);
-            }
-        }
-        barrier_keep_async();                            // B3: x_mid tile complete; slot (t-1)%3 has no readers left
-        issue(t + 2, nx3(nx3(sl)));
-        wait_async_le<NS>();                             // group t+1 landed (only group t+2 outstanding); this group's stores come after
-        {   // ---- full-row stores: x_mid always; o and q|k|v only when the backward pass will need them ----
-            const int row = threadIdx.x >> 4, ch = threadIdx.x & 15;
-            if (row < L) {
-                const int64_t tok = tok_of(G, row, a.T, a.mode);
-                const int co = Tile<bf16>::chunk_off(row, ch);
-                *reinterpret_cast<f32x4*>(a.OUT + tok * 128 + ch * 8) = *reinterpret_cast<const f32x4*>(sOut + co);
-                if (a.Qs != nullptr) *reinterpret_cast<f32x4*>(a.Os + tok * 128 + ch * 8) = *reinterpret_cast<const f32x4*>(sO + co);
-                if (BONE && a.Qs != nullptr) {
-                    *reinterpret_cast<f32x4*>(a.Qs + tok * 128 + ch * 8) = *reinterpret_cast<const f32x4*>(sQKV + co);
-                    *reinterpret_cast<f32x4*>(a.KVs + tok * 256 + ch * 8) = *reinterpret_cast<const f32x4*>(sQKV + AB_TILE + co);
-                    *reinterpret_cast<f32x4*>(a.KVs + tok * 256 + 128 + ch * 8) = *reinterpret_cast<const f32x4*>(sQKV + 2 * AB_TILE + co);
-                }
-            }
-        }
-    }
-    wait_async();
-}
-
 // ---------------------------------------------------------------------------------------------------------------
-// The same block with the inputs prefetched through REGISTERS instead of an LDS-direct ring: thread (row tid >> 4, chunk tid & 15) loads the
-// 16 bytes of x (and of x_limb) it is about to normalise -- a whole 256-byte row per 16 lanes -- one group ahead, keeps them in 4 (8) VGPRs
-// while the current group computes, and LayerNorm runs straight out of those registers.  No ring slots: 43 KB (self) / 67 KB (bone) of LDS
-// instead of 72 / 131; the q | k | v rows leave as each lane's 16-byte operand in both forms (no staging tile).
-// hipcc counts the prefetch loads itself: no hand-counted wait in this kernel.  Arithmetic identical to k_attn_blk_fwd, bit for bit.
-// Measured (one stream, B = 256, T = 27): self 55.5 us against the ring form's 56.5, bone 79.2 against 81.2: this is the default for both.
+// One-tile groups (<= 32 positions).  The inputs are prefetched through REGISTERS: thread (row tid >> 4, chunk tid & 15) loads the 16 bytes of x
+// (and of x_limb) it is about to normalise -- a whole 256-byte row per 16 lanes -- one group ahead, keeps them in 4 (8) VGPRs while the current
+// group computes, and LayerNorm runs straight out of those registers.  43 KB (self) / 67 KB (bone) of LDS; the q | k | v rows leave as each lane's
+// 16-byte operand.  hipcc counts the prefetch loads itself: no hand-counted wait in this kernel.  (Round 1's LDS-direct ring form measured
+// 56.5 / 81.2 us against 55.5 / 79.2 us and was removed.)  The self form fits 128 VGPRs, so TWO workgroups share a CU and one group's barrier /
+// LDS round-trip latencies are covered by the other's work (a group is only 17-32 positions: its dependency chain, not bandwidth, bounds a lone
+// workgroup).
 // ---------------------------------------------------------------------------------------------------------------
 // The bone form needs ~140 VGPRs (64 of them weights): at the 128 of two workgroups per CU hipcc spills four weight fragments and seven address
 // registers into the loop and the launch takes 104 us instead of 79 (measured; moving the look-ahead loads behind the core did not free enough).
-// So it runs ONE workgroup per CU, like the ring form it replaces (81 us); the self form fits 128 and runs two.
+// So it runs ONE workgroup per CU; the self form fits 128 and runs two.
 #ifndef KASF_RP_BONE_WAVES
 #define KASF_RP_BONE_WAVES 2
 #endif
@@ -711,13 +518,12 @@ __global__ __launch_bounds__(AB_THR, 2) void k_attn_blk_fwd_rp3(const AttnBlkArg
 
 }  // namespace
 
-// Returns false when the shape is outside the fused kernel's range (groups longer than 32 positions): the caller runs the unfused sequence.
+// Returns false when the shape is outside the fused kernels' range (groups longer than 96 positions): the caller runs the unfused sequence.
 bool kasf_launch_attn_block_fwd(hipStream_t s, int bone, const void* x, const void* x_limb, const float* ln_g, const float* ln_b, const float* lnl_g,
                                 const float* lnl_b, const void* Wq, const void* Wkv, const void* Wproj, const float* bproj, const float* ls1, void* q_save,
-                                void* kv_save, void* o_save, void* out, int B, int T, int mode, int form) {
+                                void* kv_save, void* o_save, void* out, int B, int T, int mode) {
     const int L = mode == 0 ? KASF_J : T;
-    static const bool no_long = getenv("KASF_NO_ATTN_BLOCK_LONG") != nullptr;       // measurement switch: groups of 33..96 positions run unfused
-    if (L > 96 || (L > 32 && no_long)) return false;
+    if (L > 96) return false;
     AttnBlkArgs a;
     a.X = (const bf16*)x; a.XL = (const bf16*)x_limb; a.ln_g = ln_g; a.ln_b = ln_b; a.lnl_g = lnl_g; a.lnl_b = lnl_b;
     a.Wq = (const bf16*)Wq; a.Wkv = (const bf16*)Wkv; a.Wproj = (const bf16*)Wproj; a.bproj = bproj; a.ls1 = ls1;
@@ -736,32 +542,16 @@ bool kasf_launch_attn_block_fwd(hipStream_t s, int bone, const void* x, const vo
         }
         return true;
     }
-    // form: 0 = LDS-direct ring (round 1), 1 = register prefetch (default); KASF_ATTN_FWD_FORM=0/1: measurement switch.
-    static const int env_form = getenv("KASF_ATTN_FWD_FORM") ? atoi(getenv("KASF_ATTN_FWD_FORM")) : -1;
-    const int use_rp = form >= 0 ? form : (env_form >= 0 ? env_form : 1);
     const int ns = bone ? 2 : 1;
-    if (use_rp) {
-        const int cap = bone ? 256 : 512;
-        const unsigned grid = (unsigned)(a.groups < cap ? a.groups : cap);
-        const size_t sh = (size_t)(1 + ns + 1 + 1) * AB_TILE * 2 + 8 * 3 * 512 * 2 + 6 * 128 * 4;
-        if (bone) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_blk_fwd_rp<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-            hipLaunchKernelGGL(k_attn_blk_fwd_rp<true>, dim3(grid), dim3(AB_THR), sh, s, a);
-        } else {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_blk_fwd_rp<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-            hipLaunchKernelGGL(k_attn_blk_fwd_rp<false>, dim3(grid), dim3(AB_THR), sh, s, a);
-        }
-        return true;
-    }
-    const int cap = bone ? 256 : 512;         // self-attention: two workgroups per CU
+    const int cap = bone ? 256 : 512;
     const unsigned grid = (unsigned)(a.groups < cap ? a.groups : cap);
-    const size_t sh = (size_t)(3 * ns + ns + 1 + 1) * AB_TILE * 2 + 8 * 3 * 512 * 2 + 6 * 128 * 4 + (bone ? 3 * AB_TILE * 2 : 0);
+    const size_t sh = (size_t)(1 + ns + 1 + 1) * AB_TILE * 2 + 8 * 3 * 512 * 2 + 6 * 128 * 4;
     if (bone) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_blk_fwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-        hipLaunchKernelGGL(k_attn_blk_fwd<true>, dim3(grid), dim3(AB_THR), sh, s, a);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_blk_fwd_rp<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        hipLaunchKernelGGL(k_attn_blk_fwd_rp<true>, dim3(grid), dim3(AB_THR), sh, s, a);
     } else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_blk_fwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-        hipLaunchKernelGGL(k_attn_blk_fwd<false>, dim3(grid), dim3(AB_THR), sh, s, a);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_blk_fwd_rp<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        hipLaunchKernelGGL(k_attn_blk_fwd_rp<false>, dim3(grid), dim3(AB_THR), sh, s, a);
     }
     return true;
 }

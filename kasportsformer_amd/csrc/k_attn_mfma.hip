@@ -141,7 +141,7 @@ __global__ __launch_bounds__(FDO ? 512 : 256) void k_attn_bwd_mfma(const bf16* _
                                                                    bf16* __restrict__ dQ, int64_t lddq, bf16* __restrict__ dK, bf16* __restrict__ dV,
                                                                    int64_t lddkv, int L, int Tn, int mode, int units, const bf16* __restrict__ Gmid,
                                                                    const bf16* __restrict__ Wp) {
-    static_assert(!FDO || NKT == 1, "fused d_o: one-tile groups");
+    static_assert(NKT == 1, "one-tile groups (<= 32 positions); longer groups: k_attn_bwd_long");
     constexpr int NWAVE = FDO ? 8 : 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TILE = NKT * 32 * 16;                           // bf16 elements of one [positions][16] tile
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(FDO ? 512 : 256) void k_attn_bwd_mfma(const bf16* _
                 float v4[4] = {st[0][4 * a4], st[0][4 * a4 + 1], st[0][4 * a4 + 2], st[0][4 * a4 + 3]};
                 store4(sdS + r * 32 + 8 * a4 + 4 * hh, v4);
             }
-        } else if (hh == 0) sStat[i] = f32x4{mx, inv, delta, 0.f};
+        }
     }
     if (NKT == 1) {   // ---------------- pass 2, one-tile groups: dV^T = dO^T . P, dK^T = Q^T . dS with P / dS read back transposed ----------------
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the tiles were written by other lanes of this wave (LDS is in order per wave)
@@ -258,38 +258,6 @@ __global__ __launch_bounds__(FDO ? 512 : 256) void k_attn_bwd_mfma(const bf16* _
         for (int ks = 0; ks < 2; ++ks) {
             dv = mfma32(tr_frag(sD, ks), tr_frag32(sP, ks), dv);
             dk = mfma32(tr_frag(sQ, ks), tr_frag32(sdS, ks), dk);
-        }
-        if (j < L) {
-            const int64_t tok = tok_of(G, j, Tn, mode);
-            store_t(dV + tok * lddkv + h * 16, dv, hh);
-            store_t(dK + tok * lddkv + h * 16, dk, hh);
-        }
-        return;
-    }
-    // ---------------- pass 2: lane = key ----------------
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-        if (32 * kt >= L) break;
-        const int j = 32 * kt + r;
-        f32x16 dv = zero16(), dk = zero16();
-#pragma unroll
-        for (int qt = 0; qt < NKT; ++qt) {
-            if (32 * qt >= L) break;
-            f32x16 s = mfma32(qf[qt], kf[kt], zero16());          // S[query][key]
-            f32x16 dp = mfma32(df[qt], vf[kt], zero16());         // dP[query][key]
-#pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const int i = 32 * qt + pos_of(g, hh);
-                const f32x4 stt = sStat[i < L ? i : 0];
-                const float p = (i < L) ? __expf(s[g] * 0.25f - stt[0]) * stt[1] : 0.f;
-                s[g] = p;                                          // P[query][key]
-                dp[g] = p * (dp[g] - stt[2]) * 0.25f;              // dS[query][key]
-            }
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                dv = mfma32(tr_frag(sD, 2 * qt + ks), pack8(s, ks), dv);       // dV^T[d][key] += dO^T . P
-                dk = mfma32(tr_frag(sQ, 2 * qt + ks), pack8(dp, ks), dk);      // dK^T[d][key] += Q^T . dS
-            }
         }
         if (j < L) {
             const int64_t tok = tok_of(G, j, Tn, mode);
@@ -603,262 +571,6 @@ __global__ __launch_bounds__(512, 4) void k_attn_bwd_pers(const bf16* __restrict
     flush(g0 + ng - 1);
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Fused backward of a SELF-attention block (bf16, groups of <= 32 positions): everything between the gradient of the block's output and the
-// gradient of its input in one persistent launch --
-//     d_o = g_mid . (ls1 . Wproj),  attention backward cores,  dXn = dq|dk|dv . Wqkv,  g_in = g_mid + LNbwd(dXn; x, gamma),  xn = LN(x)
-// -- where three launches ran before (k_attn_bwd_pers, k_dgrad_r<3>; dq|dk|dv went to HBM and came straight back, 180 MB per block).
-// 16 waves per workgroup, one workgroup per CU, two ROLES that meet at ONE barrier per group:
-//   waves 0-7  (A): wave h = head h, exactly k_attn_bwd_pers' program; dq|dk|dv of group t go into an LDS tile set (double-buffered)
-//   waves 8-15 (D): one interval later, wave d owns 16 of the 128 input channels: dXn of group t-1 = the tile set x its 48 register-resident
-//               weight fragments (24 MFMAs), rounded to bf16 into a second LDS tile like k_dgrad_r does; copies the dq|dk|dv rows out for the
-//               weight-gradient GEMM as whole 768-byte rows; and, another interval later, runs the LayerNorm backward of group t-2 with 16 lanes
-//               per row (x and g_mid chunks prefetched through registers), emitting g_in and LN(x).
-// The roles never wait for each other inside an interval: A writes buffer t&1 while D reads (t-1)&1, D's GEMM writes dXn buffer (t-1)&1 while its
-// row pass reads (t-2)&1.  The arithmetic is k_attn_bwd_pers' and k_dgrad_r's, bit for bit, except the order of the dgamma / dbeta sums.
-// ---------------------------------------------------------------------------------------------------------------
-struct AttnBlkBwdArgs {
-    const bf16 *QKV, *Gmid, *X;          // [M][384] q|k|v saved by the forward, [M][128] gradient of the block output, [M][128] block input
-    const bf16 *WpTs, *WqkvT;            // (ls1 . Wproj)^T [128][128];  Wqkv^T as k_dgrad_r reads it: [128 in][384]
-    const float *gamma, *beta;
-    bf16 *dQKV, *Gin, *XN;               // [M][384] for the weight-gradient GEMM, [M][128] gradient of the block input, [M][128] LN(x)
-    float *dgamma, *dbeta;
-    int L, T, mode, groups;
-};
-template <int NR>
-__global__ __launch_bounds__(1024, 4) void k_attn_blk_bwd(const AttnBlkBwdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int TILE = 32 * 16, T128 = 32 * 128;
-    constexpr int WAVE_BYTES = 3 * TILE * 2 + 2 * 32 * 32 * 2;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int L = a.L;
-    const int per = (a.groups + gridDim.x - 1) / gridDim.x;
-    const int g0 = blockIdx.x * per;
-    int ng = a.groups - g0;
-    if (ng > per) ng = per;
-    if (ng <= 0) return;                                             // workgroup-uniform
-    bf16* sG = reinterpret_cast<bf16*>(smem + 8 * WAVE_BYTES);      // [2][32][128] g_mid rows (FDO operand)
-    bf16* sDQKV = sG + 2 * T128;                                     // [2][q|k|v][32][128]
-    bf16* sDX = sDQKV + 2 * 3 * T128;                                // [2][32][128] dXn (bf16)
-    float* sPar = reinterpret_cast<float*>(sDX + 2 * T128);          // [gamma | beta | dgamma | dbeta][128]: role D reads / accumulates through LDS (its
-                                                                     // 48 weight registers leave no room for four per-thread vectors of 8)
-    const int stride = a.mode == 0 ? 1 : KASF_J;
-    auto base_of = [&](int G) { return a.mode == 0 ? G * KASF_J : (G / KASF_J) * a.T * KASF_J + (G % KASF_J); };
-    if (threadIdx.x >= 512 && threadIdx.x < 1024) {
-        const int c = threadIdx.x - 512;
-        sPar[c] = c < 128 ? a.gamma[c] : (c < 256 ? a.beta[c - 128] : 0.f);      // 512 entries: gamma, beta, zeroed dgamma, dbeta
-    }
-    if (wave < 8) {
-        // ======================================= role A: attention backward of head `wave` =======================================
-        const int r = lane & 31, hh = lane >> 5, h = wave;
-        bf16* sK = reinterpret_cast<bf16*>(smem + wave * WAVE_BYTES);
-        bf16* sQ = sK + TILE;
-        bf16* sD = sQ + TILE;
-        bf16* sP = sD + TILE;
-        bf16* sdS = sP + 32 * 32;
-        const int li = lane & 15, lg = lane >> 4;
-        const int grow = threadIdx.x >> 4, gch = threadIdx.x & 15;     // (threads 0..511)
-        bf16x8 wp[4];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) wp[ks] = *reinterpret_cast<const bf16x8*>(a.WpTs + (int64_t)(16 * h + li) * 128 + 32 * ks + 8 * lg);
-        bf16x8 kfN, vfN, qfN, gcN;
-        auto fetch = [&](int t) {
-            // the lane's offsets are re-derived here (a dozen integer instructions) instead of living in registers across the loop: this role sits at the
-            // 128-register cap, and a spilled value reloaded in the loop would put a scratch load -- and a vmcnt(0) -- into every group
-            int ln = lane;
-            asm volatile("" : "+v"(ln));
-            const int r_ = ln & 31, hh_ = ln >> 5, grow_ = wave * 4 + (ln >> 4), gch_ = ln & 15;
-            const int rc = r_ < L ? r_ : L - 1, growc = grow_ < L ? grow_ : L - 1;
-            const unsigned oq = (unsigned)(rc * stride) * 384u + h * 16 + 8 * hh_, og = (unsigned)(growc * stride) * 128u + gch_ * 8;
-            const unsigned b = (unsigned)base_of(g0 + t);
-            qfN = *reinterpret_cast<const bf16x8*>(a.QKV + (size_t)(b * 384u + oq));
-            kfN = *reinterpret_cast<const bf16x8*>(a.QKV + (size_t)(b * 384u + oq + 128));
-            vfN = *reinterpret_cast<const bf16x8*>(a.QKV + (size_t)(b * 384u + oq + 256));
-            gcN = *reinterpret_cast<const bf16x8*>(a.Gmid + (size_t)(b * 128u + og));
-        };
-        constexpr int NA4 = (NR + 3) / 4;
-        if (NA4 < 4) {
-#pragma unroll
-            for (int a4 = NA4; a4 < 4; ++a4) {
-                float z4[4] = {0.f, 0.f, 0.f, 0.f};
-                store4(sP + r * 32 + 8 * a4 + 4 * hh, z4);
-                store4(sdS + r * 32 + 8 * a4 + 4 * hh, z4);
-            }
-        }
-        fetch(0);
-        for (int t = 0; t < ng + 2; ++t) {
-            if (t >= ng) { __syncthreads(); continue; }              // the D waves still have two groups in their pipeline
-            const bf16x8 kf = r < L ? kfN : zero8(), vf = r < L ? vfN : zero8(), qf = r < L ? qfN : zero8();
-            bf16* sGt = sG + (t & 1) * T128;
-            *reinterpret_cast<bf16x8*>(sGt + Tile<bf16>::chunk_off(grow, gch)) = grow < L ? gcN : zero8();
-            *reinterpret_cast<bf16x8*>(sK + r * 16 + 8 * hh) = kf;
-            *reinterpret_cast<bf16x8*>(sQ + r * 16 + 8 * hh) = qf;
-            if (t + 1 < ng) fetch(t + 1);
-            __syncthreads();
-            bf16x8 df;
-            {
-                f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[ks], *reinterpret_cast<const bf16x8*>(sGt + Tile<bf16>::chunk_off(li, 4 * ks + lg)), acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[ks], *reinterpret_cast<const bf16x8*>(sGt + Tile<bf16>::chunk_off(16 + li, 4 * ks + lg)), acc[1], 0, 0, 0);
-                }
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    const float live = 16 * mt + li < L ? 1.0f : 0.0f;
-                    float v[4] = {acc[mt][0] * live, acc[mt][1] * live, acc[mt][2] * live, acc[mt][3] * live};
-                    store4(sD + (16 * mt + li) * 16 + 4 * lg, v);
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                df = *reinterpret_cast<const bf16x8*>(sD + r * 16 + 8 * hh);
-            }
-            f32x16 st = mfma32(kf, qf, zero16());
-            f32x16 dp = mfma32(vf, df, zero16());
-            float mx = -INFINITY;
-#pragma unroll
-            for (int g = 0; g < NR; ++g) {
-                const float sv = (pos_of(g, hh) < L) ? st[g] * 0.25f : -INFINITY;
-                st[g] = sv;
-                mx = fmaxf(mx, sv);
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            float sum = 0.f;
-#pragma unroll
-            for (int g = 0; g < NR; ++g) { st[g] = __expf(st[g] - mx); sum += st[g]; }
-            sum += __shfl_xor(sum, 32);
-            const float inv = 1.0f / sum;
-            float delta = 0.f;
-#pragma unroll
-            for (int g = 0; g < NR; ++g) { st[g] *= inv; delta += st[g] * dp[g]; }
-#pragma unroll
-            for (int g = NR; g < 16; ++g) st[g] = 0.f;
-            delta += __shfl_xor(delta, 32);
-#pragma unroll
-            for (int a4 = 0; a4 < NA4; ++a4) {
-                float v4[4] = {st[4 * a4], st[4 * a4 + 1], st[4 * a4 + 2], st[4 * a4 + 3]};
-                store4(sP + r * 32 + 8 * a4 + 4 * hh, v4);
-            }
-#pragma unroll
-            for (int g = 0; g < NR; ++g) st[g] = st[g] * (dp[g] - delta) * 0.25f;
-            f32x16 dq = mfma32(tr_frag(sK, 0), pack8(st, 0), zero16());
-            dq = mfma32(tr_frag(sK, 1), pack8(st, 1), dq);
-#pragma unroll
-            for (int a4 = 0; a4 < NA4; ++a4) {
-                float v4[4] = {st[4 * a4], st[4 * a4 + 1], st[4 * a4 + 2], st[4 * a4 + 3]};
-                store4(sdS + r * 32 + 8 * a4 + 4 * hh, v4);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            f32x16 dv = zero16(), dk = zero16();
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                dv = mfma32(tr_frag(sD, ks), tr_frag32(sP, ks), dv);
-                dk = mfma32(tr_frag(sQ, ks), tr_frag32(sdS, ks), dk);
-            }
-            // dq | dk | dv of position r, channels 8hh..8hh+7 of head h -> the tile set of this group (rows past L: zero)
-            const u32x4_t z = {0u, 0u, 0u, 0u};
-            const u32x4_t pq = swap_t16(dq), pk = swap_t16(dk), pv = swap_t16(dv);
-            bf16* set = sDQKV + (t & 1) * 3 * T128;
-            const int co = Tile<bf16>::chunk_off(r, 2 * h + hh);
-            *reinterpret_cast<u32x4_t*>(set + co) = r < L ? pq : z;
-            *reinterpret_cast<u32x4_t*>(set + T128 + co) = r < L ? pk : z;
-            *reinterpret_cast<u32x4_t*>(set + 2 * T128 + co) = r < L ? pv : z;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-    } else {
-        // ======================================= role D: QKV data gradient + LayerNorm backward =======================================
-        const int d = wave - 8, dt = threadIdx.x - 512, i = lane & 15, g = lane >> 4, sub = dt & 15, rl = dt >> 4;
-        bf16x8 wf[12];
-#pragma unroll
-        for (int ks = 0; ks < 12; ++ks) wf[ks] = *reinterpret_cast<const bf16x8*>(a.WqkvT + (int64_t)(16 * d + i) * 384 + 32 * ks + 8 * g);
-        const int rlc = rl < L ? rl : L - 1;
-        const unsigned ox = (unsigned)(rlc * stride) * 128u + sub * 8;
-        bf16x8 xN = {}, gN = {};
-        float dgs[8], dbs[8];                                        // dgamma / dbeta of this thread's 8 channels over its rows
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { dgs[e] = 0.f; dbs[e] = 0.f; }
-        auto rowpass = [&](int u) {                                  // LayerNorm backward of group u: one 16-lane group per row (k_dgrad_r's epilogue,
-            const bf16* dx = sDX + (u & 1) * T128;                   //  written to keep few values live: this role sits at the 128-register cap)
-            float x[8], dd[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) x[e] = (float)xN[e];
-            float sm = 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) sm += x[e];
-            const float mean = reduce16(sm) * (1.0f / 128.0f);
-            float qv = 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { x[e] -= mean; qv += x[e] * x[e]; }
-            const float rstd = rsqrtf(reduce16(qv) * (1.0f / 128.0f) + KASF_LN_EPS);
-            tile_load8(dx, rl, sub * 8, dd);
-            const bool live = rl < L;
-            const size_t off = (size_t)(((unsigned)base_of(g0 + u) + (unsigned)(rlc * stride)) * 128u + sub * 8);
-            float s1 = 0.f, s2 = 0.f;
-            {
-                float xn[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float gme = sPar[sub * 8 + e];
-                    xn[e] = x[e] * rstd * gme + sPar[128 + sub * 8 + e];
-                    x[e] *= rstd;
-                    if (live) { dgs[e] += dd[e] * x[e]; dbs[e] += dd[e]; }
-                    dd[e] *= gme;
-                    s1 += dd[e];
-                    s2 += dd[e] * x[e];
-                }
-                if (live) store8(a.XN + off, xn);
-            }
-            s1 = reduce16(s1) * (1.0f / 128.0f);
-            s2 = reduce16(s2) * (1.0f / 128.0f);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) dd[e] = rstd * (dd[e] - s1 - x[e] * s2) + (float)gN[e];
-            if (live) store8(a.Gin + off, dd);
-        };
-        for (int t = 0; t < ng + 2; ++t) {
-            __syncthreads();
-            if (t >= 2) rowpass(t - 2);                              // consumes xN / gN (requested during the previous interval)
-            if (t >= 1 && t - 1 < ng) {                              // rows of group t-1 for the next interval's row pass
-                const unsigned b = (unsigned)base_of(g0 + t - 1) * 128u + ox;
-                xN = *reinterpret_cast<const bf16x8*>(a.X + (size_t)b);
-                gN = *reinterpret_cast<const bf16x8*>(a.Gmid + (size_t)b);
-            }
-            if (t >= 1 && t - 1 < ng) {
-                const int v = t - 1;
-                const bf16* set = sDQKV + (v & 1) * 3 * T128;
-                f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-                for (int ks = 0; ks < 12; ++ks) {                    // (no fragment double-buffering: 8 registers this role does not have; its LDS latency hides
-                    const bf16* tl = set + (ks >> 2) * T128;         //  behind the A waves' work)
-                    const bf16x8 f0 = *reinterpret_cast<const bf16x8*>(tl + Tile<bf16>::chunk_off(i, 4 * (ks & 3) + g));
-                    const bf16x8 f1 = *reinterpret_cast<const bf16x8*>(tl + Tile<bf16>::chunk_off(16 + i, 4 * (ks & 3) + g));
-                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks], f0, acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks], f1, acc[1], 0, 0, 0);
-                }
-                bf16* dx = sDX + (v & 1) * T128;
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    float w4[4] = {acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3]};
-                    store4(dx + Tile<bf16>::off4(mt * 16 + i, 16 * d + 4 * g), w4);
-                }
-                // dq | dk | dv rows of group v for the weight-gradient GEMM: whole 768-byte rows, 16 bytes per lane
-                const unsigned bq = (unsigned)base_of(g0 + v);
-                int dto = dt;
-                asm volatile("" : "+v"(dto));                        // (row / chunk of the three copies re-derived per interval: see role A's fetch)
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const int c = dto + 512 * j, row = c / 48, cc = c - row * 48, sec = cc >> 4, ch = cc & 15;
-                    if (row < L)
-                        *reinterpret_cast<f32x4*>(a.dQKV + (size_t)((bq + (unsigned)(row * stride)) * 384u + sec * 128 + ch * 8)) =
-                            *reinterpret_cast<const f32x4*>(set + sec * T128 + Tile<bf16>::chunk_off(row, ch));
-                }
-            }
-        }
-        // (LDS float atomics are slow -- 16 per thread per GROUP made the launch 2.8 x longer -- so they happen once per launch)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { atomicAdd(&sPar[256 + sub * 8 + e], dgs[e]); atomicAdd(&sPar[384 + sub * 8 + e], dbs[e]); }
-    }
-    __syncthreads();                                                 // both roles have passed the same ng + 2 barriers before this one
-    if (threadIdx.x < 256) atomicAdd((threadIdx.x < 128 ? a.dgamma : a.dbeta) + (threadIdx.x & 127), sPar[256 + threadIdx.x]);
-}
 template <typename K> void set_smem(K k, size_t bytes) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
@@ -889,16 +601,9 @@ bool kasf_launch_attn_bwd_mfma(hipStream_t s, const void* q, int64_t ldq, const 
         hipLaunchKernelGGL((k_attn_bwd_mfma<1, false>), grid, dim3(256), sh, s, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldkv, (const bf16*)d_o,
                            (bf16*)dq, lddq, (bf16*)dk, (bf16*)dv, lddkv, L, Tn, mode, units, (const bf16*)nullptr, (const bf16*)nullptr);
     } else {
-        static const bool two_pass = getenv("KASF_ATTN_BWD_TWO_PASS") != nullptr;     // measurement switch: the recomputing two-pass form
-        if (!two_pass) {
-            const size_t shl = 4 * (size_t)(4 * 96 * 16 + 2 * 32 * 32) * 2;
-            set_smem(k_attn_bwd_long<3, false>, shl);
-            hipLaunchKernelGGL((k_attn_bwd_long<3, false>), grid, dim3(256), shl, s, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldkv, (const bf16*)d_o,
-                               (bf16*)dq, lddq, (bf16*)dk, (bf16*)dv, lddkv, L, Tn, mode, units, (const bf16*)nullptr, (const bf16*)nullptr);
-            return true;
-        }
-        const size_t sh = 4 * (3 * 96 * 16 * 2 + 96 * 16);
-        hipLaunchKernelGGL((k_attn_bwd_mfma<3, false>), grid, dim3(256), sh, s, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldkv, (const bf16*)d_o,
+        const size_t shl = 4 * (size_t)(4 * 96 * 16 + 2 * 32 * 32) * 2;
+        set_smem(k_attn_bwd_long<3, false>, shl);
+        hipLaunchKernelGGL((k_attn_bwd_long<3, false>), grid, dim3(256), shl, s, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldkv, (const bf16*)d_o,
                            (bf16*)dq, lddq, (bf16*)dk, (bf16*)dv, lddkv, L, Tn, mode, units, (const bf16*)nullptr, (const bf16*)nullptr);
     }
     return true;
@@ -919,12 +624,9 @@ bool kasf_launch_attn_bwd_fused_do(hipStream_t s, const void* q, int64_t ldq, co
                            (bf16*)dq, lddq, (bf16*)dk, (bf16*)dv, lddkv, L, Tn, mode, groups * 8, (const bf16*)g_mid, (const bf16*)WprojTs);
         return true;
     }
-    static const bool env_one_group = getenv("KASF_ATTN_BWD_ONE_GROUP") != nullptr;        // measurement / parity switch: the round-1 form
-    const bool one_group_per_wg = form < 0 ? env_one_group : form == 1;
-    if (!one_group_per_wg) {
+    if (form != 1) {                                    // form 1: the one-group-per-workgroup kernel the persistent one is compared with bit for bit (tests)
         const size_t shp = 8 * (3 * 32 * 16 * 2 + 2 * 32 * 32 * 2) + 2 * 32 * 128 * 2;
-        static const int cap = getenv("KASF_ATTN_BWD_WGS") ? atoi(getenv("KASF_ATTN_BWD_WGS")) : 512;
-        const dim3 grid(groups < cap ? groups : cap);
+        const dim3 grid(groups < 512 ? groups : 512);   // two workgroups per CU
         if (L <= 17) {
             set_smem(k_attn_bwd_pers<9>, shp);
             hipLaunchKernelGGL(k_attn_bwd_pers<9>, grid, dim3(512), shp, s, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldkv, (bf16*)dq, lddq, (bf16*)dk,
@@ -940,27 +642,5 @@ bool kasf_launch_attn_bwd_fused_do(hipStream_t s, const void* q, int64_t ldq, co
     set_smem(k_attn_bwd_mfma<1, true>, sh);
     hipLaunchKernelGGL((k_attn_bwd_mfma<1, true>), dim3(groups), dim3(512), sh, s, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldkv,
                        (const bf16*)nullptr, (bf16*)dq, lddq, (bf16*)dk, (bf16*)dv, lddkv, L, Tn, mode, groups * 8, (const bf16*)g_mid, (const bf16*)WprojTs);
-    return true;
-}
-
-// Fused backward of a self-attention block (bf16, 8 heads, groups of <= 32 positions).  false: shape not covered, nothing launched.
-bool kasf_launch_attn_block_bwd(hipStream_t s, const void* qkv, const void* g_mid, const void* x, const void* WprojTs, const void* WqkvT, const float* gamma,
-                                const float* beta, void* dqkv, void* g_in, void* xn, float* dgamma, float* dbeta, int B, int Tn, int mode) {
-    const int L = mode == 0 ? KASF_J : Tn, groups = mode == 0 ? B * Tn : B * KASF_J;
-    if (L > 32) return false;
-    if (groups <= 0) return true;
-    AttnBlkBwdArgs a;
-    a.QKV = (const bf16*)qkv; a.Gmid = (const bf16*)g_mid; a.X = (const bf16*)x; a.WpTs = (const bf16*)WprojTs; a.WqkvT = (const bf16*)WqkvT;
-    a.gamma = gamma; a.beta = beta; a.dQKV = (bf16*)dqkv; a.Gin = (bf16*)g_in; a.XN = (bf16*)xn; a.dgamma = dgamma; a.dbeta = dbeta;
-    a.L = L; a.T = Tn; a.mode = mode; a.groups = groups;
-    const size_t sh = 8 * (3 * 32 * 16 * 2 + 2 * 32 * 32 * 2) + (size_t)(2 + 6 + 2) * 32 * 128 * 2 + 512 * 4;
-    const dim3 grid(groups < 256 ? groups : 256);
-    if (L <= 17) {
-        set_smem(k_attn_blk_bwd<9>, sh);
-        hipLaunchKernelGGL(k_attn_blk_bwd<9>, grid, dim3(1024), sh, s, a);
-    } else {
-        set_smem(k_attn_blk_bwd<16>, sh);
-        hipLaunchKernelGGL(k_attn_blk_bwd<16>, grid, dim3(1024), sh, s, a);
-    }
     return true;
 }

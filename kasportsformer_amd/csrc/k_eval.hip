@@ -266,6 +266,8 @@ void kasf_launch_gather_clips(hipStream_t s, const float* xa, const float* ya, c
 void kasf_launch_eval_metrics(hipStream_t s, const float* pred, const float* label, const float* factor, const float* res, const int* action, int B, int T,
                               int n_actions, float* mpjpe, float* pmpjpe, float* acc, float* jpe, double* action_sums) {
     if (B <= 0) return;
-    hipLaunchKernelGGL(k_eval_metrics, dim3(B), dim3(EV_THR), (size_t)T * 51 * 2 * sizeof(float), s, pred, label, factor, res, action, T, n_actions, mpjpe,
-                       pmpjpe, acc, jpe, action_sums);
+    const size_t sh = (size_t)T * 51 * 2 * sizeof(float);      // the clip and its label staged in LDS: 99 KB at T = 243, i.e. above the 64 KB default limit
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_eval_metrics), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    if (e != hipSuccess) { kasf_set_error(1000 + (int)e, "eval_metrics: cannot reserve the clip's LDS staging area"); return; }
+    hipLaunchKernelGGL(k_eval_metrics, dim3(B), dim3(EV_THR), sh, s, pred, label, factor, res, action, T, n_actions, mpjpe, pmpjpe, acc, jpe, action_sums);
 }

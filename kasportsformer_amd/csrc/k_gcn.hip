@@ -37,10 +37,12 @@ __device__ __forceinline__ int node_of(int tok, int T, int mode) { return mode =
 // ------------------------------------------------------------------ spatial aggregate (elementwise + 4-neighbour gather)
 template <typename T>
 __global__ __launch_bounds__(256) void k_gcn_agg_spatial(const T* __restrict__ uv, T* __restrict__ y, double* __restrict__ stats, int64_t M) {
-    __shared__ float sStat[KASF_J * 2];
-    if (threadIdx.x < KASF_J * 2) sStat[threadIdx.x] = 0.f;
+    // one private row of node sums per 16-lane group, touched by that group's lane 0 only (in program order), and a fixed-order sum over the 16 rows:
+    // the workgroup's contribution does not depend on wave scheduling (LDS float atomics from several waves would)
+    __shared__ float sStat[16][KASF_J * 2];
+    for (int k = threadIdx.x; k < 16 * KASF_J * 2; k += 256) (&sStat[0][0])[k] = 0.f;
     __syncthreads();
-    const int sub = threadIdx.x & 15;
+    const int sub = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int n_items = (int)(M * 16);
     for (int item = blockIdx.x * 256 + threadIdx.x; item < n_items; item += gridDim.x * 256) {
         const int tk = item >> 4, fr = (tk / KASF_J) * KASF_J;
@@ -65,10 +67,15 @@ __global__ __launch_bounds__(256) void k_gcn_agg_spatial(const T* __restrict__ u
         for (int k = 0; k < 8; ++k) { const float r = to_f(from_f<T>(acc[k])); s1 += r; s2 += r * r; }   // statistics of the stored value
         s1 = reduce16(s1);
         s2 = reduce16(s2);
-        if (sub == 0) { atomicAdd(&sStat[i * 2], s1); atomicAdd(&sStat[i * 2 + 1], s2); }
+        if (sub == 0) { sStat[rl][i * 2] += s1; sStat[rl][i * 2 + 1] += s2; }
     }
     __syncthreads();
-    if (threadIdx.x < KASF_J * 2) atomicAdd(stat_slot(stats) + threadIdx.x, (double)sStat[threadIdx.x]);
+    if (threadIdx.x < KASF_J * 2) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sStat[k][threadIdx.x];
+        atomicAdd(stat_slot(stats) + threadIdx.x, (double)t);
+    }
 }
 
 // ------------------------------------------------------------------ temporal aggregate: persistent workgroups, one (b, joint) track at a time
@@ -308,10 +315,11 @@ __global__ __launch_bounds__(256) void k_gcn_apply(const T* __restrict__ x_in, c
 template <typename T>
 __global__ __launch_bounds__(256) void k_gcn_bwd1(const T* __restrict__ g, const T* __restrict__ xn, const T* __restrict__ y, const float* __restrict__ coef,
                                                   const float* __restrict__ ls1, T* __restrict__ rbuf, float* __restrict__ dls1,
-                                                  double* __restrict__ bstats, int64_t M, int Tn, int mode, int nodes) {
-    __shared__ float sStat[KASF_MAX_NODES * 2];
+                                                  double* __restrict__ bstats, int64_t M, int Tn, int mode, int nodes, float* __restrict__ dls_rows) {
+    extern __shared__ __attribute__((aligned(16))) char smem_b1[];
+    float* sStat = reinterpret_cast<float*>(smem_b1);   // [16][2 nodes]: one private row per 16-lane group (see k_gcn_agg_spatial)
     __shared__ float sRed[16 * 128];
-    for (int idx = threadIdx.x; idx < 2 * nodes; idx += 256) sStat[idx] = 0.f;
+    for (int idx = threadIdx.x; idx < 16 * 2 * nodes; idx += 256) sStat[idx] = 0.f;
     __syncthreads();
     const int sub = threadIdx.x & 15, rl = threadIdx.x >> 4;
     float ls[8], dls[8];
@@ -351,7 +359,7 @@ __global__ __launch_bounds__(256) void k_gcn_bwd1(const T* __restrict__ g, const
             store8(rbuf + tok * 128 + sub * 8, r);
             s1 = reduce16(s1);
             s2 = reduce16(s2);
-            if (sub == 0) { atomicAdd(&sStat[node * 2], s1); atomicAdd(&sStat[node * 2 + 1], s2); }
+            if (sub == 0) { sStat[rl * 2 * nodes + node * 2] += s1; sStat[rl * 2 * nodes + node * 2 + 1] += s2; }
         }
     }
 #pragma unroll
@@ -361,9 +369,15 @@ __global__ __launch_bounds__(256) void k_gcn_bwd1(const T* __restrict__ g, const
         float s = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) s += sRed[k * 128 + threadIdx.x];
-        atomicAdd(dls1 + threadIdx.x, s);
+        if (dls_rows != nullptr) dls_rows[(int64_t)blockIdx.x * 128 + threadIdx.x] = s;      // one row per workgroup, added in a fixed order by k_col_finish
+        else atomicAdd(dls1 + threadIdx.x, s);
     }
-    for (int idx = threadIdx.x; idx < 2 * nodes; idx += 256) atomicAdd(stat_slot(bstats) + idx, (double)sStat[idx]);
+    for (int idx = threadIdx.x; idx < 2 * nodes; idx += 256) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sStat[k * 2 * nodes + idx];
+        atomicAdd(stat_slot(bstats) + idx, (double)t);
+    }
 }
 
 // dy of one 8-channel chunk: BN backward with the finalised per-node means
@@ -713,9 +727,12 @@ void bwd2_T(hipStream_t s, const void* r, const void* y, const float* coef, cons
 
 }  // namespace
 
-static bool g_skel_ready = false;
+// the skeleton table lives in constant memory, of which every device has its own copy: once per device (one process may drive several)
 void kasf_gcn_init() {
-    if (g_skel_ready) return;
+    static bool ready[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && ready[dev]) return;
     // graph.py:16-17 -- copied as data (bit-exact indices); degree = number of listed neighbours
     static const int adj[KASF_J][4] = {{1, 7, 4, -1}, {2, 0, -1, -1}, {3, 1, -1, -1}, {2, -1, -1, -1}, {5, 0, -1, -1}, {6, 4, -1, -1},
                                        {5, -1, -1, -1}, {0, 8, -1, -1}, {7, 9, 11, 14}, {8, 10, -1, -1}, {9, -1, -1, -1}, {12, 8, -1, -1},
@@ -729,7 +746,7 @@ void kasf_gcn_init() {
             t.coef[i][e] = adj[i][e] >= 0 ? (1.0f / sqrtf((float)deg[i])) * (1.0f / sqrtf((float)deg[adj[i][e]])) : 0.f;
         }
     (void)hipMemcpyToSymbol(HIP_SYMBOL(c_skel), &t, sizeof(t));
-    g_skel_ready = true;
+    if (dev >= 0 && dev < 64) ready[dev] = true;
 }
 
 void kasf_launch_gcn_agg_fwd(int dt, hipStream_t s, const void* uv, const void* xn, void* y, uint32_t* mask, double* stats, int B, int T, int mode) {
@@ -746,13 +763,16 @@ void kasf_launch_gcn_apply(int dt, hipStream_t s, const void* x_in, const void* 
     else hipLaunchKernelGGL(k_gcn_apply<bf16>, dim3(ew_grid(M)), dim3(256), 0, s, (const bf16*)x_in, (const bf16*)xn, (const bf16*)y, stats, bn_w, bn_b, run_mean, run_var, coef, ls1, (bf16*)out, M, T, mode, nodes, count, training, momentum);
 }
 void kasf_launch_gcn_bwd1(int dt, hipStream_t s, const void* g, const void* xn, const void* y, const float* coef, const float* ls1, void* r,
-                          float* dls1, double* bstats, int B, int T, int mode) {
+                          float* dls1, double* bstats, int B, int T, int mode, KasfColSink* sink) {
     const int64_t M = (int64_t)B * T * KASF_J;
     const int nodes = mode == 0 ? KASF_J : T;
     unsigned grid = ew_grid(M);
-    if (grid > 512) grid = 512;                          // block-end atomics on dls1 / BN sums are same-address
-    if (dt == KASF_F32) hipLaunchKernelGGL(k_gcn_bwd1<float>, dim3(grid), dim3(256), 0, s, (const float*)g, (const float*)xn, (const float*)y, coef, ls1, (float*)r, dls1, bstats, M, T, mode, nodes);
-    else hipLaunchKernelGGL(k_gcn_bwd1<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)g, (const bf16*)xn, (const bf16*)y, coef, ls1, (bf16*)r, dls1, bstats, M, T, mode, nodes);
+    if (grid > 512) grid = 512;                          // block-end atomics on the BN sums are same-address
+    const size_t sh = (size_t)16 * 2 * nodes * sizeof(float);
+    float* rows = sink != nullptr ? sink->take((int)grid, 128) : nullptr;
+    if (dt == KASF_F32) hipLaunchKernelGGL(k_gcn_bwd1<float>, dim3(grid), dim3(256), sh, s, (const float*)g, (const float*)xn, (const float*)y, coef, ls1, (float*)r, dls1, bstats, M, T, mode, nodes, rows);
+    else hipLaunchKernelGGL(k_gcn_bwd1<bf16>, dim3(grid), dim3(256), sh, s, (const bf16*)g, (const bf16*)xn, (const bf16*)y, coef, ls1, (bf16*)r, dls1, bstats, M, T, mode, nodes, rows);
+    if (rows != nullptr) sink->add(rows, 128, (int)grid, 128, dls1);
 }
 void kasf_launch_gcn_bwd2(int dt, hipStream_t s, const void* r, const void* y, const float* coef, const uint32_t* mask, void* duv, int B, int T,
                           int mode, const double* bstats, float* d_bn_w, float* d_bn_b, double count, int training) {

@@ -93,12 +93,12 @@ __global__ __launch_bounds__(256) void k_linear_res(const T* __restrict__ A, con
 }
 
 // dxn = dY[M x Kd] . Wt[128 x Kd]^T (+ dxn_add);  out = (resid?) + (accumulate? out) + LNbwd(dxn; x, gamma)
-// dgamma += sum_m dxn*xhat, dbeta += sum_m dxn  (block partials -> fp32 atomics)
+// dgamma += sum_m dxn*xhat, dbeta += sum_m dxn  (one [dgamma | dbeta] row per workgroup in `part`, see lnbwd_rows)
 template <typename T, int BM, int NBUF>
 __global__ __launch_bounds__(256) void k_dgrad_lnbwd(const T* __restrict__ dY, int Kd, const T* __restrict__ Wt, const T* __restrict__ dxn_add,
                                                      const T* __restrict__ X, const float* __restrict__ gamma, const T* __restrict__ resid,
                                                      T* __restrict__ out, int accumulate, float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta, int64_t M, T* __restrict__ xn_out, const float* __restrict__ beta) {
+                                                     float* __restrict__ dbeta, int64_t M, T* __restrict__ xn_out, const float* __restrict__ beta, float* __restrict__ part) {
     constexpr int MT = BM / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* sA = reinterpret_cast<T*>(smem);                 // [NBUF][BM][128]
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void k_dgrad_lnbwd(const T* __restrict__ dY, i
     __syncthreads();
     acc_to_tile<T>(sW, acc, wn0, wm0, [](float v, int) { return v; });
     __syncthreads();
-    lnbwd_rows<T, BM>(sW, X, gamma, dxn_add, resid, out, accumulate, dgamma, dbeta, row0, M, reinterpret_cast<float*>(smem), xn_out, beta);
+    lnbwd_rows<T, BM>(sW, X, gamma, dxn_add, resid, out, accumulate, dgamma, dbeta, row0, M, reinterpret_cast<float*>(smem), xn_out, beta, part);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -211,7 +211,7 @@ __device__ __forceinline__ void wgrad_stage_sync(T* sT, const T* src, int64_t ld
 template <typename T, int NBUF, bool LN>
 __global__ __launch_bounds__(256) void k_wgrad(const T* __restrict__ G, int64_t ldg, const T* __restrict__ X, int64_t ldx,
                                                const float* __restrict__ ln_g, const float* __restrict__ ln_b, float* __restrict__ out,
-                                               int64_t ldo, float* __restrict__ dbias, int64_t M, int64_t slice, float* __restrict__ partial) {
+                                               int64_t ldo, float* __restrict__ dbias, int64_t M, int64_t slice, float* __restrict__ partial, float* __restrict__ brow) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* sG = reinterpret_cast<T*>(smem);                 // [NBUF][128][128]
     T* sX = sG + NBUF * 128 * 128;                      // [NBUF][128][128]
@@ -288,7 +288,9 @@ __global__ __launch_bounds__(256) void k_wgrad(const T* __restrict__ G, int64_t 
             float s = 0.f;
 #pragma unroll
             for (int k = 0; k < 16; ++k) s += red[k * 128 + threadIdx.x];
-            atomicAdd(dbias + n0 + threadIdx.x, s);
+            // one row of column sums per split (brow [splits][N], added in a fixed order by the finishing kernel), or an atomic without scratch
+            if (brow != nullptr) brow[(int64_t)blockIdx.z * (gridDim.x * 128) + n0 + threadIdx.x] = s;
+            else atomicAdd(dbias + n0 + threadIdx.x, s);
         }
     }
 }
@@ -305,8 +307,8 @@ constexpr int WR_BM = 64, WR_ST = 2, WR_IPT = 8;      // rows per tile, ring sta
 // One workgroup: the 128 x 128 tile (n0, k0) of split z.  N, K = full dimensions of the weight (partial tiles are laid out [z][N][K]).
 template <typename T>
 __device__ __forceinline__ void wgrad_ring_body(const T* __restrict__ G, int64_t ldg, const T* __restrict__ X, int64_t ldx, float* __restrict__ out,
-                                                int64_t ldo, float* __restrict__ dbias, int64_t M, int64_t slice, float* __restrict__ partial, int N, int K,
-                                                int n0, int k0, int z) {
+                                                int64_t ldo, float* __restrict__ dbias, int64_t M, int64_t slice, float* __restrict__ partial, float* __restrict__ brow,
+                                                int N, int K, int n0, int k0, int z) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* ring = reinterpret_cast<T*>(smem);               // [WR_ST][2][64][128]  (G tile, X tile)
     const int64_t m_begin = (int64_t)z * slice, m_end = (m_begin + slice < M) ? m_begin + slice : M;
@@ -389,7 +391,9 @@ __device__ __forceinline__ void wgrad_ring_body(const T* __restrict__ G, int64_t
             float s = 0.f;
 #pragma unroll
             for (int k = 0; k < 16; ++k) s += red[k * 128 + threadIdx.x];
-            atomicAdd(dbias + n0 + threadIdx.x, s);
+            // one row of column sums per split (brow [splits][N], added in a fixed order by the finishing kernel), or an atomic without scratch
+            if (brow != nullptr) brow[(int64_t)z * N + n0 + threadIdx.x] = s;
+            else atomicAdd(dbias + n0 + threadIdx.x, s);
         }
     }
 }
@@ -397,8 +401,8 @@ __device__ __forceinline__ void wgrad_ring_body(const T* __restrict__ G, int64_t
 template <typename T>
 __global__ __launch_bounds__(256) void k_wgrad_ring(const T* __restrict__ G, int64_t ldg, const T* __restrict__ X, int64_t ldx,
                                                     float* __restrict__ out, int64_t ldo, float* __restrict__ dbias, int64_t M, int64_t slice,
-                                                    float* __restrict__ partial) {
-    wgrad_ring_body<T>(G, ldg, X, ldx, out, ldo, dbias, M, slice, partial, gridDim.x * 128, gridDim.y * 128, blockIdx.x * 128, blockIdx.y * 128, blockIdx.z);
+                                                    float* __restrict__ partial, float* __restrict__ brow) {
+    wgrad_ring_body<T>(G, ldg, X, ldx, out, ldo, dbias, M, slice, partial, brow, gridDim.x * 128, gridDim.y * 128, blockIdx.x * 128, blockIdx.y * 128, blockIdx.z);
 }
 
 // Several weight gradients of one block in ONE launch (bf16): the launch / ramp-up / partial-write overhead of these short streaming kernels
@@ -406,7 +410,7 @@ __global__ __launch_bounds__(256) void k_wgrad_ring(const T* __restrict__ G, int
 struct WgJob {
     const bf16 *G, *X;
     int64_t ldg, ldx;
-    float *partial, *dbias;
+    float *partial, *dbias, *brow;   // brow: [splits][N] column sums of G per split (the bias gradient's partial rows), or nullptr
     int N, K, first;          // first workgroup of this job; it owns (N/128)(K/128) tiles x splits workgroups
 };
 struct WgJobs {
@@ -421,15 +425,16 @@ __global__ __launch_bounds__(256) void k_wgrad_ring_jobs(const WgJobs js) {
         if (q < js.n && (int)blockIdx.x >= js.j[q].first) ji = q;
     const WgJob& jb = js.j[ji];
     const int tiles_k = jb.K / 128, tiles = (jb.N / 128) * tiles_k, rel = blockIdx.x - jb.first, tile = rel % tiles, z = rel / tiles;
-    wgrad_ring_body<bf16>(jb.G, jb.ldg, jb.X, jb.ldx, nullptr, 0, jb.dbias, js.M, js.slice, jb.partial, jb.N, jb.K, (tile / tiles_k) * 128,
+    wgrad_ring_body<bf16>(jb.G, jb.ldg, jb.X, jb.ldx, nullptr, 0, jb.dbias, js.M, js.slice, jb.partial, jb.brow, jb.N, jb.K, (tile / tiles_k) * 128,
                           (tile % tiles_k) * 128, z);
 }
 struct FinJob {
     const float* partial;
     float* out;               // [N][K] dense, accumulated into
     int N, K, first;          // first workgroup; N*K/256 workgroups
-    const float *W, *bias, *ls;   // W != nullptr (K == 128): out += ls[n] * G, dls[n] += <W[n], G[n]> + bias[n] * db[n], db[n] *= ls[n]
+    const float *W, *bias, *ls;   // W != nullptr (K == 128): out += ls[n] * G, dls[n] += <W[n], G[n]> + bias[n] * colsum[n], db[n] += ls[n] * colsum[n]
     float *db, *dls;
+    const float* brow;            // [splits][N] per-split column sums of G (colsum = their fixed-order sum)
 };
 struct FinJobs {
     int n, splits;
@@ -477,10 +482,13 @@ __global__ __launch_bounds__(256) void k_wgrad_finish_jobs(const FinJobs js) {
             const float l = jb.ls[n];
 #pragma unroll
             for (int q = 0; q < 4; ++q) cur[q] += l * gsum[q];
+            float gs = 0.f;                              // colsum(g)[n]: the 32 lanes of this row add every 32nd split, then a fixed xor tree
+            for (int z2 = lane & 31; z2 < js.splits; z2 += 32) gs += jb.brow[(int64_t)z2 * jb.N + n];
+#pragma unroll
+            for (int m = 16; m >= 1; m >>= 1) gs += __shfl_xor(gs, m);
             if ((lane & 31) == 0) {
-                const float gs = jb.db[n];
                 jb.dls[n] += dot + jb.bias[n] * gs;
-                jb.db[n] = gs * l;
+                jb.db[n] += gs * l;
             }
         } else {
 #pragma unroll
@@ -493,8 +501,19 @@ __global__ __launch_bounds__(256) void k_wgrad_finish_jobs(const FinJobs js) {
 // out[n][k] += sum_z partial[z][n][k]   (N*K multiple of 256; out row stride ldo, partial row stride K).
 // A workgroup owns 64 consecutive float4 outputs; its 4 waves each sum every 4th split with 4 independent
 // loads in flight, then the partial sums meet in LDS (fixed order => bitwise reproducible gradients).
-__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ partial, float* __restrict__ out, int64_t ldo, int N, int K, int splits) {
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ partial, float* __restrict__ out, int64_t ldo, int N, int K, int splits,
+                                                      const float* __restrict__ brow, float* __restrict__ dbias) {
     __shared__ f32x4 sPart[4][64];
+    const int tile_wgs = (int)((int64_t)N * K / 256);
+    if ((int)blockIdx.x >= tile_wgs) {                   // extra workgroups: dbias[n] += sum_z brow[z][n], splits in order
+        const int n = ((int)blockIdx.x - tile_wgs) * 256 + threadIdx.x;
+        if (n < N) {
+            float sb = 0.f;
+            for (int z = 0; z < splits; ++z) sb += brow[(int64_t)z * N + n];
+            dbias[n] += sb;
+        }
+        return;
+    }
     const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
     const int64_t e = ((int64_t)blockIdx.x * 64 + lane) * 4, stride = (int64_t)N * K;
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
@@ -615,18 +634,24 @@ void kasf_launch_linear_res(int dt, hipStream_t s, const void* A, const void* W,
 
 template <typename T>
 static void dgrad_lnbwd_T(hipStream_t s, const void* dY, int Kd, const void* Wt, const void* dxn_add, const void* X, const float* gamma,
-                          const void* resid, void* out, int accumulate, float* dgamma, float* dbeta, int64_t M, void* xn_out, const float* beta) {
+                          const void* resid, void* out, int accumulate, float* dgamma, float* dbeta, int64_t M, void* xn_out, const float* beta,
+                          KasfColSink* sink) {
     constexpr int BM = GemmCfg<T>::BM, NBUF = GemmCfg<T>::NBUF;
     const size_t sh = (size_t)NBUF * (BM * 128 + 128 * 128) * sizeof(T);
     set_smem(k_dgrad_lnbwd<T, BM, NBUF>, sh);
-    hipLaunchKernelGGL((k_dgrad_lnbwd<T, BM, NBUF>), dim3((unsigned)((M + BM - 1) / BM)), dim3(256), sh, s, (const T*)dY, Kd, (const T*)Wt,
-                       (const T*)dxn_add, (const T*)X, gamma, (const T*)resid, (T*)out, accumulate, dgamma, dbeta, M, (T*)xn_out, beta);
+    const int grid = (int)((M + BM - 1) / BM);
+    float* part = sink != nullptr ? sink->take(grid, 256) : nullptr;
+    hipLaunchKernelGGL((k_dgrad_lnbwd<T, BM, NBUF>), dim3((unsigned)grid), dim3(256), sh, s, (const T*)dY, Kd, (const T*)Wt,
+                       (const T*)dxn_add, (const T*)X, gamma, (const T*)resid, (T*)out, accumulate, dgamma, dbeta, M, (T*)xn_out, beta, part);
+    if (part != nullptr) { sink->add(part, 256, grid, 128, dgamma); sink->add(part + 128, 256, grid, 128, dbeta); }
 }
 void kasf_launch_dgrad_lnbwd(int dt, hipStream_t s, const void* dY, int Kd, const void* Wt, const void* dxn_add, const void* X, const float* gamma,
-                             const void* resid, void* out, int accumulate, float* dgamma, float* dbeta, int64_t M, void* xn_out, const float* beta) {
-    if (dt == KASF_BF16 && kasf_launch_dgrad_r(s, dY, Kd, Wt, dxn_add, X, gamma, resid, out, accumulate, dgamma, dbeta, M, xn_out, beta)) return;
-    DT_DISPATCH(dt, (dgrad_lnbwd_T<float>(s, dY, Kd, Wt, dxn_add, X, gamma, resid, out, accumulate, dgamma, dbeta, M, xn_out, beta)),
-                (dgrad_lnbwd_T<bf16>(s, dY, Kd, Wt, dxn_add, X, gamma, resid, out, accumulate, dgamma, dbeta, M, xn_out, beta)));
+                             const void* resid, void* out, int accumulate, float* dgamma, float* dbeta, int64_t M, void* xn_out, const float* beta,
+                             KasfColSink* sink) {
+    if (M <= 0) return;
+    if (dt == KASF_BF16 && kasf_launch_dgrad_r(s, dY, Kd, Wt, dxn_add, X, gamma, resid, out, accumulate, dgamma, dbeta, M, xn_out, beta, sink)) return;
+    DT_DISPATCH(dt, (dgrad_lnbwd_T<float>(s, dY, Kd, Wt, dxn_add, X, gamma, resid, out, accumulate, dgamma, dbeta, M, xn_out, beta, sink)),
+                (dgrad_lnbwd_T<bf16>(s, dY, Kd, Wt, dxn_add, X, gamma, resid, out, accumulate, dgamma, dbeta, M, xn_out, beta, sink)));
 }
 
 template <typename T>
@@ -635,7 +660,7 @@ static void wgrad_T(hipStream_t s, const void* G, int64_t ldg, int N, const void
     constexpr int NBUF = GemmCfg<T>::WG_NBUF;
     const int tiles = (N / 128) * (K / 128);
     // one workgroup per CU (the 128 KB of LDS allow only one resident anyway): fewest splits that still fill the chip
-    static const int target = getenv("KASF_WGRAD_WGS") ? atoi(getenv("KASF_WGRAD_WGS")) : 248;   // measurement switch (496 = two per CU: slower, the partial tiles double)
+    constexpr int target = 248;                          // (496 = two per CU measured slower: the partial tiles double)
     int splits = (target + tiles - 1) / tiles;
     const int64_t max_splits = (M + WG_BM - 1) / WG_BM;
     if (splits > max_splits) splits = (int)max_splits;
@@ -643,34 +668,31 @@ static void wgrad_T(hipStream_t s, const void* G, int64_t ldg, int N, const void
     int64_t slice = (M + splits - 1) / splits;
     slice = (slice + WG_BM - 1) / WG_BM * WG_BM;
     splits = (int)((M + slice - 1) / slice);
-    if (partial != nullptr && (int64_t)splits * N * K > partial_floats) partial = nullptr;     // fall back to atomics
+    if (partial != nullptr && (int64_t)splits * N * K + (int64_t)splits * N > partial_floats) partial = nullptr;     // fall back to atomics
+    float* brow = (partial != nullptr && dbias != nullptr) ? partial + (int64_t)splits * N * K : nullptr;      // [splits][N] rows of the bias gradient
     const size_t sh = (size_t)2 * NBUF * 128 * 128 * sizeof(T);
     const dim3 grid(N / 128, K / 128, splits);
     if (ln_g == nullptr && sizeof(T) == 2) {
         const size_t shr = (size_t)WR_ST * 2 * WR_BM * 128 * sizeof(T);
         set_smem(k_wgrad_ring<T>, shr);
-        hipLaunchKernelGGL(k_wgrad_ring<T>, grid, dim3(256), shr, s, (const T*)G, ldg, (const T*)X, ldx, out, ldo, dbias, M, slice, partial);
+        hipLaunchKernelGGL(k_wgrad_ring<T>, grid, dim3(256), shr, s, (const T*)G, ldg, (const T*)X, ldx, out, ldo, dbias, M, slice, partial, brow);
     } else if (ln_g != nullptr) {
         set_smem(k_wgrad<T, NBUF, true>, sh);
         hipLaunchKernelGGL((k_wgrad<T, NBUF, true>), grid, dim3(256), sh, s, (const T*)G, ldg, (const T*)X, ldx, ln_g, ln_b, out, ldo, dbias, M, slice,
-                           partial);
+                           partial, brow);
     } else {
         set_smem(k_wgrad<T, NBUF, false>, sh);
         hipLaunchKernelGGL((k_wgrad<T, NBUF, false>), grid, dim3(256), sh, s, (const T*)G, ldg, (const T*)X, ldx, ln_g, ln_b, out, ldo, dbias, M, slice,
-                           partial);
+                           partial, brow);
     }
-    if (partial != nullptr) {
-        hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((int64_t)N * K / 256)), dim3(256), 0, s, partial, out, ldo, N, K, splits);
-    }
+    if (partial != nullptr)                              // fixed-order sum of the per-split tiles (+ (N + 255) / 256 workgroups for the bias rows)
+        hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((int64_t)N * K / 256 + (brow != nullptr ? (N + 255) / 256 : 0))), dim3(256), 0, s, partial, out, ldo, N, K,
+                           splits, brow, dbias);
 }
 void kasf_launch_wgrad(int dt, hipStream_t s, const void* G, int64_t ldg, int N, const void* X, int64_t ldx, int K, const float* ln_g,
                        const float* ln_b, float* out, int64_t ldo, float* dbias, int64_t M, float* partial, int64_t partial_floats) {
     DT_DISPATCH(dt, (wgrad_T<float>(s, G, ldg, N, X, ldx, K, ln_g, ln_b, out, ldo, dbias, M, partial, partial_floats)),
                 (wgrad_T<bf16>(s, G, ldg, N, X, ldx, K, ln_g, ln_b, out, ldo, dbias, M, partial, partial_floats)));
-}
-
-void kasf_launch_wgrad_reduce(hipStream_t s, const float* partial, float* out, int64_t ldo, int N, int K, int splits) {
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((int64_t)N * K / 256)), dim3(256), 0, s, partial, out, ldo, N, K, splits);
 }
 
 void kasf_launch_pack(int dt, hipStream_t s, const float* params, void* arena, const KasfPackDesc* desc, const int* tile_start, int ndesc,
@@ -689,7 +711,7 @@ bool kasf_launch_wgrad_jobs(hipStream_t s, int njobs, const void* const* G, cons
     if (njobs < 1 || njobs > 3 || M <= 0) return false;
     int tiles = 0;
     for (int j = 0; j < njobs; ++j) tiles += N[j] / 128;
-    static const int target = getenv("KASF_WGRAD_WGS") ? atoi(getenv("KASF_WGRAD_WGS")) : 248;
+    constexpr int target = 248;
     int splits = (target + tiles - 1) / tiles;
     const int64_t max_splits = (M + WG_BM - 1) / WG_BM;
     if (splits > max_splits) splits = (int)max_splits;
@@ -697,7 +719,10 @@ bool kasf_launch_wgrad_jobs(hipStream_t s, int njobs, const void* const* G, cons
     slice = (slice + WG_BM - 1) / WG_BM * WG_BM;
     splits = (int)((M + slice - 1) / slice);
     int64_t need = 0;
-    for (int j = 0; j < njobs; ++j) need += (int64_t)splits * N[j] * 128;
+    for (int j = 0; j < njobs; ++j) {
+        need += (int64_t)splits * N[j] * 128 + (dbias[j] != nullptr ? (int64_t)splits * N[j] : 0);
+        if (dbias[j] != nullptr && j != fin_job) return false;        // a bias gradient is finished together with the layer-scale algebra only
+    }
     if (partial == nullptr || need > partial_floats) return false;
     WgJobs js;
     FinJobs fj;
@@ -705,12 +730,13 @@ bool kasf_launch_wgrad_jobs(hipStream_t s, int njobs, const void* const* G, cons
     int first = 0, ffirst = 0;
     float* pp = partial;
     for (int j = 0; j < njobs; ++j) {
-        js.j[j] = WgJob{(const bf16*)G[j], (const bf16*)X[j], N[j], 128, pp, dbias[j], N[j], 128, first};
+        float* brow = dbias[j] != nullptr ? pp + (int64_t)splits * N[j] * 128 : nullptr;      // per-split rows of the bias gradient, behind the job's tiles
+        js.j[j] = WgJob{(const bf16*)G[j], (const bf16*)X[j], N[j], 128, pp, dbias[j], brow, N[j], 128, first};
         const bool fin = j == fin_job;
-        fj.j[j] = FinJob{pp, dW[j], N[j], 128, ffirst, fin ? fin_W : nullptr, fin_bias, fin_ls, dbias[j], fin_dls};
+        fj.j[j] = FinJob{pp, dW[j], N[j], 128, ffirst, fin ? fin_W : nullptr, fin_bias, fin_ls, dbias[j], fin_dls, brow};
         first += (N[j] / 128) * splits;
         ffirst += N[j] * 128 / 256;
-        pp += (int64_t)splits * N[j] * 128;
+        pp += (int64_t)splits * N[j] * 128 + (brow != nullptr ? (int64_t)splits * N[j] : 0);
     }
     const size_t shr = (size_t)WR_ST * 2 * WR_BM * 128 * sizeof(bf16);
     set_smem(k_wgrad_ring_jobs, shr);

@@ -27,7 +27,7 @@ template <int KC, bool RESID, bool ADD, bool ACC, bool XN, int RING>
 __global__ __launch_bounds__(R_THR) void k_dgrad_r(const bf16* __restrict__ dY, const bf16* __restrict__ Wt, const bf16* __restrict__ dxn_add,
                                                    const bf16* __restrict__ X, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                    const bf16* __restrict__ resid, bf16* __restrict__ out, float* __restrict__ dgamma,
-                                                   float* __restrict__ dbeta, bf16* __restrict__ xn_out, int64_t M) {
+                                                   float* __restrict__ dbeta, bf16* __restrict__ xn_out, int64_t M, float* __restrict__ part) {
     constexpr int Kd = 128 * KC;
     constexpr int NSTREAM = KC + 1 + (RESID ? 1 : 0) + (ADD ? 1 : 0) + (ACC ? 1 : 0);     // LDS-direct loads per wave per tile
     constexpr int SLOT = NSTREAM * R_TILE;
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(R_THR) void k_dgrad_r(const bf16* __restrict__ dY, 
     }
     wait_async();
     __syncthreads();
-    // ---- dgamma / dbeta: 32 row groups -> one atomic per channel per workgroup ----
+    // ---- dgamma / dbeta: 32 row groups -> one value per channel per workgroup: row blockIdx.x of `part` (fixed-order finish, k_reduce.hip) ----
 #pragma unroll
     for (int e = 0; e < 8; ++e) { sRed[rl * 128 + sub * 8 + e] = dg[e]; sRed[R_TILE + rl * 128 + sub * 8 + e] = db[e]; }
     __syncthreads();
@@ -163,13 +163,14 @@ __global__ __launch_bounds__(R_THR) void k_dgrad_r(const bf16* __restrict__ dY, 
         float s = 0.f;
 #pragma unroll 8
         for (int k = 0; k < 32; ++k) s += sRed[which * R_TILE + k * 128 + c];
-        atomicAdd((which == 0 ? dgamma : dbeta) + c, s);
+        if (part != nullptr) part[(int64_t)blockIdx.x * 256 + threadIdx.x] = s;
+        else atomicAdd((which == 0 ? dgamma : dbeta) + c, s);
     }
 }
 
 template <int KC, bool RESID, bool ADD, bool ACC, bool XN>
 void launch_dgrad_r(hipStream_t s, const void* dY, const void* Wt, const void* add, const void* X, const float* gamma, const float* beta, const void* resid,
-                    void* out, float* dgamma, float* dbeta, void* xn_out, int64_t M) {
+                    void* out, float* dgamma, float* dbeta, void* xn_out, int64_t M, KasfColSink* sink) {
     constexpr int NSTREAM = KC + 1 + (RESID ? 1 : 0) + (ADD ? 1 : 0) + (ACC ? 1 : 0);
     constexpr size_t fixed = (size_t)R_TILE * 2;                                        // sD (the end-of-kernel reduction reuses the ring: >= 32 KB)
     constexpr bool ring3 = 3 * NSTREAM * R_TILE * 2 + fixed <= 160 * 1024;
@@ -179,8 +180,12 @@ void launch_dgrad_r(hipStream_t s, const void* dY, const void* Wt, const void* a
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     const int64_t tiles = (M + R_BM - 1) / R_BM;
     const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
+    const int64_t per = (tiles + grid - 1) / grid;
+    const int active = (int)((tiles + per - 1) / per);                                  // workgroups that own at least one tile (the others return at once)
+    float* part = sink != nullptr ? sink->take(active, 256) : nullptr;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(R_THR), sh, s, (const bf16*)dY, (const bf16*)Wt, (const bf16*)add, (const bf16*)X, gamma, beta,
-                       (const bf16*)resid, (bf16*)out, dgamma, dbeta, (bf16*)xn_out, M);
+                       (const bf16*)resid, (bf16*)out, dgamma, dbeta, (bf16*)xn_out, M, part);
+    if (part != nullptr) { sink->add(part, 256, active, 128, dgamma); sink->add(part + 128, 256, active, 128, dbeta); }
 }
 
 
@@ -319,13 +324,13 @@ void launch_linear_r(hipStream_t s, const void* A, const void* W, const float* b
 
 // Returns false when the combination is not one of the instantiated ones (the caller then uses k_dgrad_lnbwd).
 bool kasf_launch_dgrad_r(hipStream_t s, const void* dY, int Kd, const void* Wt, const void* dxn_add, const void* X, const float* gamma, const void* resid,
-                         void* out, int accumulate, float* dgamma, float* dbeta, int64_t M, void* xn_out, const float* beta) {
+                         void* out, int accumulate, float* dgamma, float* dbeta, int64_t M, void* xn_out, const float* beta, KasfColSink* sink) {
     const bool R = resid != nullptr, A = dxn_add != nullptr, C = accumulate != 0, XN = xn_out != nullptr;
     if (M <= 0) return true;
-    if (Kd == 384 && R && !A && !C && XN) launch_dgrad_r<3, true, false, false, true>(s, dY, Wt, dxn_add, X, gamma, beta, resid, out, dgamma, dbeta, xn_out, M);
-    else if (Kd == 128 && R && !A && !C && XN) launch_dgrad_r<1, true, false, false, true>(s, dY, Wt, dxn_add, X, gamma, beta, resid, out, dgamma, dbeta, xn_out, M);
-    else if (Kd == 256 && !R && !A && C && XN) launch_dgrad_r<2, false, false, true, true>(s, dY, Wt, dxn_add, X, gamma, beta, resid, out, dgamma, dbeta, xn_out, M);
-    else if (Kd == 256 && R && A && !C && !XN) launch_dgrad_r<2, true, true, false, false>(s, dY, Wt, dxn_add, X, gamma, beta, resid, out, dgamma, dbeta, xn_out, M);
+    if (Kd == 384 && R && !A && !C && XN) launch_dgrad_r<3, true, false, false, true>(s, dY, Wt, dxn_add, X, gamma, beta, resid, out, dgamma, dbeta, xn_out, M, sink);
+    else if (Kd == 128 && R && !A && !C && XN) launch_dgrad_r<1, true, false, false, true>(s, dY, Wt, dxn_add, X, gamma, beta, resid, out, dgamma, dbeta, xn_out, M, sink);
+    else if (Kd == 256 && !R && !A && C && XN) launch_dgrad_r<2, false, false, true, true>(s, dY, Wt, dxn_add, X, gamma, beta, resid, out, dgamma, dbeta, xn_out, M, sink);
+    else if (Kd == 256 && R && A && !C && !XN) launch_dgrad_r<2, true, true, false, false>(s, dY, Wt, dxn_add, X, gamma, beta, resid, out, dgamma, dbeta, xn_out, M, sink);
     else return false;
     return true;
 }

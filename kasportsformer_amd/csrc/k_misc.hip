@@ -86,10 +86,14 @@ __global__ __launch_bounds__(256) void k_prologue_fwd(const float* __restrict__ 
 }
 
 // Embedding backward for one stream: dW[128][3], db[128], dpos[17][128], optional din3[M][3] = g . W
+constexpr int EMBED_ROW = 17 * 128 + 128 * 3 + 128;
 template <typename T>
 __global__ __launch_bounds__(256) void k_embed_bwd(const T* __restrict__ g, const float* __restrict__ in3, const float* __restrict__ W,
                                                    float* __restrict__ dW, float* __restrict__ db, float* __restrict__ dpos, float* __restrict__ din3,
-                                                   int64_t frames) {
+                                                   int64_t frames, float* __restrict__ rows) {
+    // rows != nullptr: this workgroup's sums go to row blockIdx.x of `rows` (dpos[17][128] | dW[128][3] | db[128] = EMBED_ROW floats) and are added in a
+    // fixed order by k_col_finish; otherwise fp32 atomics
+    float* prow = rows != nullptr ? rows + (int64_t)blockIdx.x * EMBED_ROW : nullptr;
     __shared__ float sRed[16][128];
     const int sub = threadIdx.x & 15, rl = threadIdx.x >> 4;
     float w[8][3], aw[8][3], ab[8], apA[8], apB[8];
@@ -142,11 +146,11 @@ __global__ __launch_bounds__(256) void k_embed_bwd(const T* __restrict__ g, cons
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        atomicAdd(dpos + rl * 128 + sub * 8 + e, apA[e]);
+        if (prow != nullptr) prow[rl * 128 + sub * 8 + e] = apA[e]; else atomicAdd(dpos + rl * 128 + sub * 8 + e, apA[e]);
         float b16 = apB[e];                          // joint 16: rows rl < EU hold a share each (lanes 16 rl + sub of the first waves)
         b16 += __shfl_xor(b16, 16);
         b16 += __shfl_xor(b16, 32);
-        if (threadIdx.x < 16) atomicAdd(dpos + 16 * 128 + sub * 8 + e, b16);
+        if (threadIdx.x < 16) { if (prow != nullptr) prow[16 * 128 + sub * 8 + e] = b16; else atomicAdd(dpos + 16 * 128 + sub * 8 + e, b16); }
     }
     for (int q = 0; q < 4; ++q) {               // q<3: dW[:, q], q==3: db
         __syncthreads();
@@ -157,15 +161,24 @@ __global__ __launch_bounds__(256) void k_embed_bwd(const T* __restrict__ g, cons
             float s = 0.f;
 #pragma unroll
             for (int k = 0; k < 16; ++k) s += sRed[k][threadIdx.x];
-            if (q < 3) atomicAdd(dW + threadIdx.x * 3 + q, s); else atomicAdd(db + threadIdx.x, s);
+            if (prow != nullptr) { if (q < 3) prow[2176 + threadIdx.x * 3 + q] = s; else prow[2560 + threadIdx.x] = s; }
+            else if (q < 3) atomicAdd(dW + threadIdx.x * 3 + q, s); else atomicAdd(db + threadIdx.x, s);
         }
     }
 }
 
 // Limb-refusion backward: thread = one of the 51 (group, channel) MLPs, register accumulation over frames.
 __global__ __launch_bounds__(64) void k_refusion_bwd(const float* __restrict__ x, const float* __restrict__ dlimb3, const float* __restrict__ P,
-                                                     float* __restrict__ Gr, const KasfProOff* __restrict__ offp, int64_t frames) {
+                                                     float* __restrict__ Gr, const KasfProOff* __restrict__ offp, int64_t frames,
+                                                     float* __restrict__ rows, int64_t base, int row_len) {
     const int t = threadIdx.x;
+    // rows != nullptr: row blockIdx.x of `rows` mirrors the gradient range [base, base + row_len) of the 204 limb-MLP tensors (alignment gaps zeroed);
+    // k_col_finish adds the rows in a fixed order.  Otherwise fp32 atomics into the gradients.
+    float* prow = rows != nullptr ? rows + (int64_t)blockIdx.x * row_len - base : nullptr;
+    if (rows != nullptr) {
+        for (int k = t; k < row_len; k += 64) rows[(int64_t)blockIdx.x * row_len + k] = 0.f;
+        __syncthreads();
+    }
     if (t >= 51) return;
     const int i = t / 3, ch = t % 3, n = c_limb_n[i];
     int64_t o[4];
@@ -196,6 +209,18 @@ __global__ __launch_bounds__(64) void k_refusion_bwd(const float* __restrict__ x
 #pragma unroll
             for (int k = 0; k < 4; ++k) dw1[h][k] += dz * in[k];
         }
+    }
+    if (prow != nullptr) {
+        prow[o[3]] = db2;
+#pragma unroll
+        for (int h = 0; h < 16; ++h) {
+            prow[o[1] + h] = db1[h];
+            prow[o[2] + h] = dw2[h];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < n) prow[o[0] + h * n + k] = dw1[h][k];
+        }
+        return;
     }
     atomicAdd(Gr + o[3], db2);
 #pragma unroll
@@ -265,10 +290,8 @@ __global__ __launch_bounds__(256) void k_gate_bwd(const T* __restrict__ g, const
                                                   float* __restrict__ dW, float* __restrict__ db, float* __restrict__ part, int64_t M, int adaptive) {
     __shared__ float sRed[16][384];
     __shared__ float sW[3][384];
-    __shared__ float sDb[3];
     const int sub = threadIdx.x & 15, rl = threadIdx.x >> 4;
     for (int c = threadIdx.x; c < 3 * 384; c += 256) sW[c / 384][c % 384] = W[c];
-    if (threadIdx.x < 3) sDb[threadIdx.x] = 0.f;
     __syncthreads();
     float dw[3][3][8], dbl[3] = {0.f, 0.f, 0.f};
 #pragma unroll
@@ -341,35 +364,15 @@ __global__ __launch_bounds__(256) void k_gate_bwd(const T* __restrict__ g, const
             else atomicAdd(dW + j * 384 + c, s);
         }
     }
-    if (sub == 0) { atomicAdd(&sDb[0], dbl[0]); atomicAdd(&sDb[1], dbl[1]); atomicAdd(&sDb[2], dbl[2]); }
+    __syncthreads();
+    if (sub == 0) { sRed[rl][0] = dbl[0]; sRed[rl][1] = dbl[1]; sRed[rl][2] = dbl[2]; }      // the 16 groups' shares, added in a fixed order
     __syncthreads();
     if (threadIdx.x < 3) {
-        if (prow != nullptr) prow[1152 + threadIdx.x] = sDb[threadIdx.x];
-        else atomicAdd(db + threadIdx.x, sDb[threadIdx.x]);
-    }
-}
-
-// dW[1152] / db[3] += column sums of part[nb][GATE_PART_LD].  A workgroup owns 16 columns; its 16 row groups each sum every 16th partial
-// row with 8 independent loads in flight, then meet in LDS (fixed order => bitwise reproducible).
-__global__ __launch_bounds__(256) void k_gate_reduce(const float* __restrict__ part, float* __restrict__ dW, float* __restrict__ db, int nb) {
-    const int cl = threadIdx.x & 15, q = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
-    __shared__ float sP[16][17];
-    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (c < 1155) {
-        int k = q;
-        for (; k + 7 * 16 < nb; k += 8 * 16) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) s[u] += part[(int64_t)(k + 16 * u) * GATE_PART_LD + c];
-        }
-        for (; k < nb; k += 16) s[0] += part[(int64_t)k * GATE_PART_LD + c];
-    }
-    sP[q][cl] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
-    __syncthreads();
-    if (q == 0 && c < 1155) {
         float t = 0.f;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) t += sP[k][cl];
-        if (c < 1152) dW[c] += t; else db[c - 1152] += t;
+        for (int k = 0; k < 16; ++k) t += sRed[k][threadIdx.x];
+        if (prow != nullptr) prow[1152 + threadIdx.x] = t;
+        else atomicAdd(db + threadIdx.x, t);
     }
 }
 
@@ -403,9 +406,11 @@ __global__ __launch_bounds__(256) void k_head_fwd(const T* __restrict__ rep, con
     }
 }
 
+constexpr int HEAD_ROW = 3 * 512 + 4;
 template <typename T>
 __global__ __launch_bounds__(256) void k_head_bwd(const float* __restrict__ dy, const T* __restrict__ rep, const float* __restrict__ W, T* __restrict__ dpre,
-                                                  float* __restrict__ dW, float* __restrict__ db, int64_t M) {
+                                                  float* __restrict__ dW, float* __restrict__ db, int64_t M, float* __restrict__ rows) {
+    float* prow = rows != nullptr ? rows + (int64_t)blockIdx.x * HEAD_ROW : nullptr;      // dW[3][512] | db[3] of this workgroup (fixed-order finish)
     __shared__ float sRed[16][512];
     const int sub = threadIdx.x & 15, rl = threadIdx.x >> 4;
     float w[3][32], dw[3][32], dbl[3] = {0.f, 0.f, 0.f};
@@ -443,10 +448,18 @@ __global__ __launch_bounds__(256) void k_head_bwd(const float* __restrict__ dy, 
             float s = 0.f;
 #pragma unroll
             for (int k = 0; k < 16; ++k) s += sRed[k][c];
-            atomicAdd(dW + j * 512 + c, s);
+            if (prow != nullptr) prow[j * 512 + c] = s; else atomicAdd(dW + j * 512 + c, s);
         }
     }
-    if (sub == 0) { atomicAdd(db, dbl[0]); atomicAdd(db + 1, dbl[1]); atomicAdd(db + 2, dbl[2]); }
+    __syncthreads();
+    if (sub == 0) { sRed[rl][0] = dbl[0]; sRed[rl][1] = dbl[1]; sRed[rl][2] = dbl[2]; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sRed[k][threadIdx.x];
+        if (prow != nullptr) prow[1536 + threadIdx.x] = t; else atomicAdd(db + threadIdx.x, t);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -513,22 +526,31 @@ __device__ __forceinline__ float norm3(float a, float b, float c) { return sqrtf
 
 __global__ __launch_bounds__(256) void k_loss3(const float* __restrict__ P, const float* __restrict__ Y, float* __restrict__ dP, float* __restrict__ losses,
                                                int B, int T, float lam_n, float lam_v, float gscale) {
+    // Bit-reproducible: every sum below is formed in an order that does not depend on scheduling (a thread's own loop, a fixed tree over waves); the
+    // per-clip loss terms go to losses[4 + 4 b ..] and k_loss3_finish adds the clips in a fixed order (no atomics anywhere: dP feeds the whole backward).
     extern __shared__ float sm[];
     float* sS = sm;            // [T] scale
     float* sDen = sS + T;      // [T]
     float* sWt = sDen + T;     // [T] sum_j u_j . p_j
-    __shared__ float sL[3];
+    __shared__ float sL[4][3];
     const int b = blockIdx.x;
     const float* p = P + (int64_t)b * T * 51;
     const float* y = Y + (int64_t)b * T * 51;
     float* dp = dP + (int64_t)b * T * 51;
-    if (threadIdx.x < 3) sL[threadIdx.x] = 0.f;
     for (int t = threadIdx.x; t < T; t += 256) {
         float den = 0.f, num = 0.f;
         for (int k = 0; k < 51; ++k) { den += p[t * 51 + k] * p[t * 51 + k]; num += y[t * 51 + k] * p[t * 51 + k]; }
         sDen[t] = den;
-        sS[t] = num / den;
-        sWt[t] = 0.f;
+        const float s = num / den;
+        sS[t] = s;
+        float wt = 0.f;                                  // sum over the frame's joints of u_j . p_j, u_j = e_j / |e_j|, e_j = s p_j - y_j
+        for (int j = 0; j < KASF_J; ++j) {
+            const int it = t * KASF_J + j;
+            const float e0 = s * p[it * 3] - y[it * 3], e1 = s * p[it * 3 + 1] - y[it * 3 + 1], e2 = s * p[it * 3 + 2] - y[it * 3 + 2];
+            const float n = norm3(e0, e1, e2);
+            if (n > 0.f) wt += (e0 * p[it * 3] + e1 * p[it * 3 + 1] + e2 * p[it * 3 + 2]) / n;
+        }
+        sWt[t] = wt;
     }
     __syncthreads();
     const float n1 = (float)B * T * KASF_J, n3 = (float)B * (T - 1) * KASF_J;
@@ -537,11 +559,8 @@ __global__ __launch_bounds__(256) void k_loss3(const float* __restrict__ P, cons
         const int t = it / KASF_J;
         const float s = sS[t];
         const float e0 = s * p[it * 3] - y[it * 3], e1 = s * p[it * 3 + 1] - y[it * 3 + 1], e2 = s * p[it * 3 + 2] - y[it * 3 + 2];
-        const float n = norm3(e0, e1, e2);
-        l2 += n;
-        if (n > 0.f) atomicAdd(&sWt[t], (e0 * p[it * 3] + e1 * p[it * 3 + 1] + e2 * p[it * 3 + 2]) / n);
+        l2 += norm3(e0, e1, e2);
     }
-    __syncthreads();
     for (int it = threadIdx.x; it < T * KASF_J; it += 256) {
         const int t = it / KASF_J;
         float gr[3] = {0.f, 0.f, 0.f};
@@ -578,12 +597,31 @@ __global__ __launch_bounds__(256) void k_loss3(const float* __restrict__ P, cons
         dp[it * 3] = gr[0] * gscale; dp[it * 3 + 1] = gr[1] * gscale; dp[it * 3 + 2] = gr[2] * gscale;
     }
     l1 = reduce64(l1); l2 = reduce64(l2); l3 = reduce64(l3);
-    if ((threadIdx.x & 63) == 0) { atomicAdd(&sL[0], l1); atomicAdd(&sL[1], l2); atomicAdd(&sL[2], l3); }
+    if ((threadIdx.x & 63) == 0) { sL[threadIdx.x >> 6][0] = l1; sL[threadIdx.x >> 6][1] = l2; sL[threadIdx.x >> 6][2] = l3; }
     __syncthreads();
+    if (threadIdx.x < 3) losses[4 + 4 * b + threadIdx.x] = (sL[0][threadIdx.x] + sL[1][threadIdx.x]) + (sL[2][threadIdx.x] + sL[3][threadIdx.x]);
+}
+// losses[0..3] = {total, mpjpe, n_mpjpe, velocity} from the per-clip sums at losses[4 + 4 b + {0, 1, 2}]: one workgroup, fixed order
+__global__ __launch_bounds__(256) void k_loss3_finish(float* __restrict__ losses, int B, int T, float lam_n, float lam_v) {
+    __shared__ float sP[256][3];
+    float a[3] = {0.f, 0.f, 0.f};
+    for (int b = threadIdx.x; b < B; b += 256)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) a[k] += losses[4 + 4 * b + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) sP[threadIdx.x][k] = a[k];
+    __syncthreads();
+    for (int h = 128; h >= 1; h >>= 1) {
+        if (threadIdx.x < h)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) sP[threadIdx.x][k] += sP[threadIdx.x + h][k];
+        __syncthreads();
+    }
     if (threadIdx.x == 0) {
-        const float a = sL[0] / n1, bq = sL[1] / n1, c = T > 1 ? sL[2] / n3 : 0.f;
-        atomicAdd(losses + 1, a); atomicAdd(losses + 2, bq); atomicAdd(losses + 3, c);
-        atomicAdd(losses, a + lam_n * bq + lam_v * c);
+        const float n1 = (float)B * T * KASF_J, n3 = (float)B * (T - 1) * KASF_J;
+        const float m1 = sP[0][0] / n1, m2 = sP[0][1] / n1, m3 = T > 1 ? sP[0][2] / n3 : 0.f;
+        losses[0] = m1 + lam_n * m2 + lam_v * m3;
+        losses[1] = m1; losses[2] = m2; losses[3] = m3;
     }
 }
 
@@ -617,15 +655,23 @@ void kasf_launch_prologue_fwd(int dt, hipStream_t s, const float* x, const float
     else hipLaunchKernelGGL(k_prologue_fwd<bf16>, dim3(grid), dim3(256), 0, s, x, params, off, (bf16*)xj, (bf16*)xb, (bf16*)xl, bone3, limb3, frames);
 }
 void kasf_launch_embed_bwd(int dt, hipStream_t s, const void* g, const float* in3, const float* W, float* dW, float* db, float* dpos, float* din3,
-                           int64_t frames) {
+                           int64_t frames, KasfColSink* sink) {
     const unsigned grid = (unsigned)(frames < 128 ? frames : 128);
-    if (dt == KASF_F32) hipLaunchKernelGGL(k_embed_bwd<float>, dim3(grid), dim3(256), 0, s, (const float*)g, in3, W, dW, db, dpos, din3, frames);
-    else hipLaunchKernelGGL(k_embed_bwd<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)g, in3, W, dW, db, dpos, din3, frames);
+    float* rows = sink != nullptr ? sink->take((int)grid, EMBED_ROW) : nullptr;
+    if (dt == KASF_F32) hipLaunchKernelGGL(k_embed_bwd<float>, dim3(grid), dim3(256), 0, s, (const float*)g, in3, W, dW, db, dpos, din3, frames, rows);
+    else hipLaunchKernelGGL(k_embed_bwd<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)g, in3, W, dW, db, dpos, din3, frames, rows);
+    if (rows != nullptr) {
+        sink->add(rows, EMBED_ROW, (int)grid, 17 * 128, dpos);
+        sink->add(rows + 2176, EMBED_ROW, (int)grid, 384, dW);
+        sink->add(rows + 2560, EMBED_ROW, (int)grid, 128, db);
+    }
 }
 void kasf_launch_refusion_bwd(hipStream_t s, const float* x, const float* dlimb3, const float* params, float* grads, const KasfProOff* off,
-                              int64_t frames) {
+                              int64_t frames, KasfColSink* sink, int64_t grad_base, int grad_len) {
     const unsigned grid = (unsigned)(frames < 256 ? frames : 256);
-    hipLaunchKernelGGL(k_refusion_bwd, dim3(grid), dim3(64), 0, s, x, dlimb3, params, grads, off, frames);
+    float* rows = (sink != nullptr && grad_len > 0) ? sink->take((int)grid, grad_len) : nullptr;
+    hipLaunchKernelGGL(k_refusion_bwd, dim3(grid), dim3(64), 0, s, x, dlimb3, params, grads, off, frames, rows, grad_base, grad_len);
+    if (rows != nullptr) sink->add(rows, grad_len, (int)grid, grad_len, grads + grad_base);
 }
 void kasf_launch_gate_fwd(int dt, hipStream_t s, const void* xa, const void* xg, const void* xb, const float* W, const float* b, void* out,
                           float* alpha, int64_t M, int adaptive) {
@@ -634,13 +680,13 @@ void kasf_launch_gate_fwd(int dt, hipStream_t s, const void* xa, const void* xg,
     else hipLaunchKernelGGL(k_gate_fwd<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)xa, (const bf16*)xg, (const bf16*)xb, W, b, (bf16*)out, alpha, M, adaptive);
 }
 void kasf_launch_gate_bwd(int dt, hipStream_t s, const void* g, const void* g1, const void* g2, const void* xa, const void* xg, const void* xb,
-                          const float* W, const float* alpha, void* ga, void* gg, void* gb, float* dW, float* db, int64_t M, int adaptive, float* part,
-                          int64_t part_floats) {
+                          const float* W, const float* alpha, void* ga, void* gg, void* gb, float* dW, float* db, int64_t M, int adaptive, KasfColSink* sink) {
     unsigned grid = ew_grid(M * 16, 1024);              // 4 workgroups per CU: enough loads in flight for an HBM stream of 7-9 tensors
-    if (part == nullptr || (int64_t)grid * GATE_PART_LD > part_floats) { part = nullptr; if (grid > 256) grid = 256; }   // atomics: few workgroups
+    float* part = (sink != nullptr && adaptive) ? sink->take((int)grid, GATE_PART_LD) : nullptr;      // one row of dW[3][384] | db[3] per workgroup
+    if (part == nullptr && grid > 256) grid = 256;      // atomics: few workgroups
     if (dt == KASF_F32) hipLaunchKernelGGL(k_gate_bwd<float>, dim3(grid), dim3(256), 0, s, (const float*)g, (const float*)g1, (const float*)g2, (const float*)xa, (const float*)xg, (const float*)xb, W, alpha, (float*)ga, (float*)gg, (float*)gb, dW, db, part, M, adaptive);
     else hipLaunchKernelGGL(k_gate_bwd<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)g, (const bf16*)g1, (const bf16*)g2, (const bf16*)xa, (const bf16*)xg, (const bf16*)xb, W, alpha, (bf16*)ga, (bf16*)gg, (bf16*)gb, dW, db, part, M, adaptive);
-    if (part != nullptr && adaptive) hipLaunchKernelGGL(k_gate_reduce, dim3(73), dim3(256), 0, s, part, dW, db, (int)grid);
+    if (part != nullptr) { sink->add(part, GATE_PART_LD, (int)grid, 1152, dW); sink->add(part + 1152, GATE_PART_LD, (int)grid, 3, db); }
 }
 void kasf_launch_head_fwd(int dt, hipStream_t s, const void* rep, const float* W, const float* b, float* out, int64_t M) {
     const unsigned grid = ew_grid(M * 16);
@@ -665,10 +711,13 @@ void kasf_launch_rep_bwd(int dt, hipStream_t s, const float* drep, const void* r
     if (dt == KASF_F32) hipLaunchKernelGGL(k_rep_bwd<float>, dim3(grid), dim3(256), 0, s, drep, (const float*)rep, (float*)dpre, n8);
     else hipLaunchKernelGGL(k_rep_bwd<bf16>, dim3(grid), dim3(256), 0, s, drep, (const bf16*)rep, (bf16*)dpre, n8);
 }
-void kasf_launch_head_bwd(int dt, hipStream_t s, const float* dy, const void* rep, const float* W, void* dpre, float* dW, float* db, int64_t M) {
+void kasf_launch_head_bwd(int dt, hipStream_t s, const float* dy, const void* rep, const float* W, void* dpre, float* dW, float* db, int64_t M,
+                          KasfColSink* sink) {
     const unsigned grid = ew_grid(M * 16, 256);
-    if (dt == KASF_F32) hipLaunchKernelGGL(k_head_bwd<float>, dim3(grid), dim3(256), 0, s, dy, (const float*)rep, W, (float*)dpre, dW, db, M);
-    else hipLaunchKernelGGL(k_head_bwd<bf16>, dim3(grid), dim3(256), 0, s, dy, (const bf16*)rep, W, (bf16*)dpre, dW, db, M);
+    float* rows = sink != nullptr ? sink->take((int)grid, HEAD_ROW) : nullptr;
+    if (dt == KASF_F32) hipLaunchKernelGGL(k_head_bwd<float>, dim3(grid), dim3(256), 0, s, dy, (const float*)rep, W, (float*)dpre, dW, db, M, rows);
+    else hipLaunchKernelGGL(k_head_bwd<bf16>, dim3(grid), dim3(256), 0, s, dy, (const bf16*)rep, W, (bf16*)dpre, dW, db, M, rows);
+    if (rows != nullptr) { sink->add(rows, HEAD_ROW, (int)grid, 1536, dW); sink->add(rows + 1536, HEAD_ROW, (int)grid, 3, db); }
 }
 void kasf_launch_cast_to_f32(int dt, hipStream_t s, const void* src, float* dst, int64_t n) {
     if (dt == KASF_F32) hipLaunchKernelGGL(k_cast_to_f32<float>, dim3(ew_grid(n)), dim3(256), 0, s, (const float*)src, dst, n);
@@ -691,8 +740,8 @@ void kasf_launch_finalize_ls(hipStream_t s, float* dW, const float* W, const flo
 }
 void kasf_launch_loss3(hipStream_t s, const float* pred, const float* tgt, float* dpred, float* losses, int B, int T, float lambda_n, float lambda_v,
                        float grad_scale) {
-    (void)hipMemsetAsync(losses, 0, 4 * sizeof(float), s);
     hipLaunchKernelGGL(k_loss3, dim3(B), dim3(256), 3 * T * sizeof(float), s, pred, tgt, dpred, losses, B, T, lambda_n, lambda_v, grad_scale);
+    hipLaunchKernelGGL(k_loss3_finish, dim3(1), dim3(256), 0, s, losses, B, T, lambda_n, lambda_v);
 }
 void kasf_launch_adamw(hipStream_t s, float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float wd,
                        float bc1, float bc2, float grad_scale) {

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(NTHR) void k_mlp_bwd(const T* __restrict__ X, const
                                                  const float* __restrict__ ln_b, const T* __restrict__ W1, const float* __restrict__ b1,
                                                  const T* __restrict__ W2ts, const T* __restrict__ W1t, T* __restrict__ Hbuf,
                                                  T* __restrict__ dZbuf, T* __restrict__ xn_buf, T* __restrict__ g_in,
-                                                 float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t M) {
+                                                 float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t M, float* __restrict__ part) {
     constexpr int MT = BM / (NTHR / 128) / 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* sA = reinterpret_cast<T*>(smem);        // LN(x)        [BM][128]
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(NTHR) void k_mlp_bwd(const T* __restrict__ X, const
     __syncthreads();
     acc_to_tile<T>(sD, accA, wn0, wm0, [](float v, int) { return v; });
     __syncthreads();
-    lnbwd_rows<T, BM, NTHR>(sD, X, ln_g, (const T*)nullptr, G, g_in, 0, dgamma, dbeta, row0, M, reinterpret_cast<float*>(sW));
+    lnbwd_rows<T, BM, NTHR>(sD, X, ln_g, (const T*)nullptr, G, g_in, 0, dgamma, dbeta, row0, M, reinterpret_cast<float*>(sW), (T*)nullptr, nullptr, part);
 }
 
 template <typename T> struct MlpCfg;
@@ -201,24 +201,30 @@ void mlp_fwd_T(hipStream_t s, const void* x, const float* ln_g, const float* ln_
 }
 template <typename T>
 void mlp_bwd_T(hipStream_t s, const void* x, const void* g, const float* ln_g, const float* ln_b, const void* W1, const float* b1, const void* W2ts,
-               const void* W1t, void* Hbuf, void* dZbuf, void* xn_buf, void* g_in, float* dgamma, float* dbeta, int64_t M) {
+               const void* W1t, void* Hbuf, void* dZbuf, void* xn_buf, void* g_in, float* dgamma, float* dbeta, int64_t M, KasfColSink* sink) {
     constexpr int BM = MlpCfg<T>::BM_B, NBUF = MlpCfg<T>::NBUF, NTHR = MlpCfg<T>::NTHR;
     const size_t sh = (size_t)(4 * BM * 128 + NBUF * 128 * 128) * sizeof(T);
     set_smem(k_mlp_bwd<T, BM, NBUF, NTHR>, sh);
-    hipLaunchKernelGGL((k_mlp_bwd<T, BM, NBUF, NTHR>), dim3((unsigned)((M + BM - 1) / BM)), dim3(NTHR), sh, s, (const T*)x, (const T*)g, ln_g, ln_b,
-                       (const T*)W1, b1, (const T*)W2ts, (const T*)W1t, (T*)Hbuf, (T*)dZbuf, (T*)xn_buf, (T*)g_in, dgamma, dbeta, M);
+    const int grid = (int)((M + BM - 1) / BM);
+    float* part = sink != nullptr ? sink->take(grid, 256) : nullptr;          // one [dgamma | dbeta] row per workgroup
+    hipLaunchKernelGGL((k_mlp_bwd<T, BM, NBUF, NTHR>), dim3((unsigned)grid), dim3(NTHR), sh, s, (const T*)x, (const T*)g, ln_g, ln_b,
+                       (const T*)W1, b1, (const T*)W2ts, (const T*)W1t, (T*)Hbuf, (T*)dZbuf, (T*)xn_buf, (T*)g_in, dgamma, dbeta, M, part);
+    if (part != nullptr) { sink->add(part, 256, grid, 128, dgamma); sink->add(part + 128, 256, grid, 128, dbeta); }
 }
 
 }  // namespace
 
 void kasf_launch_mlp_fwd(int dt, hipStream_t s, const void* x, const float* ln_g, const float* ln_b, const void* W1, const float* b1, const void* W2,
                          const float* b2, const float* ls2, void* out, int64_t M, void* xn_out) {
-    if (dt == KASF_F32) mlp_fwd_T<float>(s, x, ln_g, ln_b, W1, b1, W2, b2, ls2, out, M);
-    else kasf_launch_mlp_fwd_r(s, x, ln_g, ln_b, W1, b1, W2, b2, ls2, out, M, xn_out);      // first generation: mlp_fwd_T<bf16>
+    if (M <= 0) return;
+    if (dt == KASF_F32) { mlp_fwd_T<float>(s, x, ln_g, ln_b, W1, b1, W2, b2, ls2, out, M); return; }
+    const int64_t tiles = (M + 31) / 32;                 // bf16: persistent producer / consumer kernel (k_mlp3.hip), one workgroup per CU
+    kasf_launch_mlp_fwd_s(s, x, ln_g, ln_b, W1, b1, W2, b2, ls2, out, M, xn_out, (unsigned)(tiles < 256 ? tiles : 256));
 }
 void kasf_launch_mlp_bwd(int dt, hipStream_t s, const void* x, const void* g, const float* ln_g, const float* ln_b, const void* W1, const float* b1,
                          const void* W2ts, const void* W1t, void* Hbuf, void* dZbuf, void* xn_buf, void* g_in, float* dgamma, float* dbeta,
-                         int64_t M) {
-    if (dt == KASF_F32) mlp_bwd_T<float>(s, x, g, ln_g, ln_b, W1, b1, W2ts, W1t, Hbuf, dZbuf, xn_buf, g_in, dgamma, dbeta, M);
-    else mlp_bwd_T<bf16>(s, x, g, ln_g, ln_b, W1, b1, W2ts, W1t, Hbuf, dZbuf, xn_buf, g_in, dgamma, dbeta, M);
+                         int64_t M, KasfColSink* sink) {
+    if (M <= 0) return;
+    if (dt == KASF_F32) mlp_bwd_T<float>(s, x, g, ln_g, ln_b, W1, b1, W2ts, W1t, Hbuf, dZbuf, xn_buf, g_in, dgamma, dbeta, M, sink);
+    else mlp_bwd_T<bf16>(s, x, g, ln_g, ln_b, W1, b1, W2ts, W1t, Hbuf, dZbuf, xn_buf, g_in, dgamma, dbeta, M, sink);
 }

@@ -1,6 +1,6 @@
 // MLP forward, third generation (bf16): the waves of a workgroup are SPECIALISED.
 //
-// k_mlp_fwd_r (k_mlp2.hip) gives every wave the same program: GEMM1 (32 MFMAs), GELU (~370 vector instructions), barrier, GEMM2 (32 MFMAs),
+// The second generation gave every wave the same program: GEMM1 (32 MFMAs), GELU (~370 vector instructions), barrier, GEMM2 (32 MFMAs),
 // epilogue.  The two waves that share a SIMD belong to the same workgroup and move in lockstep between the barriers, so the matrix pipe idles
 // during GELU and the vector ALU idles during the GEMMs: measured 18.6 % MFMA busy, 42 % VALU busy, and a tile time equal to the SUM of the
 // phases plus the stalls (SQ counters in profiles/r1_mlp_sq_counters.json).  Software-pipelining the symmetric program did not help.
@@ -272,8 +272,15 @@ __global__ __launch_bounds__(S_THR) void k_mlp_fwd_s(const bf16* __restrict__ X,
 
 
 // ---------------------------------------------------------------------------------------------------------------
-// Fused MLP backward with specialised waves: the same hidden-quarter ownership, grid mapping, inputs and outputs as k_mlp_bwd_q
-// (k_mlp2.hip, where the algorithm is described), but waves 0-3 (one per SIMD) are producers and waves 4-7 consumers:
+// Fused MLP backward (bf16): hidden-quarter ownership with register-resident weights and specialised waves.
+// A workgroup owns ONE QUARTER of the hidden units (128 of 512) and a long range of tokens: its slices of W1, (ls2.W2)^T and W1^T live in VGPRs for
+// the whole kernel; per 32-token tile  Z_q = W1_q LN(x)^T,  dH_q = (ls2.W2)_q^T g^T,  H_q = GELU(Z_q),  dZ_q = dH_q GELU'(Z_q)  go registers -> LDS
+// (bf16) once;  dA_q = W1_q^T dZ_q is stored as a bf16 partial (summed over the four quarters by k_lnbwd_sum4_fin, which also does the LayerNorm
+// backward + residual); the weight gradients  dW1_q += dZ_q^T LN(x)  and  dW2_q += g^T H_q  accumulate in registers over the whole token range from
+// transposed LDS fragments (ds_read_b64_tr_b16) and leave the kernel once as per-range partial tiles.  The 512-wide H / dZ never reach HBM.
+// XCD-aware mapping: workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), so the four hidden quarters of one token range sit at
+// blockIdx b, b+8, b+16, b+24: same XCD, same L2 -> LN(x) and g cross the fabric once, not four times.
+// Waves 0-3 (one per SIMD) are producers and waves 4-7 consumers:
 //     iteration t:   producers  Z_q(t), dH_q(t), GELU / GELU' -> sH[t & 1], sD[t & 1]                       (wave p: hidden units [32p, 32p + 32) of the quarter)
 //                    consumers  loads of tile t+2;  dA_q(t-1) = W1_q^T dZ_q  (wave c: channels [32c, 32c + 32)),
 //                               dW1_q += dZ_q^T LN(x),  dW2_q += g^T H_q  of tile t-1  (wave c: a 64 x 64 block of each 128 x 128 quarter)
@@ -282,69 +289,18 @@ __global__ __launch_bounds__(S_THR) void k_mlp_fwd_s(const bf16* __restrict__ X,
 // wave.  LDS: LN(x) and g rings 5 x (8 + 8) KB (tile t-1 still feeds the weight gradients while t is in use and t+1 .. t+3 land), H / dZ
 // double-buffered 2 x (8 + 8) KB.
 // ---------------------------------------------------------------------------------------------------------------
-//
-// XCHG = true (the default path): the four quarter partials of dA are no longer summed by a second kernel (k_lnbwd_sum4 re-read 4 x 256 B
-// per token that this kernel had just written, plus x and g: 38 of the chain's 157 us and 240 of its 464 MB).  The PRODUCER waves -- which
-// idle a third of every tile at the barrier and have 70 registers to spare -- also act as reducers: workgroup q of a token range owns the
-// tiles u = q (mod 4) of that range, and once all sixteen consumer waves of the range's four workgroups have published their channel slabs of
-// tile u, producer wave p adds the four partials of rows [8p, 8p + 8), applies the LayerNorm backward + residual and writes g_in (two passes
-// of four rows, one per iteration, loads issued at the top of the iteration and consumed at its end).  Hand-off between workgroups follows
-// the placement-independent recipe of the CDNA4 guide (write-through `sc1` payload stores, completion by the consumer's own counted vmcnt
-// wait, `sc1` flag word = launch epoch | tiles published, `sc1` polls and payload loads): the four workgroups of a range share an XCD only
-// by observed dispatch order, which must not be a correctness assumption.  Nothing ever blocks inside the tile loop (a poll that is not
-// satisfied is simply repeated next iteration); after its last tile a producer waits for the slabs of its remaining tiles with a BOUNDED
-// spin and poisons the rows it could not finish (NaN) instead of hanging.
 // ---------------------------------------------------------------------------------------------------------------
-struct MlpXchg {
-    const bf16* X;            // raw block input (LayerNorm statistics are recomputed from it)
-    const float* gamma;
-    bf16* g_in;               // out: g + LNbwd(sum of the four partials)
-    float *dgamma, *dbeta, *gsum;
-    unsigned* flags;          // [ranges][4 quarters][4 consumer waves]: tiles whose channel slab is complete in memory; zero before the launch
-    unsigned* err;            // set to 1 if a bounded wait ran out
-};
-
-typedef __attribute__((address_space(1))) unsigned gu32;
-typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-// Hand-off payload moves as 16-byte `sc1` accesses through a buffer descriptor (uniform base in SGPRs, 32-bit per-lane byte offset): write-through
-// stores leave the XCD's L2 for memory, `sc1` loads bypass this CU's L1.  Narrower sc1 stores cost one fabric write EACH (8-byte ones 2.7x the time
-// per byte: the first version of this hand-off, with the accumulators' natural 8-byte stores, made the kernel 40 us slower).
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t xchg_rsrc(const void* uniform_base, unsigned bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(uniform_base), 0, (int)bytes, 0x00020000);
-}
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
-    const bf16x2 t = {(bf16)a, (bf16)b};
-    return __builtin_bit_cast(unsigned, t);
-}
-__device__ __forceinline__ void add8(float (&d)[8], const u32x4 bits) {
-    const bf16x8 t = __builtin_bit_cast(bf16x8, bits);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) d[e] += (float)t[e];
-}
-__device__ __forceinline__ void store_sc1_b32_s(const void* ubase, unsigned off, unsigned v) {      // flag word: base in SGPRs (no 64-bit VGPR address)
-    asm volatile("global_store_dword %0, %1, %2 sc1" ::"v"(off), "v"(v), "s"(ubase) : "memory");
-}
-constexpr unsigned XCHG_SPIN_LIMIT = 400000;
-constexpr int XAUX = 16;         // aux bit 4 = sc1
-#ifdef KASF_BWD_STORE16         // measurement switch: two 16-byte stores per tile for the dA partials of the two-kernel chain as well (measured: no
-constexpr bool W16 = true;      // difference, 160-163 vs 158-166 us; and the extra registers cost a spilled prologue iteration), default: the accumulators' 8-byte stores
-#else
-constexpr bool W16 = false;
-#endif     // x s_sleep 32 (~1 us): a lost workgroup costs 0.4 s and a NaN-poisoned gradient, not a hang
-
-template <bool XCHG>
 __global__ __launch_bounds__(S_THR) void k_mlp_bwd_s(const bf16* __restrict__ XN, const bf16* __restrict__ G, const bf16* __restrict__ W1,
                                                      const float* __restrict__ b1, const bf16* __restrict__ W2ts, const bf16* __restrict__ W1t,
                                                      bf16* __restrict__ dApart, float* __restrict__ dW1part, float* __restrict__ dW2part,
-                                                     float* __restrict__ db1, int64_t M, int tiles_per_range, const MlpXchg xa) {
+                                                     float* __restrict__ db1, float* __restrict__ db1_rows, int64_t M, int tiles_per_range) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* sA = reinterpret_cast<bf16*>(smem);            // [5][32][128] LN(x) ring
     bf16* sG = sA + 5 * TL;                              // [5][32][128] upstream gradient ring
     bf16* sH = sG + 5 * TL;                              // [2][32][128] H of this quarter
     bf16* sD = sH + 2 * TL;                              // [2][32][128] dZ of this quarter
     int q, range;
-    {   // the four hidden quarters of one token range sit on one XCD (see k_mlp_bwd_q)
+    {   // the four hidden quarters of one token range sit on one XCD
         const int used = gridDim.x >> 2, full = used & ~7, b = blockIdx.x;
         if (b < 4 * full) { q = (b >> 3) & 3; range = (b & 7) + 8 * (b >> 5); }
         else { q = (b - 4 * full) & 3; range = full + ((b - 4 * full) >> 2); }
@@ -370,95 +326,10 @@ __global__ __launch_bounds__(S_THR) void k_mlp_bwd_s(const bf16* __restrict__ XN
             bias4[nt] = *reinterpret_cast<const f32x4*>(b1 + q * 128 + h0 + 16 * nt + 4 * g);
             db1acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        // ---- reducer role (XCHG): 16 lanes per row, 4 rows per pass, rows [8w + 4 pass, +4) of this workgroup's tiles u = q (mod 4) ----
-        const int sub = lane & 15, rq = lane >> 4;
-        float gm[8], dgam[8], dbet[8], gsv[8];
-        u32x4 pl[4] = {};
-        bf16x8 xr = {}, gr = {};
-        int64_t next_u = q;
-        int pass = 0;
-        bool ready = false;
-        const gu32* rflags = (const gu32*)xa.flags + (int64_t)range * 16;
-        const __amdgpu_buffer_rsrc_t ex_rsrc = xchg_rsrc(uniform_ptr(dApart), (unsigned)(M * 1024));      // [4][M][128] bf16 (the launcher checks that this fits 32 bits)
-        if (XCHG) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { gm[e] = xa.gamma[sub * 8 + e]; dgam[e] = 0.f; dbet[e] = 0.f; gsv[e] = 0.f; }
-        }
-        auto red_row = [&](int64_t u, int ps) { return (tile0 + u) * S_BM + 8 * w + 4 * ps + rq; };
-        auto red_issue = [&](int64_t u, int ps) {       // sc1 (L1-bypassing) loads of the four partial slabs' bytes of this lane; x and g are kernel inputs: plain
-            const int64_t row = red_row(u, ps);
-            if (row < M) {
-#pragma unroll
-                for (int qq = 0; qq < 4; ++qq)
-                    pl[qq] = __builtin_amdgcn_raw_buffer_load_b128(ex_rsrc, (unsigned)((((int64_t)qq * M + row) * 128 + sub * 8) * 2), 0, XAUX);
-                xr = *reinterpret_cast<const bf16x8*>(xa.X + row * 128 + sub * 8);
-                gr = *reinterpret_cast<const bf16x8*>(G + row * 128 + sub * 8);
-            }
-        };
-        auto red_finish = [&](int64_t u, int ps, bool ok) {   // g_in = g + LNbwd(sum of partials; x, gamma); dgamma / dbeta / colsum(g) in registers
-            const int64_t row = red_row(u, ps);
-            if (row < M) {
-                float d[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, x[8], tg[8];
-#pragma unroll
-                for (int qq = 0; qq < 4; ++qq) add8(d, pl[qq]);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { x[e] = (float)xr[e]; tg[e] = (float)gr[e]; }
-                float sm = 0.f;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) sm += x[e];
-                const float mean = reduce16(sm) * (1.0f / 128.0f);
-                float qv = 0.f;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { x[e] -= mean; qv += x[e] * x[e]; }
-                const float rstd = rsqrtf(reduce16(qv) * (1.0f / 128.0f) + KASF_LN_EPS);
-                float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    x[e] *= rstd;
-                    dgam[e] += d[e] * x[e];
-                    dbet[e] += d[e];
-                    d[e] *= gm[e];
-                    s1 += d[e];
-                    s2 += d[e] * x[e];
-                }
-                s1 = reduce16(s1) * (1.0f / 128.0f);
-                s2 = reduce16(s2) * (1.0f / 128.0f);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { gsv[e] += tg[e]; tg[e] += rstd * (d[e] - s1 - x[e] * s2); }
-                if (!ok) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) tg[e] = __builtin_nanf("");      // a slab never arrived: make the failure visible downstream
-                }
-                store8(xa.g_in + row * 128 + sub * 8, tg);
-            }
-        };
-        auto red_poll = [&]() -> unsigned { return lane < 16 ? __hip_atomic_load(rflags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu; };
-        // Retire the weight / bias / gamma loads HERE, with a wait the compiler's own counter model sees: inside the loop it cannot tell that they
-        // completed iterations ago, and the wait it would otherwise put in front of their first use in the loop body -- vmcnt(1), counted along the
-        // path that issues only the flag poll -- also drains the six reducer loads issued a few instructions earlier (measured: +40 us per launch).
-        // (a plain s_waitcnt builtin is dropped by that pass as "not needed yet"; a USE of every loaded register is not)
-        if (XCHG) {
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) { asm volatile("" ::"v"(w1f[nt][ks])); asm volatile("" ::"v"(w2f[nt][ks])); }
-                asm volatile("" ::"v"(bias4[nt]));
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) asm volatile("" ::"v"(gm[e]));
-        }
         barrier_keep_async();                            // tile 0 has landed
         TSTART();
         int sp = 0;                                      // ring slot of tile t (t mod 5, rolling)
         for (int64_t t = 0; t <= ntiles; ++t, sp = sp == 4 ? 0 : sp + 1) {
-            bool issued = false;
-            unsigned fl = 0;
-            if (XCHG) {
-                issued = ready && next_u < ntiles;
-                if (issued) red_issue(next_u, pass);      // in flight during this tile's GEMMs and GELU
-                fl = red_poll();                          // decides at the END of this iteration what the next one may issue: never waited for here
-                __builtin_amdgcn_sched_barrier(0);
-            }
             if (t < ntiles) {
                 const bf16* cA = sA + sp * TL;
                 const bf16* cG = sG + sp * TL;
@@ -523,51 +394,8 @@ __global__ __launch_bounds__(S_THR) void k_mlp_bwd_s(const bf16* __restrict__ XN
                 act(1);
                 TMARK(17);
             }
-            if (XCHG) {
-                __builtin_amdgcn_sched_barrier(0);
-                if (issued) {
-                    red_finish(next_u, pass, true);
-                    if (pass == 1) next_u += 4;
-                    pass ^= 1;
-                }
-                ready = __all((int64_t)fl > next_u);     // all 16 slabs of tile next_u published (flag = tiles published)
-            }
             barrier_keep_async();
             TMARK(18);
-        }
-        if (XCHG) {
-            // ---- tail: the tiles of this workgroup that the other workgroups' consumers had not published when the loop ended ----
-            while (next_u < ntiles) {
-                bool ok = false;
-                for (unsigned spins = 0; spins < XCHG_SPIN_LIMIT; ++spins) {
-                    ok = __all((int64_t)red_poll() > next_u);
-                    if (ok) break;
-                    __builtin_amdgcn_s_sleep(32);
-                }
-                if (!ok && lane == 0) atomicExch(xa.err, 1u);
-                for (; pass < 2; ++pass) {
-                    red_issue(next_u, pass);
-                    red_finish(next_u, pass, ok);
-                }
-                pass = 0;
-                next_u += 4;
-            }
-            // ---- LayerNorm parameter gradients and colsum(g): lanes of equal `sub`, then the four producer waves through LDS (free by now) ----
-            float* sRed = reinterpret_cast<float*>(sH);  // [4 waves][3][128]
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float a = dgam[e], b = dbet[e], c = gsv[e];
-                a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
-                b += __shfl_xor(b, 16); b += __shfl_xor(b, 32);
-                c += __shfl_xor(c, 16); c += __shfl_xor(c, 32);
-                if (rq == 0) { sRed[(w * 3 + 0) * 128 + sub * 8 + e] = a; sRed[(w * 3 + 1) * 128 + sub * 8 + e] = b; sRed[(w * 3 + 2) * 128 + sub * 8 + e] = c; }
-            }
-            barrier_keep_async();                        // (the consumers join this one after their last stores)
-            for (int item = threadIdx.x; item < 3 * 128; item += 256) {
-                const int which = item >> 7, c = item & 127;
-                const float v = (sRed[(0 * 3 + which) * 128 + c] + sRed[(1 * 3 + which) * 128 + c]) + (sRed[(2 * 3 + which) * 128 + c] + sRed[(3 * 3 + which) * 128 + c]);
-                atomicAdd((which == 0 ? xa.dgamma : (which == 1 ? xa.dbeta : xa.gsum)) + c, v);
-            }
         }
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
@@ -578,7 +406,10 @@ __global__ __launch_bounds__(S_THR) void k_mlp_bwd_s(const bf16* __restrict__ XN
                 v += __shfl_xor(v, 2);
                 v += __shfl_xor(v, 4);
                 v += __shfl_xor(v, 8);
-                if (i == 0) atomicAdd(db1 + q * 128 + h0 + 16 * nt + 4 * g + r, v);
+                if (i == 0) {                            // one row of db1 per token range (added in a fixed order by k_col_finish), or an atomic without scratch
+                    if (db1_rows != nullptr) db1_rows[(int64_t)range * 512 + q * 128 + h0 + 16 * nt + 4 * g + r] = v;
+                    else atomicAdd(db1 + q * 128 + h0 + 16 * nt + 4 * g + r, v);
+                }
             }
     } else {
         // ------------------------------------------------ consumer: channels [32c, 32c + 32) of dA, a 64 x 64 block of each weight-gradient quarter ------------------------------------------------
@@ -688,55 +519,27 @@ __global__ __launch_bounds__(S_THR) void k_mlp_bwd_s(const bf16* __restrict__ XN
             // tile t+1 must have landed.  In issue order this wave has, youngest first: loads(t+3) 4, stores(t-2) 4, loads(t+2) 4, stores(t-3) 4, loads(t+1) ...
             // (every full tile stores exactly 4 times per wave; only the last tile of the last range can store less, and no wait follows it).  The first
             // iterations have fewer stores in the sequence, so they wait for all but the two youngest load groups instead.
-            // XCHG: TWO 16-byte slab stores + ONE flag store per iteration (the flag store is issued unconditionally so that the count never varies):
-            // loads(t+3) 4, flag 1, stores(t-2) 2, loads(t+2) 4, flag 1, stores(t-3) 2 = 14.
-            if (XCHG) { if (t >= 3) wait_async_le<14>(); else wait_async_le<8>(); }
-            else if (W16) { if (t >= 3) wait_async_le<12>(); else wait_async_le<8>(); }      // two 16-byte stores per tile instead of four 8-byte ones
-            else { if (t >= 3) wait_async_le<16>(); else wait_async_le<8>(); }
+            if (t >= 3) wait_async_le<16>(); else wait_async_le<8>();
             TMARK(27);
             if (t >= 1) {
                 const int64_t row0 = (tile0 + t - 1) * S_BM;
-                if (XCHG || W16) {   // slab stores, 16 bytes per lane (XCHG: write-through): lanes g and g ^ 1 (16 lanes apart) hold adjacent 4-channel groups of the same
-                              // token, so one v_permlane16_swap per dword hands the even-g lane both halves of feature tile 0 and the odd-g lane those of tile 1
-                    const __amdgpu_buffer_rsrc_t rs = xchg_rsrc(uniform_ptr(dApart + ((int64_t)q * M + row0) * 128), 32u * 256u);
-                    const int nvalid = (int)((M - row0) < S_BM ? (M - row0) : S_BM);
-                    const unsigned cho = (unsigned)(ch0 + ((g & 1) ? 16 + 4 * (g - 1) : 4 * g)) * 2u;
 #pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) {
-                        // (packed two by two: hipcc 7.2 miscompiles the bf16x4 -> 2 x u32 bit_cast in front of this builtin -- one swap, duplicated dwords)
-                        const auto s0 = __builtin_amdgcn_permlane16_swap(pack_bf16x2(accA[0][mt][0], accA[0][mt][1]), pack_bf16x2(accA[1][mt][0], accA[1][mt][1]), false, false);
-                        const auto s1 = __builtin_amdgcn_permlane16_swap(pack_bf16x2(accA[0][mt][2], accA[0][mt][3]), pack_bf16x2(accA[1][mt][2], accA[1][mt][3]), false, false);
-                        const u32x4 chunk = {s0[0], s1[0], s0[1], s1[1]};
-                        // (rows past M of the last tile: redirected into the tile's first row slot of the SAME lane pair is not possible -- skip them; the
-                        //  store count per iteration then differs only in the very last tile of the last range, after which no counted wait follows)
-                        if (mt * 16 + i < nvalid) __builtin_amdgcn_raw_buffer_store_b128(chunk, rs, (unsigned)(mt * 16 + i) * 256u + cho, 0, XCHG ? XAUX : 0);
-                    }
-                } else {
+                for (int mt = 0; mt < 2; ++mt) {
+                    const int64_t row = row0 + mt * 16 + i;
+                    if (row < M) {
 #pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) {
-                        const int64_t row = row0 + mt * 16 + i;
-                        if (row < M) {
-#pragma unroll
-                            for (int nt = 0; nt < 2; ++nt) {
-                                const float v[4] = {accA[nt][mt][0], accA[nt][mt][1], accA[nt][mt][2], accA[nt][mt][3]};
-                                store4(dApart + ((int64_t)q * M + row) * 128 + ch0 + 16 * nt + 4 * g, v);
-                            }
+                        for (int nt = 0; nt < 2; ++nt) {
+                            const float v[4] = {accA[nt][mt][0], accA[nt][mt][1], accA[nt][mt][2], accA[nt][mt][3]};
+                            store4(dApart + ((int64_t)q * M + row) * 128 + ch0 + 16 * nt + 4 * g, v);
                         }
                     }
                 }
-            }
-            if (XCHG) {
-                // Everything older than the 14 (8) youngest operations of this wave has completed: in particular the slab stores of tile t - 4 and
-                // of every tile before it.  Publish that count (write-through, one lane); the reducers never see a slab before its bytes are in memory.
-                const unsigned done = t >= 3 ? (unsigned)(t - 3) : 0u;
-                if (lane == 0) store_sc1_b32_s(uniform_ptr(xa.flags + (int64_t)range * 16 + q * 4 + c), 0u, done);
             }
             TMARK(28);
             barrier_keep_async();
             TMARK(29);
         }
-        wait_async();                                    // drain the look-ahead requests before the wave retires (and every slab store)
-        if (XCHG && lane == 0) store_sc1_b32_s(uniform_ptr(xa.flags + (int64_t)range * 16 + q * 4 + c), 0u, (unsigned)ntiles);
+        wait_async();                                    // drain the look-ahead requests before the wave retires
         float* p1 = dW1part + (int64_t)range * 512 * 128;        // [512][128]
         float* p2 = dW2part + (int64_t)range * 128 * 512;        // [128][512]
 #pragma unroll
@@ -749,7 +552,6 @@ __global__ __launch_bounds__(S_THR) void k_mlp_bwd_s(const bf16* __restrict__ XN
                     p1[(int64_t)(q * 128 + rr) * 128 + cc] = accW1[a][b][r];
                     p2[(int64_t)rr * 512 + q * 128 + cc] = accW2[a][b][r];
                 }
-        if (XCHG) barrier_keep_async();                  // pairs with the producers' barrier before their cross-wave reduction
     }
 }
 
@@ -772,19 +574,9 @@ extern "C" void kasf_debug_read_prof(long long* dst, int reset) {
 #endif
 
 void kasf_launch_mlp_bwd_s(hipStream_t s, const void* xn, const void* g, const void* W1, const float* b1, const void* W2ts, const void* W1t, void* dApart,
-                           float* p1, float* p2, float* db1, int64_t M, int tiles_per_range, int used) {
+                           float* p1, float* p2, float* db1, float* db1_rows, int64_t M, int tiles_per_range, int used) {
     const size_t sh = (size_t)(14 * TL) * sizeof(bf16);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_bwd_s<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    hipLaunchKernelGGL(k_mlp_bwd_s<false>, dim3(4 * used), dim3(S_THR), sh, s, (const bf16*)xn, (const bf16*)g, (const bf16*)W1, b1, (const bf16*)W2ts,
-                       (const bf16*)W1t, (bf16*)dApart, p1, p2, db1, M, tiles_per_range, MlpXchg{});
-}
-// the same kernel with the in-kernel reduction of the four dA partials (no k_lnbwd_sum4 afterwards); flags: 16 * used zeroed words, err: 1 word
-void kasf_launch_mlp_bwd_x(hipStream_t s, const void* x, const void* xn, const void* g, const float* ln_g, const void* W1, const float* b1, const void* W2ts,
-                           const void* W1t, void* dApart, float* p1, float* p2, float* db1, float* gsum, void* g_in, float* dgamma, float* dbeta, unsigned* flags,
-                           unsigned* err, int64_t M, int tiles_per_range, int used) {
-    const size_t sh = (size_t)(14 * TL) * sizeof(bf16);
-    MlpXchg xa{(const bf16*)x, ln_g, (bf16*)g_in, dgamma, dbeta, gsum, flags, err};
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_bwd_s<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    hipLaunchKernelGGL(k_mlp_bwd_s<true>, dim3(4 * used), dim3(S_THR), sh, s, (const bf16*)xn, (const bf16*)g, (const bf16*)W1, b1, (const bf16*)W2ts,
-                       (const bf16*)W1t, (bf16*)dApart, p1, p2, db1, M, tiles_per_range, xa);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_bwd_s), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    hipLaunchKernelGGL(k_mlp_bwd_s, dim3(4 * used), dim3(S_THR), sh, s, (const bf16*)xn, (const bf16*)g, (const bf16*)W1, b1, (const bf16*)W2ts,
+                       (const bf16*)W1t, (bf16*)dApart, p1, p2, db1, db1_rows, M, tiles_per_range);
 }

@@ -26,6 +26,31 @@ struct KasfProOff {
 
 int kasf_set_error(int code, const char* msg);
 
+// ---- k_reduce.hip: bit-reproducible per-channel reductions across workgroups ----
+// A kernel that ends in "one value per channel per workgroup" stores row blockIdx.x of a scratch matrix (take) instead of adding atomically; add()
+// registers the fixed-order sum of a column range of that matrix into a gradient vector; kasf_col_flush runs every registered sum in one launch
+// (call it on a stream that is ordered after the producers) and resets the sink.  Launchers take `KasfColSink* sink`: nullptr = the old fp32
+// atomics (single-operator entry points without scratch).
+#define KASF_COLJOBS_MAX 96
+struct KasfColJob {
+    const float* part;      // [rows][ld]
+    float* dst;             // mode 0: dst[c] += sum_r part[r][c];   mode 1 (fc2 finish): dst[c] = b[c] * sum, dst2[c] += a[c] * sum
+    const float *a, *b;
+    float* dst2;
+    int rows, ncols, ld, mode;
+};
+struct KasfColSink {
+    float* scratch = nullptr;       // device memory, `cap` floats
+    int64_t cap = 0, used = 0;
+    int njobs = 0;
+    bool overflow = false;
+    KasfColJob jobs[KASF_COLJOBS_MAX];
+    float* take(int rows, int ld);  // rows x ld floats of scratch (nullptr + overflow flag when exhausted: the kernel then falls back to atomics)
+    void add(const float* part, int ld, int rows, int ncols, float* dst, int mode = 0, const float* a = nullptr, const float* b = nullptr,
+             float* dst2 = nullptr);
+};
+void kasf_col_flush(hipStream_t s, KasfColSink* const* sinks, int nsinks);
+
 // ---- k_gemm.hip ----
 void kasf_launch_linear(int dt, hipStream_t s, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* C, int64_t ldc,
                         int64_t M, int N, const float* ln_g, const float* ln_b, void* xn_out, int act);
@@ -33,7 +58,7 @@ void kasf_launch_linear_res(int dt, hipStream_t s, const void* A, const void* W,
                             int64_t M);
 void kasf_launch_dgrad_lnbwd(int dt, hipStream_t s, const void* dY, int Kd, const void* Wt, const void* dxn_add, const void* X, const float* gamma,
                              const void* resid, void* out, int accumulate, float* dgamma, float* dbeta, int64_t M, void* xn_out = nullptr,
-                             const float* beta = nullptr);   // xn_out: also write LN(x) (operand of the matching weight gradient)
+                             const float* beta = nullptr, KasfColSink* sink = nullptr);   // xn_out: also write LN(x) (operand of the matching weight gradient)
 void kasf_launch_wgrad(int dt, hipStream_t s, const void* G, int64_t ldg, int N, const void* X, int64_t ldx, int K, const float* ln_g,
                        const float* ln_b, float* out, int64_t ldo, float* dbias, int64_t M, float* partial = nullptr, int64_t partial_floats = 0);
 // partial: optional fp32 scratch (>= splits*N*K floats): per-split tiles are stored there and summed by a second kernel
@@ -49,28 +74,18 @@ void kasf_launch_mlp_fwd(int dt, hipStream_t s, const void* x, const float* ln_g
 // g_in = g + LNbwd(dA), also writes H = GELU(Z) and dZ ([M x 512] each) for the weight-gradient GEMMs
 void kasf_launch_mlp_bwd(int dt, hipStream_t s, const void* x, const void* g, const float* ln_g, const float* ln_b, const void* W1, const float* b1,
                          const void* W2t_scaled, const void* W1t, void* Hbuf, void* dZbuf, void* xn_buf, void* g_in, float* dgamma, float* dbeta,
-                         int64_t M);
+                         int64_t M, KasfColSink* sink = nullptr);
 
-// ---- k_mlp2.hip (bf16): hidden-quarter MLP backward with fused weight gradients ----
-// dApart: 4*M*128 bf16 scratch; partial: >= 2*64*65536 floats; dW2 / gsum are the UNSCALED fc2 weight gradient and colsum(g)
-// (finish with kasf_launch_finalize_ls).  Writes g_in = g + LNbwd(dA) and accumulates dgamma/dbeta, dW1, db1.
-// xn = LN(x) as stored by the forward pass.
-// partial layout: [0, KASF_MLP_PARTIAL_FLOATS) per-range weight-gradient tiles, then KASF_MLP_FLAG_WORDS 32-bit words: the hand-off flags of the in-kernel
-// partial reduction ([64 ranges][4 quarters][4 waves], must be ZERO at launch; cleared again by the finishing kernel) and, at KASF_MLP_ERR_WORD, a word
-// that is set to 1 if a bounded wait between workgroups ever ran out (err != nullptr: that word is used instead).
+// ---- k_mlp2.hip / k_mlp3.hip (bf16): hidden-quarter MLP backward with fused weight gradients ----
+// dApart: 4*M*128 bf16 scratch; partial: >= KASF_MLP_PARTIAL_FLOATS floats; xn = LN(x) as stored by the forward pass.
+// Writes g_in = g + LNbwd(dA), dW1, db1, dgamma / dbeta, the fc2 weight gradient and gsum = colsum(g).
+// W2 / b2 / ls2 / dls2 (fp32 masters) given: fc2 is finished as well (dls2, dW2 scaled by ls2, gsum slot = db2 = ls2 . colsum(g)) -- the colsum terms by
+// the sink's k_col_finish, so they are complete only after kasf_col_flush.  sink == nullptr: per-channel sums by fp32 atomics (operator tests).
 #define KASF_MLP_PARTIAL_FLOATS (2 * 64 * 65536)
-#define KASF_MLP_FLAG_WORDS 2048
-#define KASF_MLP_ERR_WORD 1024
-#define KASF_MLP_TICKET_WORD 1536      // ticket counter of k_lnbwd_sum4_fin: zero at launch, left zero (the words must be zeroed once per scratch buffer)
 void kasf_launch_mlp_bwd_q(hipStream_t s, const void* x, const void* xn, const void* g, const float* ln_g, const void* W1, const float* b1,
                            const void* W2ts, const void* W1t, void* dApart, float* partial, float* dW1, float* dW2, float* db1, float* gsum, void* g_in,
                            float* dgamma, float* dbeta, int64_t M, const float* W2 = nullptr, const float* b2 = nullptr, const float* ls2 = nullptr,
-                           float* dls2 = nullptr, unsigned* err = nullptr);   // W2/b2/ls2/dls2 (fp32 masters): also finish fc2 (dls2, scaled dW2, db2 = ls2 * gsum in place)
-bool kasf_mlp_bwd_xchg_enabled();     // KASF_MLP_BWD_XCHG=1: the experimental in-kernel reduction of the dA partials (needs zeroed hand-off flags)
-void kasf_launch_mlp_bwd_x(hipStream_t s, const void* x, const void* xn, const void* g, const float* ln_g, const void* W1, const float* b1, const void* W2ts,
-                           const void* W1t, void* dApart, float* p1, float* p2, float* db1, float* gsum, void* g_in, float* dgamma, float* dbeta, unsigned* flags,
-                           unsigned* err, int64_t M, int tiles_per_range, int used);
-// bf16 forward with all weights resident in registers (persistent workgroups)
+                           float* dls2 = nullptr, KasfColSink* sink = nullptr);
 // BatchNorm batch-statistics buffers: KASF_STAT_SLOTS copies of [KASF_MAX_NODES][2] doubles (k_gcn.hip: producers pick a copy by workgroup index)
 #define KASF_STAT_SLOTS 4
 #define KASF_MAX_NODES 256                 // BatchNorm1d channels = joints (17) or frames: n_frames <= 256
@@ -78,15 +93,11 @@ void kasf_launch_mlp_bwd_x(hipStream_t s, const void* x, const void* xn, const v
 // 32-bit words per row of the stored temporal adjacency (bit c of word c >> 5 = "frame c is a neighbour")
 inline int kasf_gcn_mask_words(int n_frames) { return n_frames <= 96 ? 3 : (n_frames + 31) / 32; }
 
-void kasf_launch_mlp_fwd_r(hipStream_t s, const void* x, const float* ln_g, const float* ln_b, const void* W1, const float* b1, const void* W2,
-                           const float* b2, const float* ls2, void* out, int64_t M, void* xn_out);
-// producer / consumer form of the same kernel (k_mlp3.hip); kasf_launch_mlp_fwd_r forwards to it unless KASF_MLP_FWD_LOCKSTEP is set
+// bf16 forward with all weights resident in registers (persistent workgroups, producer / consumer waves; k_mlp3.hip)
 void kasf_launch_mlp_fwd_s(hipStream_t s, const void* x, const float* ln_g, const float* ln_b, const void* W1, const float* b1, const void* W2,
                            const float* b2, const float* ls2, void* out, int64_t M, void* xn_out, unsigned grid);
-// producer / consumer form of k_mlp_bwd_q (k_mlp3.hip): same inputs, partial-tile layout and grid mapping
 void kasf_launch_mlp_bwd_s(hipStream_t s, const void* xn, const void* g, const void* W1, const float* b1, const void* W2ts, const void* W1t, void* dApart,
-                           float* p1, float* p2, float* db1, int64_t M, int tiles_per_range, int used);
-void kasf_launch_wgrad_reduce(hipStream_t s, const float* partial, float* out, int64_t ldo, int N, int K, int splits);
+                           float* p1, float* p2, float* db1, float* db1_rows, int64_t M, int tiles_per_range, int used);
 
 // ---- k_attn.hip ----
 // mode 0: spatial (groups = B*T frames of 17 tokens), mode 1: temporal (groups = B*17 joint tracks of T tokens)
@@ -108,7 +119,7 @@ void kasf_launch_gcn_apply(int dt, hipStream_t s, const void* x_in, const void* 
                            float* run_mean, float* run_var, float* coef, const float* ls1, void* out, int B, int T, int mode, double count, int training,
                            float momentum);
 void kasf_launch_gcn_bwd1(int dt, hipStream_t s, const void* g, const void* xn, const void* y, const float* coef, const float* ls1, void* r,
-                          float* dls1, double* bstats, int B, int T, int mode);
+                          float* dls1, double* bstats, int B, int T, int mode, KasfColSink* sink = nullptr);
 // BatchNorm-backward finalisation (means of the backward sums, d(bn weight / bias)) is part of bwd2
 void kasf_launch_gcn_bwd2(int dt, hipStream_t s, const void* r, const void* y, const float* coef, const uint32_t* mask, void* duv, int B, int T,
                           int mode, const double* bstats, float* d_bn_w, float* d_bn_b, double count, int training = 1);
@@ -118,16 +129,18 @@ void kasf_launch_gcn_bwd2(int dt, hipStream_t s, const void* r, const void* y, c
 void kasf_launch_prologue_fwd(int dt, hipStream_t s, const float* x, const float* params, const KasfProOff* off, void* xj, void* xb, void* xl,
                               float* bone3, float* limb3, int64_t frames);
 void kasf_launch_embed_bwd(int dt, hipStream_t s, const void* g, const float* in3, const float* W, float* dW, float* db, float* dpos, float* din3,
-                           int64_t frames);
+                           int64_t frames, KasfColSink* sink = nullptr);
+// grad_base / grad_len: the contiguous range of the flat gradient array that holds the 204 limb-MLP tensors (one scratch row mirrors it)
 void kasf_launch_refusion_bwd(hipStream_t s, const float* x, const float* dlimb3, const float* params, float* grads, const KasfProOff* off,
-                              int64_t frames);
+                              int64_t frames, KasfColSink* sink = nullptr, int64_t grad_base = 0, int grad_len = 0);
 void kasf_launch_gate_fwd(int dt, hipStream_t s, const void* xa, const void* xg, const void* xb, const float* W, const float* b, void* out,
                           float* alpha, int64_t M, int adaptive);
 void kasf_launch_gate_bwd(int dt, hipStream_t s, const void* g, const void* g1, const void* g2, const void* xa, const void* xg, const void* xb,
-                          const float* W, const float* alpha, void* ga, void* gg, void* gb, float* dW, float* db, int64_t M, int adaptive, float* part,
-                          int64_t part_floats);   // g1/g2: optional extra addends of the incoming gradient; part: scratch for per-workgroup partials
+                          const float* W, const float* alpha, void* ga, void* gg, void* gb, float* dW, float* db, int64_t M, int adaptive,
+                          KasfColSink* sink = nullptr);   // g1/g2: optional extra addends of the incoming gradient
 void kasf_launch_head_fwd(int dt, hipStream_t s, const void* rep, const float* W, const float* b, float* out, int64_t M);
-void kasf_launch_head_bwd(int dt, hipStream_t s, const float* dy, const void* rep, const float* W, void* dpre, float* dW, float* db, int64_t M);
+void kasf_launch_head_bwd(int dt, hipStream_t s, const float* dy, const void* rep, const float* W, void* dpre, float* dW, float* db, int64_t M,
+                          KasfColSink* sink = nullptr);
 // return_rep=True backward: dpre = drep * (1 - rep^2), drep [M,512] fp32
 void kasf_launch_rep_bwd(int dt, hipStream_t s, const float* drep, const void* rep, void* dpre, int64_t M);
 void kasf_launch_cast_to_f32(int dt, hipStream_t s, const void* src, float* dst, int64_t n);
@@ -151,7 +164,7 @@ void kasf_launch_gather_clips(hipStream_t s, const float* xa, const float* ya, c
 
 // ---- k_gemm2.hip (bf16, persistent, register-resident weights) ----
 bool kasf_launch_dgrad_r(hipStream_t s, const void* dY, int Kd, const void* Wt, const void* dxn_add, const void* X, const float* gamma, const void* resid,
-                         void* out, int accumulate, float* dgamma, float* dbeta, int64_t M, void* xn_out, const float* beta);
+                         void* out, int accumulate, float* dgamma, float* dbeta, int64_t M, void* xn_out, const float* beta, KasfColSink* sink = nullptr);
 bool kasf_launch_linear_r(hipStream_t s, const void* A, const void* W, const float* bias, void* C, int64_t M, int N, const float* ln_g, const float* ln_b,
                           void* xn_out);
 void kasf_launch_linear_res_r(hipStream_t s, const void* A, const void* W, const float* bias, const float* ls, const void* resid, void* C, int64_t M);
@@ -160,14 +173,11 @@ void kasf_launch_linear_res_r(hipStream_t s, const void* A, const void* W, const
 // q_save / kv_save / o_save: what the backward pass reads (nullptr in evaluation: nothing but x_mid is written).  false: shape not covered.
 bool kasf_launch_attn_block_fwd(hipStream_t s, int bone, const void* x, const void* x_limb, const float* ln_g, const float* ln_b, const float* lnl_g,
                                 const float* lnl_b, const void* Wq, const void* Wkv, const void* Wproj, const float* bproj, const float* ls1, void* q_save,
-                                void* kv_save, void* o_save, void* out, int B, int T, int mode, int form = -1 /* -1: default, 0: LDS-direct ring, 1: register prefetch */);
+                                void* kv_save, void* o_save, void* out, int B, int T, int mode);
 
 // ---- k_gemm.hip: several bf16 weight gradients dW_j[N_j][128] += G_j^T X_j in one streaming launch + one finishing launch ----
 bool kasf_launch_wgrad_jobs(hipStream_t s, int njobs, const void* const* G, const void* const* X, const int* N, float* const* dW, float* const* dbias,
                             int fin_job, const float* fin_W, const float* fin_bias, const float* fin_ls, float* fin_dls, int64_t M, float* partial,
                             int64_t partial_floats);
-// fused backward of a self-attention block: d_o, attention backward, QKV data gradient, LayerNorm backward + residual, LN(x) in one launch (bf16)
-bool kasf_launch_attn_block_bwd(hipStream_t s, const void* qkv, const void* g_mid, const void* x, const void* WprojTs, const void* WqkvT, const float* gamma,
-                                const float* beta, void* dqkv, void* g_in, void* xn, float* dgamma, float* dbeta, int B, int Tn, int mode);
 bool kasf_launch_attn_bwd_fused_do(hipStream_t s, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, const void* g_mid,
-                                   const void* WprojTs, void* dq, int64_t lddq, void* dk, void* dv, int64_t lddkv, int B, int Tn, int mode, int form = -1 /* -1: default (persistent), 0: persistent, 1: one group per workgroup (round-1 form) */);
+                                   const void* WprojTs, void* dq, int64_t lddq, void* dk, void* dv, int64_t lddkv, int B, int Tn, int mode, int form = 0 /* 0: persistent, 1: one group per workgroup (bit-equal comparison form for the tests) */);

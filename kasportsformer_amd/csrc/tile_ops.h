@@ -45,13 +45,14 @@ __device__ __forceinline__ void acc_to_tile(T* sC, f32x4 (&acc)[NT][MT], int wn0
 
 // LayerNorm backward over the BM x 128 tile of d(LN output) held in sC (swizzled, type T):
 //   out = [resid +] [out +] rstd * (dxh - mean(dxh) - xhat * mean(dxh * xhat)),  dxh = (sC [+ dxn_add]) * gamma
-// and dgamma += sum_m d*xhat, dbeta += sum_m d (block partials -> fp32 atomics).  xhat/rstd are
+// and dgamma += sum_m d*xhat, dbeta += sum_m d: this workgroup's sums go to row blockIdx.x of `part` ([dgamma | dbeta], 256 floats, added in a
+// fixed order by k_col_finish) or, without scratch (part == nullptr), into the gradients by fp32 atomics.  xhat/rstd are
 // recomputed from X.  `red` is >= NTHR * 64 B of LDS that is free at this point (must not alias sC).
 template <typename T, int BM, int NTHR = 256>
 __device__ __forceinline__ void lnbwd_rows(const T* sC, const T* __restrict__ X, const float* __restrict__ gamma, const T* __restrict__ dxn_add,
                                            const T* __restrict__ resid, T* __restrict__ out, int accumulate, float* __restrict__ dgamma,
                                            float* __restrict__ dbeta, int64_t row0, int64_t M, float* red, T* __restrict__ xn_out = nullptr,
-                                           const float* __restrict__ beta = nullptr) {
+                                           const float* __restrict__ beta = nullptr, float* __restrict__ part = nullptr) {
     const int sub = threadIdx.x & 15, rl = threadIdx.x >> 4;
     float gm[8], dg[8], db[8];
 #pragma unroll
@@ -123,7 +124,8 @@ __device__ __forceinline__ void lnbwd_rows(const T* sC, const T* __restrict__ X,
         float s = 0.f;
 #pragma unroll
         for (int k = 0; k < RS; ++k) s += red[which * RS * 128 + k * 128 + c];
-        atomicAdd((which ? dbeta : dgamma) + c, s);
+        if (part != nullptr) part[(int64_t)blockIdx.x * 256 + threadIdx.x] = s;
+        else atomicAdd((which ? dbeta : dgamma) + c, s);
     }
 }
 

@@ -16,10 +16,11 @@ class _Loss3(torch.autograd.Function):
         pred, target = pred.contiguous().float(), target.contiguous().float()
         B, T = pred.shape[0], pred.shape[1]
         dpred = torch.empty_like(pred)
-        losses = torch.empty(4, dtype=torch.float32, device=pred.device)
+        scratch = torch.empty(4 + 4 * B, dtype=torch.float32, device=pred.device)      # [0:4] the result, the rest per-clip sums (kasf.h)
         lib = _lib.load()
-        _lib.check(lib.kasf_loss3(pred.data_ptr(), target.data_ptr(), dpred.data_ptr(), losses.data_ptr(), B, T, float(lambda_n), float(lambda_v),
+        _lib.check(lib.kasf_loss3(pred.data_ptr(), target.data_ptr(), dpred.data_ptr(), scratch.data_ptr(), B, T, float(lambda_n), float(lambda_v),
                                   1.0, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        losses = scratch[:4]
         ctx.save_for_backward(dpred)
         ctx.mark_non_differentiable(losses)
         return losses[0].clone(), losses

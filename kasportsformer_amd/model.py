@@ -109,6 +109,8 @@ class KASportsFormer(nn.Module):
             unsupported.append("num_heads not in {2, 4, 8, 16} (8 = configs/*.yaml:84 runs the MFMA attention kernels, the others generic ones)")
         if neighbour_num != 4 or not 4 <= n_frames <= 256:
             unsupported.append("neighbour_num != 4 or n_frames outside [4, 256]")
+        if num_heads == 2 and n_frames > 157:
+            unsupported.append("num_heads=2 with n_frames > 157 (the generic attention backward keeps a head's track in LDS)")
         if unsupported:
             raise NotImplementedError("kasportsformer_amd builds the shipped configuration only; unsupported: " + "; ".join(unsupported))
         if compute_dtype not in ("bf16", "fp32"):

@@ -105,6 +105,9 @@ def test_unsupported_configurations_raise_like_the_reference():
     with pytest.raises(NotImplementedError):
         K.KASportsFormer(num_heads=8, drop=0.1)
     with pytest.raises(NotImplementedError):
+        K.KASportsFormer(n_layers=1, num_heads=2, n_frames=158)   # the generic attention backward keeps a head's track in LDS: rejected up front, not at the first backward()
+    assert K.KASportsFormer(n_layers=1, num_heads=2, n_frames=157).n_frames == 157
+    with pytest.raises(NotImplementedError):
         K.KASportsFormer(num_heads=8, act_layer=nn.ReLU)
     m = K.KASportsFormer(n_layers=1, num_heads=8, use_tcn=False, graph_only=False, temporal_connection_len=1)   # dead kwargs accepted
     with pytest.raises(RuntimeError):

@@ -149,9 +149,8 @@ def test_mlp_backward_and_wgrad(lib, cd):
 
 @pytest.mark.parametrize("M", [459, 3000, 20011, 117504, 33])     # 20011: ten tiles per token range (steady-state ring slots and vmcnt accounting) + a ragged tail;
 def test_mlp_backward_fused_bf16(lib, M):                          # 117504: the benchmark's launch (58 tiles per range); 33: two tiles, one of them a single row
-    """k_mlp_bwd_s + k_lnbwd_sum4 + k_mlp_wfinish (the bf16 engine path) -- or, under KASF_MLP_BWD_XCHG, the experimental k_mlp_bwd_s<true> that
-    reduces the four dA partials inside the kernel, workgroup to workgroup; under KASF_MLP_BWD_LOCKSTEP the symmetric kernel -- against autograd.
-    Launched three times on the same scratch: the hand-off flags must come back zeroed, and no bounded wait may run out."""
+    """k_mlp_bwd_s + k_lnbwd_sum4_fin (the bf16 engine path; here without a column sink: per-channel sums by fp32 atomics) against autograd.
+    Launched three times on the same scratch with a different upstream gradient each time."""
     from kasportsformer_amd import _lib
     cd = "bf16"
     p = _mlp_params(seed=30)
@@ -160,7 +159,7 @@ def test_mlp_backward_fused_bf16(lib, M):                          # 117504: the
     w2ts = _dev((p["ls"][:, None] * p["W2"]).T.contiguous(), cd)
     w1t = _dev(p["W1"].T.contiguous(), cd)
     dap = torch.empty(4 * M * 128, device="cuda", dtype=torch.bfloat16)
-    part = torch.empty(2 * 64 * 65536 + 2048, device="cuda")
+    part = torch.empty(2 * 64 * 65536, device="cuda")
     gin = torch.empty_like(xd)
     z = lambda *s: torch.zeros(*s, device="cuda")
     dW1, dW2, db1, gsum, dg, db = z(512, 128), z(128, 512), z(512), z(128), z(128), z(128)
@@ -168,7 +167,7 @@ def test_mlp_backward_fused_bf16(lib, M):                          # 117504: the
     _lib.check(lib.kasf_op_mlp_fwd(1, ptr(xd), ptr(_f32(p["g"])), ptr(_f32(p["b"])), ptr(w1), ptr(_f32(p["b1"])), ptr(_dev(p["W2"], cd)), ptr(_f32(p["b2"])),
                                    ptr(_f32(p["ls"])), ptr(out), M, ptr(xn), stream()))
     g_final = gd
-    for rep in range(3):           # a different upstream gradient every time: a reducer that read a stale slab of the previous launch would be off by a factor
+    for rep in range(3):           # a different upstream gradient every time: anything stale from the previous launch would be off by a factor
         for t in (dW1, dW2, db1, gsum, dg, db):
             t.zero_()
         gin.fill_(float("nan"))
@@ -176,11 +175,6 @@ def test_mlp_backward_fused_bf16(lib, M):                          # 117504: the
         _lib.check(lib.kasf_op_mlp_bwd_fused(ptr(xd), ptr(xn), ptr(gd), ptr(_f32(p["g"])), ptr(w1), ptr(_f32(p["b1"])), ptr(w2ts), ptr(w1t),
                                              ptr(dap), ptr(part), ptr(dW1), ptr(dW2), ptr(db1), ptr(gsum), ptr(gin), ptr(dg), ptr(db), M, stream()))
         torch.cuda.synchronize()
-        if rep == 0 and "KASF_MLP_BWD_XCHG" not in os.environ:
-            part[2 * 64 * 65536:].zero_()                  # (the default chain never touches the flag words)
-        words = part[2 * 64 * 65536:].view(torch.int32)
-        assert int(words[1024]) == 0, "a bounded inter-workgroup wait ran out"
-        assert int(words[:1024].abs().max()) == 0, "hand-off flags were not cleared for the next launch"
         assert bool(torch.isfinite(gin).all()), rep
     xr = _back(xd).requires_grad_(True)
     pr = {k: (v.clone().requires_grad_(True) if k in ("b1", "W2", "g", "b") else v) for k, v in p.items()}

@@ -33,15 +33,13 @@ BRANCH = re.compile(r"^\s+s_cbranch_\w+\s+(\.LBB\d+_\d+)|^\s+s_branch\s+(\.LBB\d
 G4, S4 = ["glds"] * 4, ["store"] * 4
 DECLARED = {
     # k_mlp_bwd_s consumer, two-kernel chain, steady state: loads(t+3) 4, stores(t-2) 4, loads(t+2) 4, stores(t-3) 4  (k_mlp3.hip, comment at the wait)
-    (r"k_mlp_bwd_sILb0E", 16): [G4 + S4 + G4 + S4],
+    (r"k_mlp_bwd_sE", 16): [G4 + S4 + G4 + S4],
     # its first three iterations (hipcc peels them): fewer stores exist yet; the prologue's weight loads (plain loads) may have been sunk below the
     # prologue's uncounted wait -- "all but the two youngest load groups" holds in each of these forms
-    (r"k_mlp_bwd_sILb0E", 8): [G4 + G4, G4 + ["load"] * 4, G4 + S4],
+    (r"k_mlp_bwd_sE", 8): [G4 + G4, G4 + ["load"] * 4, G4 + S4],
 }
-# the opt-in experimental variant (KASF_MLP_BWD_XCHG) mixes compiler-scheduled buffer stores and a spilled peeled iteration into the sequence: its
-# counts are argued in the source and it is checked on the GPU only; it must still not spill inside its loops
-PATTERN_EXEMPT = (r"k_mlp_bwd_sILb1E",)
-SPILL_OUTSIDE_LOOP_OK = (r"k_mlp_bwd_sILb1E",)
+PATTERN_EXEMPT = ()
+SPILL_OUTSIDE_LOOP_OK = ()
 
 
 def kind(instr: str) -> str:
