@@ -29,6 +29,7 @@ __device__ __forceinline__ double stat_sum(const double* stats, int idx) {
     for (int sl = 0; sl < KASF_STAT_SLOTS; ++sl) v += stats[sl * KASF_STAT_LD + idx];
     return v;
 }
+__device__ __forceinline__ void stat_add(double* slot, double v) { atomicAdd(slot, v); }
 __device__ __forceinline__ double* stat_slot(double* stats) { return stats + (blockIdx.x % KASF_STAT_SLOTS) * KASF_STAT_LD; }
 
 // 32-bit token arithmetic (the engine bounds M * 16 below 2^31): a 64-bit divide by 17 is ~40 instructions per lane, paid by all 16 lanes of a token
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256) void k_gcn_agg_spatial(const T* __restrict__ u
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) t += sStat[k][threadIdx.x];
-        atomicAdd(stat_slot(stats) + threadIdx.x, (double)t);
+        stat_add(stat_slot(stats) + threadIdx.x, (double)t);
     }
 }
 
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(256) void k_gcn_agg_temporal(const T* __restrict__ 
         }
     }
     __syncthreads();
-    if (threadIdx.x < 2 * L) atomicAdd(stat_slot(stats) + threadIdx.x, (double)sStat[threadIdx.x]);
+    if (threadIdx.x < 2 * L) stat_add(stat_slot(stats) + threadIdx.x, (double)sStat[threadIdx.x]);
 }
 
 // ------------------------------------------------------------------ BatchNorm1d(num_nodes) + ReLU + layer-scale + residual
@@ -376,7 +377,7 @@ __global__ __launch_bounds__(256) void k_gcn_bwd1(const T* __restrict__ g, const
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) t += sStat[k * 2 * nodes + idx];
-        atomicAdd(stat_slot(bstats) + idx, (double)t);
+        stat_add(stat_slot(bstats) + idx, (double)t);
     }
 }
 
@@ -610,7 +611,7 @@ __global__ __launch_bounds__(256) void k_gcn_agg_temporal_g(const T* __restrict_
         }
     }
     __syncthreads();
-    for (int idx = threadIdx.x; idx < 2 * L; idx += 256) atomicAdd(stat_slot(stats) + idx, (double)sStat[idx]);
+    for (int idx = threadIdx.x; idx < 2 * L; idx += 256) stat_add(stat_slot(stats) + idx, (double)sStat[idx]);
 }
 
 template <typename T>
