@@ -159,12 +159,14 @@ int kasf_op_attention_fwd(int32_t dtype, const void* q, int64_t ldq, const void*
                           int32_t mode, void* stream);
 int kasf_op_attention_bwd(int32_t dtype, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, const void* d_o, void* dq, int64_t lddq,
                           void* dk, void* dv, int64_t lddkv, int32_t batch, int32_t n_frames, int32_t mode, void* stream);
-/* bf16, 8 heads, groups of <= 32 positions: the same with d_o = g_mid . wproj_t_scaled^T formed inside the kernel (what the training step runs:
+/* bf16, 8 heads, groups of <= 96 positions: the same with d_o = g_mid . wproj_t_scaled^T formed inside the kernel (what the training step runs:
  * attention.py's proj + layer-scale data gradient folded in); wproj_t_scaled [128 in][128 out] = (ls1 . Wproj)^T packed bf16.
- * form 0: persistent kernel (default in the engine), 1: one group per workgroup (round-1 form, kept as the comparison point): bit-identical results */
+ * Groups of <= 32 positions: form 0 = persistent kernel (the engine's), 1 = one group per workgroup (the comparison point): bit-identical results.
+ * Groups of 33..96 positions (temporal attention at T = 81): with o_saved [M,128] (the attention output) and lse [M,8] fp32 (log-sum-exp of the scaled
+ * scores per token and head), both as the training forward leaves them, the key-tile-outer kernel runs; with either NULL the self-contained one. */
 int kasf_op_attention_bwd_fused_do(const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, const void* g_mid, const void* wproj_t_scaled,
                                    void* dq, int64_t lddq, void* dk, void* dv, int64_t lddkv, int32_t batch, int32_t n_frames, int32_t mode, int32_t form,
-                                   void* stream);
+                                   const void* o_saved, const float* lse, void* stream);
 /* fp32 <-> model dtype */
 int kasf_op_cast(int32_t dtype, const void* src, void* dst, int64_t n, int32_t to_f32, void* stream);
 

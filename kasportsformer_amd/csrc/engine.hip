@@ -40,7 +40,7 @@ static bool single_stream() {
 }
 constexpr int64_t WG_PARTIAL_FLOATS = KASF_MLP_PARTIAL_FLOATS + 65536;   // per-split weight-gradient tiles (256 workgroups x 128x128, or 64 ranges x (dW1 + dW2) of the MLP) + the per-split rows of a bias gradient
 
-struct BlkWs { int64_t qkv, kv, o, xn, y, mask, x_mid, xn2, x_out, stats, bstats, coef; };
+struct BlkWs { int64_t qkv, kv, o, xn, y, mask, x_mid, xn2, x_out, stats, bstats, coef, lse; };
 struct LayerWs { BlkWs b[6]; int64_t gate_out, alpha; };
 struct WsEntry { std::string name; int64_t off, numel; int kind; };
 struct Scratch { int64_t uv, t1, t2, hbuf, dzbuf, d_o, dqkv, rbuf, duv, xn_a, xn_b, wg_part, g_in, col; };   // per-branch (att / graph / bone); col: per-workgroup rows of the column reductions (k_reduce.hip)
@@ -282,6 +282,8 @@ void build_plan(const kasf_model* m, int B, bool train, bool names, Plan& p) {
             if (kind == KIND_ATT) w.qkv = take(M * 384, 0, "qkv", l, b);
             if (kind == KIND_BONE) { w.qkv = take(M * 128, 0, "q", l, b); w.kv = take(M * 256, 0, "kv", l, b); }
             if (kind != KIND_GRAPH) w.o = take(M * 128, 0, "o", l, b);
+            // temporal attention over 33..96 frames (T = 81): log-sum-exp of the scores per (token, head), left by the fused forward for k_attn_bwd_kt
+            w.lse = (train && kind != KIND_GRAPH && (b & 1) && T > 32 && T <= 96 && m->cfg.dtype == KASF_BF16 && m->cfg.num_heads == 8) ? take(M * 8, 1, "lse", l, b) : -1;
             if (kind == KIND_GRAPH) {
                 w.xn = take(M * 128, 0, "xn", l, b);
                 w.y = take(M * 128, 0, "y", l, b);
@@ -358,7 +360,7 @@ void block_forward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void* 
         mixer_done = kasf_launch_attn_block_fwd(c.s, bone ? 1 : 0, x_in, bone ? x_limb : nullptr, P + o.n1w, P + o.n1b, bone ? P + o.n1lw : nullptr,
                                                 bone ? P + o.n1lb : nullptr, c.pk(o.p_mix), bone ? c.pk(o.p_kv) : nullptr, c.pk(o.p_proj), P + o.proj_b,
                                                 P + o.ls1, c.train ? c.w(w.qkv) : nullptr, (c.train && bone) ? c.w(w.kv) : nullptr,
-                                                c.train ? c.w(w.o) : nullptr, c.w(w.x_mid), c.B, c.T, o.mode);
+                                                c.train ? c.w(w.o) : nullptr, c.w(w.x_mid), c.B, c.T, o.mode, (c.train && w.lse >= 0) ? (float*)c.w(w.lse) : nullptr);
     }
     if (mixer_done) {
     } else if (o.kind == KIND_ATT) {
@@ -433,7 +435,7 @@ void block_backward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void*
         const char* q = (const char*)c.w(w.qkv);
         char* dq = (char*)c.w(sc.dqkv);
         if (fdo) kasf_launch_attn_bwd_fused_do(c.s, q, 384, q + 128 * c.es, q + 256 * c.es, 384, g_mid, c.pk(o.p_projTs), dq, 384, dq + 128 * c.es,
-                                               dq + 256 * c.es, 384, c.B, c.T, o.mode);
+                                               dq + 256 * c.es, 384, c.B, c.T, o.mode, 0, c.w(w.o), w.lse >= 0 ? (const float*)c.w(w.lse) : nullptr);
         else kasf_launch_attn_bwd(c.dt, c.s, q, 384, q + 128 * c.es, q + 256 * c.es, 384, c.w(sc.d_o), dq, 384, dq + 128 * c.es, dq + 256 * c.es, 384, c.B,
                                   c.T, o.mode, heads);
         kasf_launch_dgrad_lnbwd(c.dt, c.s, dq, 384, c.pk(o.p_mixT), nullptr, x_in, P + o.n1w, g_mid, dst, accumulate, G + o.n1w, G + o.n1b, c.M,
@@ -459,7 +461,7 @@ void block_backward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void*
         char* dq = (char*)c.w(sc.dqkv);
         char* dkv = dq + c.M * 128 * c.es;
         if (fdo) kasf_launch_attn_bwd_fused_do(c.s, c.w(w.qkv), 128, kv, kv + 128 * c.es, 256, g_mid, c.pk(o.p_projTs), dq, 128, dkv, dkv + 128 * c.es, 256, c.B,
-                                               c.T, o.mode);
+                                               c.T, o.mode, 0, c.w(w.o), w.lse >= 0 ? (const float*)c.w(w.lse) : nullptr);
         else kasf_launch_attn_bwd(c.dt, c.s, c.w(w.qkv), 128, kv, kv + 128 * c.es, 256, c.w(sc.d_o), dq, 128, dkv, dkv + 128 * c.es, 256, c.B, c.T, o.mode, heads);
         kasf_launch_dgrad_lnbwd(c.dt, c.s, dq, 128, c.pk(o.p_mixT), nullptr, x_in, P + o.n1w, g_mid, dst, accumulate, G + o.n1w, G + o.n1b, c.M,
                                 c.w(sc.xn_a), P + o.n1b, c.sink);
@@ -496,7 +498,7 @@ int check_model(const kasf_model* m) {
 extern "C" {
 
 const char* kasf_last_error(void) { return g_err.c_str(); }
-int kasf_version(void) { return 3; }
+int kasf_version(void) { return 4; }
 
 int kasf_model_create(const kasf_config* cfg, kasf_model** out) {
     if (cfg == nullptr || out == nullptr) return kasf_set_error(2, "null argument");
@@ -911,12 +913,13 @@ int kasf_op_attention_bwd(int32_t dtype, const void* q, int64_t ldq, const void*
     return g_err.empty() ? 0 : 3;
 }
 int kasf_op_attention_bwd_fused_do(const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, const void* g_mid, const void* wproj_t_scaled, void* dq,
-                                   int64_t lddq, void* dk, void* dv, int64_t lddkv, int32_t batch, int32_t n_frames, int32_t mode, int32_t form, void* stream) {
+                                   int64_t lddq, void* dk, void* dv, int64_t lddkv, int32_t batch, int32_t n_frames, int32_t mode, int32_t form, const void* o_saved,
+                                   const float* lse, void* stream) {
     g_err.clear();
     if (form < 0 || form > 1) return kasf_set_error(2, "form: 0 (persistent) or 1 (one group per workgroup)");
     if (batch < 1 || n_frames < 1 || (int64_t)batch * n_frames * 17 * 384 >= ((int64_t)1 << 31)) return kasf_set_error(2, "batch * n_frames * 17 * 384 must stay below 2^31");
-    if (!kasf_launch_attn_bwd_fused_do((hipStream_t)stream, q, ldq, k, v, ldkv, g_mid, wproj_t_scaled, dq, lddq, dk, dv, lddkv, batch, n_frames, mode, form))
-        return kasf_set_error(2, "fused-d_o attention backward: groups of at most 32 positions (bf16, 8 heads)");
+    if (!kasf_launch_attn_bwd_fused_do((hipStream_t)stream, q, ldq, k, v, ldkv, g_mid, wproj_t_scaled, dq, lddq, dk, dv, lddkv, batch, n_frames, mode, form, o_saved, lse))
+        return kasf_set_error(2, "fused-d_o attention backward: groups of at most 96 positions (form 1: at most 32); bf16, 8 heads");
     HIPCHK(hipGetLastError());
     return g_err.empty() ? 0 : 3;
 }

@@ -60,6 +60,7 @@ struct AttnBlkArgs {
     bf16* KVs;                // training, bone: [M][256]
     bf16* Os;                 // training: attention output [M][128]
     bf16* OUT;                // x_mid [M][128]
+    float* LSE;               // training, groups of 33..96 positions: log-sum-exp of the scaled scores per (token, head) [M][8] for k_attn_bwd_kt; or nullptr
     int L, T, mode, groups;
 };
 
@@ -467,6 +468,8 @@ __global__ __launch_bounds__(AB_THR, 2) void k_attn_blk_fwd_rp3(const AttnBlkArg
                     for (int e = 0; e < 16; ++e) { st[kt][e] = __expf(st[kt][e] - mx); sum += st[kt][e]; }
                 sum += __shfl_xor(sum, 32);
                 const float inv = 1.0f / sum;
+                if (a.LSE != nullptr && hh == 0 && 32 * qt + r32 < L)      // the backward pass rebuilds P = exp(s - lse) tile by tile without a statistics pass
+                    a.LSE[(size_t)(unsigned)(base_of(G) + (32 * qt + r32) * stride) * 8u + w] = mx + __logf(sum);
                 f32x16 ot = z;
 #pragma unroll
                 for (int kt = 0; kt < NKT; ++kt) {
@@ -521,13 +524,13 @@ __global__ __launch_bounds__(AB_THR, 2) void k_attn_blk_fwd_rp3(const AttnBlkArg
 // Returns false when the shape is outside the fused kernels' range (groups longer than 96 positions): the caller runs the unfused sequence.
 bool kasf_launch_attn_block_fwd(hipStream_t s, int bone, const void* x, const void* x_limb, const float* ln_g, const float* ln_b, const float* lnl_g,
                                 const float* lnl_b, const void* Wq, const void* Wkv, const void* Wproj, const float* bproj, const float* ls1, void* q_save,
-                                void* kv_save, void* o_save, void* out, int B, int T, int mode) {
+                                void* kv_save, void* o_save, void* out, int B, int T, int mode, float* lse_save) {
     const int L = mode == 0 ? KASF_J : T;
     if (L > 96) return false;
     AttnBlkArgs a;
     a.X = (const bf16*)x; a.XL = (const bf16*)x_limb; a.ln_g = ln_g; a.ln_b = ln_b; a.lnl_g = lnl_g; a.lnl_b = lnl_b;
     a.Wq = (const bf16*)Wq; a.Wkv = (const bf16*)Wkv; a.Wproj = (const bf16*)Wproj; a.bproj = bproj; a.ls1 = ls1;
-    a.Qs = (bf16*)q_save; a.KVs = (bf16*)kv_save; a.Os = (bf16*)o_save; a.OUT = (bf16*)out;
+    a.Qs = (bf16*)q_save; a.KVs = (bf16*)kv_save; a.Os = (bf16*)o_save; a.OUT = (bf16*)out; a.LSE = lse_save;
     a.L = L; a.T = T; a.mode = mode; a.groups = mode == 0 ? B * T : B * KASF_J;
     if (a.groups <= 0) return true;
     if (L > 32) {                                       // three-tile groups: one workgroup per CU

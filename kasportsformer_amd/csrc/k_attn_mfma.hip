@@ -409,6 +409,131 @@ __global__ __launch_bounds__(FDO ? 512 : 256, 2) void k_attn_bwd_long(const bf16
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Backward for groups of 33..96 positions with d_o formed in-kernel, KEY-TILE-OUTER (round 3; replaces k_attn_bwd_long<3, true>: 242 us per launch
+// at T = 81, B = 128 = 1.3 TB/s, the kernel furthest below any roof).  What changed:
+//   * no softmax-statistics pass and no recomputed dP: the forward (k_attn_blk_fwd_rp3) leaves lse = max + log(sum) per (token, head), so every
+//     32 x 32 block of P is rebuilt on its own as exp(s / 4 - lse);  delta = rowsum(d_o . o) comes from the saved attention output, not from P . dP;
+//   * scores are formed UN-transposed, S[query][key] = Q . K^T (lane = key, registers = queries): P and dS are then already in the operand layout
+//     of dV^T = d_o^T . P and dK^T = Q^T . dS (the accumulator -> operand reuse of the forward core), so only ONE 2 KB block per tile pair -- dS, for
+//     dQ^T = K^T . dS^T -- goes through LDS and comes back transposed, where the query-tile-outer kernel sent P and dS both ways;
+//   * one key tile's dK / dV (32 registers) and the three query tiles' dQ (48) are live instead of 96 + 16, per tile pair 8 MFMAs instead of 9 + the
+//     statistics pass, and the dS blocks alternate between two buffers so that consecutive tile pairs overlap.
+// One wave per (group, head), the 8 heads of a group per workgroup (the group's g_mid rows are staged once for the d_o products), one workgroup per CU.
+// ---------------------------------------------------------------------------------------------------------------
+template <int NKT>
+__global__ __launch_bounds__(512, 2) void k_attn_bwd_kt(const bf16* __restrict__ Q, int64_t ldq, const bf16* __restrict__ K, const bf16* __restrict__ V,
+                                                        int64_t ldkv, const bf16* __restrict__ O, const float* __restrict__ LSE, bf16* __restrict__ dQ,
+                                                        int64_t lddq, bf16* __restrict__ dK, bf16* __restrict__ dV, int64_t lddkv, int L, int Tn, int mode,
+                                                        const bf16* __restrict__ Gmid, const bf16* __restrict__ Wp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TILE = NKT * 32 * 16;                           // [positions][16] operand tile (bf16 elements)
+    constexpr int WAVE_BYTES = 3 * TILE * 2 + 2 * 32 * 32 * 2 + 2 * NKT * 32 * 4;     // K, Q, d_o tiles; two dS blocks; lse, delta
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
+    const int G = blockIdx.x, h = wave;
+    bf16* sK = reinterpret_cast<bf16*>(smem + wave * WAVE_BYTES);
+    bf16* sQ = sK + TILE;
+    bf16* sD = sQ + TILE;
+    bf16* sdS = sD + TILE;                                        // [2][32 keys][32 queries]
+    float* sLse = reinterpret_cast<float*>(sdS + 2 * 32 * 32);    // [32 NKT]
+    float* sDel = sLse + NKT * 32;
+    bf16* sG = reinterpret_cast<bf16*>(smem + 8 * WAVE_BYTES);    // [32 NKT][128] g_mid rows of the group (swizzled tile; rows past L zero)
+    bf16x8 kf[NKT], vf[NKT];
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) {
+        const int pos = 32 * t + r;
+        kf[t] = row_frag(K, ldkv, G, pos, L, Tn, mode, h, hh, sK);
+        vf[t] = row_frag(V, ldkv, G, pos, L, Tn, mode, h, hh, nullptr);
+        row_frag(Q, ldq, G, pos, L, Tn, mode, h, hh, sQ);
+    }
+    {   // d_o = g_mid . (ls1 . Wproj)^T restricted to this head: 24 MFMAs against the wave's 16 rows of the packed weight
+        for (int c = threadIdx.x; c < NKT * 32 * 16; c += 512) {
+            const int row = c >> 4, ch = c & 15;
+            bf16x8 v = zero8();
+            if (row < L) v = *reinterpret_cast<const bf16x8*>(Gmid + tok_of(G, row, Tn, mode) * 128 + ch * 8);
+            *reinterpret_cast<bf16x8*>(sG + Tile<bf16>::chunk_off(row, ch)) = v;
+        }
+        const int li = lane & 15, lg = lane >> 4;
+        bf16x8 wp[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) wp[ks] = *reinterpret_cast<const bf16x8*>(Wp + (int64_t)(16 * h + li) * 128 + 32 * ks + 8 * lg);
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < 2 * NKT; ++mt) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[ks], *reinterpret_cast<const bf16x8*>(sG + Tile<bf16>::chunk_off(16 * mt + li, 4 * ks + lg)), acc, 0, 0, 0);
+            float v[4] = {acc[0], acc[1], acc[2], acc[3]};
+            store4(sD + (16 * mt + li) * 16 + 4 * lg, v);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // the d_o tile was written by other lanes of this wave
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) {   // lse and delta = sum_d d_o . o of query 32 t + r (the two lane halves hold 8 channels each)
+        const int pos = 32 * t + r;
+        float lse = INFINITY, part = 0.f;                         // rows past L: exp(s - inf) = 0 keeps them out of every product
+        if (pos < L) {
+            const int64_t tok = tok_of(G, pos, Tn, mode);
+            lse = LSE[tok * 8 + h];
+            const bf16x8 o8 = *reinterpret_cast<const bf16x8*>(O + tok * 128 + h * 16 + 8 * hh), d8 = *reinterpret_cast<const bf16x8*>(sD + pos * 16 + 8 * hh);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) part += (float)o8[e] * (float)d8[e];
+        }
+        part += __shfl_xor(part, 32);
+        if (hh == 0) { sLse[pos] = lse; sDel[pos] = part; }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    auto rowf = [&](const bf16* tile, int t) { return *reinterpret_cast<const bf16x8*>(tile + (32 * t + r) * 16 + 8 * hh); };
+    f32x16 dq[NKT];
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) dq[t] = zero16();
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+        if (32 * kt >= L) break;
+        const bool keyok = 32 * kt + r < L;                       // lane = key
+        f32x16 dv = zero16(), dk = zero16();
+#pragma unroll
+        for (int qt = 0; qt < NKT; ++qt) {
+            if (32 * qt >= L) break;
+            bf16* blk = sdS + ((kt * NKT + qt) & 1) * 32 * 32;
+            f32x16 p = mfma32(rowf(sQ, qt), kf[kt], zero16());    // S[query][key]: lane = key, registers = queries
+            f32x16 ds = mfma32(rowf(sD, qt), vf[kt], zero16());   // dP[query][key] = sum_d d_o[query][d] V[key][d]
+#pragma unroll
+            for (int a4 = 0; a4 < 4; ++a4) {                      // registers 4a .. 4a+3 = queries 32 qt + 8a + 4hh + {0..3}
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(sLse + 32 * qt + 8 * a4 + 4 * hh), d4 = *reinterpret_cast<const f32x4*>(sDel + 32 * qt + 8 * a4 + 4 * hh);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float pv = keyok ? __expf(p[4 * a4 + e] * 0.25f - l4[e]) : 0.f;
+                    p[4 * a4 + e] = pv;
+                    ds[4 * a4 + e] = pv * (ds[4 * a4 + e] - d4[e]) * 0.25f;                  // dS (scale folded)
+                }
+                float v4[4] = {ds[4 * a4], ds[4 * a4 + 1], ds[4 * a4 + 2], ds[4 * a4 + 3]};
+                store4(blk + r * 32 + 8 * a4 + 4 * hh, v4);                                  // dS block [key][query] for the transposed read-back
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {                      // contraction over the 32 queries of this tile, operands straight from the registers
+                dv = mfma32(tr_frag(sD, 2 * qt + ks), pack8(p, ks), dv);                     // dV^T[d][key] += d_o^T . P
+                dk = mfma32(tr_frag(sQ, 2 * qt + ks), pack8(ds, ks), dk);                    // dK^T[d][key] += Q^T . dS
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the block was written by other lanes of this wave
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) dq[qt] = mfma32(tr_frag(sK, 2 * kt + ks), tr_frag32(blk, ks), dq[qt]);      // dQ^T[d][query] += K^T . dS^T
+        }
+        const int j = 32 * kt + r;
+        if (j < L) {
+            const int64_t tok = tok_of(G, j, Tn, mode);
+            store_t(dV + tok * lddkv + h * 16, dv, hh);
+            store_t(dK + tok * lddkv + h * 16, dk, hh);
+        }
+    }
+#pragma unroll
+    for (int qt = 0; qt < NKT; ++qt) {
+        const int i = 32 * qt + r;
+        if (i < L) store_t(dQ + tok_of(G, i, Tn, mode) * lddq + h * 16, dq[qt], hh);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Persistent form of k_attn_bwd_mfma<1, true> (groups of <= 32 positions, d_o formed in-kernel): the same arithmetic, bit for bit, but
 //   * a workgroup walks a contiguous range of groups: the 16 rows of the packed projection weight a wave needs stay in registers for the
 //     whole launch (the one-group-per-workgroup form re-read 32 KB of weights per group: 221 MB of L2 traffic per launch, more than the
@@ -612,12 +737,20 @@ bool kasf_launch_attn_bwd_mfma(hipStream_t s, const void* q, int64_t ldq, const 
 // Attention backward with the projection's data gradient fused in (bf16, groups of <= 32 positions): d_o = g_mid . WprojTs^T is formed per head
 // inside the kernel.  false: shape not covered (the caller computes d_o with a linear and calls kasf_launch_attn_bwd).
 bool kasf_launch_attn_bwd_fused_do(hipStream_t s, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, const void* g_mid,
-                                   const void* WprojTs, void* dq, int64_t lddq, void* dk, void* dv, int64_t lddkv, int B, int Tn, int mode, int form) {
+                                   const void* WprojTs, void* dq, int64_t lddq, void* dk, void* dv, int64_t lddkv, int B, int Tn, int mode, int form,
+                                   const void* o_saved, const float* lse) {
     const int L = mode == 0 ? KASF_J : Tn, groups = mode == 0 ? B * Tn : B * KASF_J;
     if (L > 96) return false;
     if (groups <= 0) return true;
     if (L > 32) {                                       // three-tile groups (temporal attention at T = 81): one workgroup = the 8 heads of one group
         if (form == 1) return false;                    // (the one-group-per-workgroup comparison form exists for one-tile groups only)
+        if (o_saved != nullptr && lse != nullptr) {     // key-tile-outer kernel: statistics and delta from what the forward left behind
+            const size_t shk = 8 * (size_t)(3 * 96 * 16 * 2 + 2 * 32 * 32 * 2 + 2 * 96 * 4) + (size_t)96 * 128 * 2;
+            set_smem(k_attn_bwd_kt<3>, shk);
+            hipLaunchKernelGGL(k_attn_bwd_kt<3>, dim3(groups), dim3(512), shk, s, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldkv, (const bf16*)o_saved, lse,
+                               (bf16*)dq, lddq, (bf16*)dk, (bf16*)dv, lddkv, L, Tn, mode, (const bf16*)g_mid, (const bf16*)WprojTs);
+            return true;
+        }
         const size_t shl = 8 * (size_t)(4 * 96 * 16 + 2 * 32 * 32) * 2 + (size_t)96 * 128 * 2;
         set_smem(k_attn_bwd_long<3, true>, shl);
         hipLaunchKernelGGL((k_attn_bwd_long<3, true>), dim3(groups), dim3(512), shl, s, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldkv, (const bf16*)nullptr,

@@ -173,11 +173,12 @@ void kasf_launch_linear_res_r(hipStream_t s, const void* A, const void* W, const
 // q_save / kv_save / o_save: what the backward pass reads (nullptr in evaluation: nothing but x_mid is written).  false: shape not covered.
 bool kasf_launch_attn_block_fwd(hipStream_t s, int bone, const void* x, const void* x_limb, const float* ln_g, const float* ln_b, const float* lnl_g,
                                 const float* lnl_b, const void* Wq, const void* Wkv, const void* Wproj, const float* bproj, const float* ls1, void* q_save,
-                                void* kv_save, void* o_save, void* out, int B, int T, int mode);
+                                void* kv_save, void* o_save, void* out, int B, int T, int mode, float* lse_save = nullptr);   // lse_save [M][8]: groups of 33..96 positions in training
 
 // ---- k_gemm.hip: several bf16 weight gradients dW_j[N_j][128] += G_j^T X_j in one streaming launch + one finishing launch ----
 bool kasf_launch_wgrad_jobs(hipStream_t s, int njobs, const void* const* G, const void* const* X, const int* N, float* const* dW, float* const* dbias,
                             int fin_job, const float* fin_W, const float* fin_bias, const float* fin_ls, float* fin_dls, int64_t M, float* partial,
                             int64_t partial_floats);
 bool kasf_launch_attn_bwd_fused_do(hipStream_t s, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, const void* g_mid,
-                                   const void* WprojTs, void* dq, int64_t lddq, void* dk, void* dv, int64_t lddkv, int B, int Tn, int mode, int form = 0 /* 0: persistent, 1: one group per workgroup (bit-equal comparison form for the tests) */);
+                                   const void* WprojTs, void* dq, int64_t lddq, void* dk, void* dv, int64_t lddkv, int B, int Tn, int mode, int form = 0 /* 0: persistent, 1: one group per workgroup (bit-equal comparison form for the tests) */,
+                                   const void* o_saved = nullptr, const float* lse = nullptr);   // o_saved [M][128] + lse [M][8] (both from the forward): groups of 33..96 positions take the key-tile-outer kernel

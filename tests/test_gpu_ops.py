@@ -280,7 +280,7 @@ def test_attention_backward_fused_do(lib, bone, mode, T, B):                    
         else:
             dqkv = torch.full((B, T, 17, 384), float("nan"), device="cuda", dtype=torch.bfloat16)
             oargs = (dqkv.data_ptr(), 384, dqkv.data_ptr() + 256, dqkv.data_ptr() + 512, 384)
-        _lib.check(lib.kasf_op_attention_bwd_fused_do(*args, ptr(gd), ptr(wd), *oargs, B, T, mode, form, stream()))
+        _lib.check(lib.kasf_op_attention_bwd_fused_do(*args, ptr(gd), ptr(wd), *oargs, B, T, mode, form, None, None, stream()))
         torch.cuda.synchronize()
         outs.append(torch.cat((dq, dkv), dim=-1).float().cpu() if bone else dqkv.float().cpu())
     assert torch.isfinite(outs[0]).all()
@@ -290,6 +290,55 @@ def test_attention_backward_fused_do(lib, bone, mode, T, B):                    
     q, k, v = _heads(qr, 3, 8)
     attention_core(q, k, v, "spatial" if mode == 0 else "temporal", 0.25).backward(d_o)
     assert rel_err(outs[0], qr.grad) < TOL["bf16"]
+
+
+@pytest.mark.parametrize("bone", [False, True])
+@pytest.mark.parametrize("T,B", [(81, 3), (33, 2), (64, 2), (96, 1), (50, 5)])       # 33: a one-row last tile; 64 / 96: two / three full tiles
+def test_attention_backward_long_groups_key_tile_outer(lib, bone, T, B):
+    """Temporal groups of 33..96 frames: k_attn_bwd_kt (statistics from the forward's log-sum-exp, delta from the saved attention output, un-transposed
+    scores) against the oracle's attention core, and against the self-contained kernel it replaces in the engine (same operands, no lse / o)."""
+    from kasportsformer_amd import _lib
+    from oracle.kasf_oracle import attention_core, _heads
+    mode = 1
+    qkv = _rand(B, T, 17, 384, seed=34)
+    g_mid = _rand(B, T, 17, 128, seed=35)
+    W = _rand(128, 128, seed=36) * 0.2
+    ls1 = _rand(128, seed=37)
+    wts = (ls1[:, None] * W).t().contiguous()
+    qd, gd, wd = _dev(qkv, "bf16"), _dev(g_mid, "bf16"), _dev(wts, "bf16")
+    # what the training forward leaves behind: o (bf16) and lse = log sum_j exp(q_i . k_j / 4) per (token, head), from the stored bf16 q, k, v
+    qf = _back(qd)
+    q, k, v = _heads(qf, 3, 8)                                    # [B,H,T,J,d]
+    s = (q.transpose(2, 3) @ k.transpose(2, 3).transpose(-2, -1)) * 0.25          # [B,H,J,T,T]
+    lse = torch.logsumexp(s, dim=-1).permute(0, 3, 2, 1).contiguous()             # [B,T,J,H]
+    o = attention_core(q, k, v, "temporal", 0.25)                                 # [B,T,J,128]
+    od, lsed = _dev(o, "bf16"), lse.float().cuda()
+    if bone:
+        qsep, kv = qd[..., :128].contiguous(), qd[..., 128:].contiguous()
+        args = (qsep.data_ptr(), 128, kv.data_ptr(), kv.data_ptr() + 256, 256)
+    else:
+        args = (qd.data_ptr(), 384, qd.data_ptr() + 256, qd.data_ptr() + 512, 384)
+    outs = []
+    for with_stats in (True, False):
+        if bone:
+            dq = torch.full((B, T, 17, 128), float("nan"), device="cuda", dtype=torch.bfloat16)
+            dkv = torch.full((B, T, 17, 256), float("nan"), device="cuda", dtype=torch.bfloat16)
+            oargs = (dq.data_ptr(), 128, dkv.data_ptr(), dkv.data_ptr() + 256, 256)
+        else:
+            dqkv = torch.full((B, T, 17, 384), float("nan"), device="cuda", dtype=torch.bfloat16)
+            oargs = (dqkv.data_ptr(), 384, dqkv.data_ptr() + 256, dqkv.data_ptr() + 512, 384)
+        _lib.check(lib.kasf_op_attention_bwd_fused_do(*args, ptr(gd), ptr(wd), *oargs, B, T, mode, 0, ptr(od) if with_stats else None,
+                                                      ptr(lsed) if with_stats else None, stream()))
+        torch.cuda.synchronize()
+        outs.append(torch.cat((dq, dkv), dim=-1).float().cpu() if bone else dqkv.float().cpu())
+    assert torch.isfinite(outs[0]).all() and torch.isfinite(outs[1]).all()
+    d_o = (_back(gd) @ _back(wd).t()).to(torch.bfloat16).float()
+    qr = _back(qd).requires_grad_(True)
+    q, k, v = _heads(qr, 3, 8)
+    attention_core(q, k, v, "temporal", 0.25).backward(d_o)
+    assert rel_err(outs[0], qr.grad) < TOL["bf16"]
+    assert rel_err(outs[1], qr.grad) < TOL["bf16"]
+    assert rel_err(outs[0], outs[1]) < TOL["bf16"]
 
 
 def test_loss3_and_adamw(lib):
