@@ -420,30 +420,60 @@ __global__ __launch_bounds__(FDO ? 512 : 256, 2) void k_attn_bwd_long(const bf16
 //     statistics pass, and the dS blocks alternate between two buffers so that consecutive tile pairs overlap.
 // One wave per (group, head), the 8 heads of a group per workgroup (the group's g_mid rows are staged once for the d_o products), one workgroup per CU.
 // ---------------------------------------------------------------------------------------------------------------
-template <int NKT>
+// tr_frag32 for a block whose rows are LD elements apart (LD = 36: the 72-byte row stride spreads the 32 row stores of a block over all banks;
+// with 64-byte rows every fourth lane hit the same bank)
+template <int LD>
+__device__ __forceinline__ bf16x8 tr_frag32s(const bf16* s_tile, int ks) {
+    const int lane = threadIdx.x & 63, u = lane & 15, hh = lane >> 5, q = u >> 2, p = u & 3, c0 = 16 * ((lane >> 4) & 1);
+    typedef __attribute__((address_space(3))) bf16x4 lds_v4;
+    const int k0 = 16 * ks + 4 * hh;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)(s_tile + (k0 + q) * LD + c0 + 4 * p));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)(s_tile + (k0 + 8 + q) * LD + c0 + 4 * p));
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+constexpr int KT_LD = 36;                                         // row stride of a dS block
+// NR2: score registers of the LAST query tile that can hold a live query (register g holds queries (g & 3) + 8 (g >> 2) + 4 hh of the tile: 9 when
+// the tile has at most 17 positions -- T = 81 = 32 + 32 + 17 --, else 16); the vector work and block stores of the dead registers are skipped.
+template <int NKT, int NR2>
 __global__ __launch_bounds__(512, 2) void k_attn_bwd_kt(const bf16* __restrict__ Q, int64_t ldq, const bf16* __restrict__ K, const bf16* __restrict__ V,
                                                         int64_t ldkv, const bf16* __restrict__ O, const float* __restrict__ LSE, bf16* __restrict__ dQ,
                                                         int64_t lddq, bf16* __restrict__ dK, bf16* __restrict__ dV, int64_t lddkv, int L, int Tn, int mode,
                                                         const bf16* __restrict__ Gmid, const bf16* __restrict__ Wp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TILE = NKT * 32 * 16;                           // [positions][16] operand tile (bf16 elements)
-    constexpr int WAVE_BYTES = 3 * TILE * 2 + 2 * 32 * 32 * 2 + 2 * NKT * 32 * 4;     // K, Q, d_o tiles; two dS blocks; lse, delta
+    constexpr int BLK = 32 * KT_LD;                               // one dS block
+    constexpr int WAVE_BYTES = 3 * TILE * 2 + 2 * BLK * 2 + 2 * NKT * 32 * 4;     // K, Q, d_o tiles; two dS blocks; lse, delta
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
     const int G = blockIdx.x, h = wave;
     bf16* sK = reinterpret_cast<bf16*>(smem + wave * WAVE_BYTES);
     bf16* sQ = sK + TILE;
     bf16* sD = sQ + TILE;
-    bf16* sdS = sD + TILE;                                        // [2][32 keys][32 queries]
-    float* sLse = reinterpret_cast<float*>(sdS + 2 * 32 * 32);    // [32 NKT]
+    bf16* sdS = sD + TILE;                                        // [2][32 keys][KT_LD]
+    float* sLse = reinterpret_cast<float*>(sdS + 2 * BLK);        // [32 NKT]
     float* sDel = sLse + NKT * 32;
     bf16* sG = reinterpret_cast<bf16*>(smem + 8 * WAVE_BYTES);    // [32 NKT][128] g_mid rows of the group (swizzled tile; rows past L zero)
-    bf16x8 kf[NKT], vf[NKT];
+    bf16x8 kf[NKT], vf[NKT], o8[NKT];
+    float lse_r[NKT];
+    // every global load of the group is issued up front (one workgroup per CU: nothing else would cover a second round trip to memory)
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) {
+        const int pos = 32 * t + r;
+        const int64_t tokc = tok_of(G, pos < L ? pos : L - 1, Tn, mode);
+        lse_r[t] = LSE[tokc * 8 + h];
+        o8[t] = *reinterpret_cast<const bf16x8*>(O + tokc * 128 + h * 16 + 8 * hh);
+    }
 #pragma unroll
     for (int t = 0; t < NKT; ++t) {
         const int pos = 32 * t + r;
         kf[t] = row_frag(K, ldkv, G, pos, L, Tn, mode, h, hh, sK);
         vf[t] = row_frag(V, ldkv, G, pos, L, Tn, mode, h, hh, nullptr);
-        row_frag(Q, ldq, G, pos, L, Tn, mode, h, hh, sQ);
+        {   // Q / 4 (a power of two: exact in bf16) into the wave's tile
+            bf16x8 qv = row_frag(Q, ldq, G, pos, L, Tn, mode, h, hh, nullptr);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qv[e] = (bf16)((float)qv[e] * 0.25f);
+            *reinterpret_cast<bf16x8*>(sQ + pos * 16 + 8 * hh) = qv;
+        }
     }
     {   // d_o = g_mid . (ls1 . Wproj)^T restricted to this head: 24 MFMAs against the wave's 16 rows of the packed weight
         for (int c = threadIdx.x; c < NKT * 32 * 16; c += 512) {
@@ -473,51 +503,74 @@ __global__ __launch_bounds__(512, 2) void k_attn_bwd_kt(const bf16* __restrict__
         const int pos = 32 * t + r;
         float lse = INFINITY, part = 0.f;                         // rows past L: exp(s - inf) = 0 keeps them out of every product
         if (pos < L) {
-            const int64_t tok = tok_of(G, pos, Tn, mode);
-            lse = LSE[tok * 8 + h];
-            const bf16x8 o8 = *reinterpret_cast<const bf16x8*>(O + tok * 128 + h * 16 + 8 * hh), d8 = *reinterpret_cast<const bf16x8*>(sD + pos * 16 + 8 * hh);
+            lse = lse_r[t];
+            const bf16x8 d8 = *reinterpret_cast<const bf16x8*>(sD + pos * 16 + 8 * hh);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) part += (float)o8[e] * (float)d8[e];
+            for (int e = 0; e < 8; ++e) part += (float)o8[t][e] * (float)d8[e];
         }
         part += __shfl_xor(part, 32);
         if (hh == 0) { sLse[pos] = lse; sDel[pos] = part; }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     auto rowf = [&](const bf16* tile, int t) { return *reinterpret_cast<const bf16x8*>(tile + (32 * t + r) * 16 + 8 * hh); };
+    const int nt = (L + 31) >> 5;                                 // live 32-position tiles (2 or 3)
     f32x16 dq[NKT];
 #pragma unroll
     for (int t = 0; t < NKT; ++t) dq[t] = zero16();
+    // The tile pairs (kt, qt) are walked kt-major.  Program order inside a pair, chosen so that no LDS latency sits between dependent steps (two waves
+    // per SIMD hide little): every LDS read the pair needs -- lse / delta of its queries, the transposed d_o / Q fragments, the row fragments of the
+    // NEXT pair -- is issued first, then the next pair's two score products, then the vector work, then the dS block stores (all reads of the wave's
+    // tiles are ahead of them: the compiler cannot move a read across a store it cannot disambiguate), the dV / dK products and last the block's
+    // transposed read-back for dQ.  sQ holds Q / 4 (exact in bf16): S and dK come out scaled, dS is stored unscaled and dQ is scaled once at the end.
+    f32x16 s_nxt = mfma32(rowf(sQ, 0), kf[0], zero16());          // S[query][key] / 4 of the first pair: lane = key, registers = queries
+    f32x16 p_nxt = mfma32(rowf(sD, 0), vf[0], zero16());          // dP[query][key] = sum_d d_o[query][d] V[key][d]
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
-        if (32 * kt >= L) break;
-        const bool keyok = 32 * kt + r < L;                       // lane = key
+        if (kt >= nt) break;
+        const bool keyok = 32 * kt + r < L;                       // lane = key (false only in the last tile)
+        const bf16x8 kt0 = tr_frag(sK, 2 * kt), kt1 = tr_frag(sK, 2 * kt + 1);
         f32x16 dv = zero16(), dk = zero16();
 #pragma unroll
         for (int qt = 0; qt < NKT; ++qt) {
-            if (32 * qt >= L) break;
-            bf16* blk = sdS + ((kt * NKT + qt) & 1) * 32 * 32;
-            f32x16 p = mfma32(rowf(sQ, qt), kf[kt], zero16());    // S[query][key]: lane = key, registers = queries
-            f32x16 ds = mfma32(rowf(sD, qt), vf[kt], zero16());   // dP[query][key] = sum_d d_o[query][d] V[key][d]
+            if (qt >= nt) break;
+            bf16* blk = sdS + ((kt * NKT + qt) & 1) * BLK;
+            f32x4 l4[4], d4[4];
 #pragma unroll
             for (int a4 = 0; a4 < 4; ++a4) {                      // registers 4a .. 4a+3 = queries 32 qt + 8a + 4hh + {0..3}
-                const f32x4 l4 = *reinterpret_cast<const f32x4*>(sLse + 32 * qt + 8 * a4 + 4 * hh), d4 = *reinterpret_cast<const f32x4*>(sDel + 32 * qt + 8 * a4 + 4 * hh);
+                l4[a4] = *reinterpret_cast<const f32x4*>(sLse + 32 * qt + 8 * a4 + 4 * hh);
+                d4[a4] = *reinterpret_cast<const f32x4*>(sDel + 32 * qt + 8 * a4 + 4 * hh);
+            }
+            const bf16x8 dt0 = tr_frag(sD, 2 * qt), dt1 = tr_frag(sD, 2 * qt + 1), qt0 = tr_frag(sQ, 2 * qt), qt1 = tr_frag(sQ, 2 * qt + 1);
+            f32x16 p = s_nxt, ds = p_nxt;
+            {   // the two score products of the NEXT pair (kt-major order; past the end: pair (0, 0) again, unused) run under this pair's vector work
+                const int qn = qt + 1 < nt ? qt + 1 : 0;
+                const bool same_kt = qt + 1 < nt;
+                const bf16x8 kn = same_kt ? kf[kt] : kf[kt + 1 < NKT ? kt + 1 : 0], vn = same_kt ? vf[kt] : vf[kt + 1 < NKT ? kt + 1 : 0];
+                s_nxt = mfma32(rowf(sQ, qn), kn, zero16());
+                p_nxt = mfma32(rowf(sD, qn), vn, zero16());
+            }
+            const int NRQ = (qt == NKT - 1) ? NR2 : 16;           // (a constant after unrolling; NR2 < 16 is only chosen when all NKT tiles are live)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float pv = keyok ? __expf(p[4 * a4 + e] * 0.25f - l4[e]) : 0.f;
-                    p[4 * a4 + e] = pv;
-                    ds[4 * a4 + e] = pv * (ds[4 * a4 + e] - d4[e]) * 0.25f;                  // dS (scale folded)
-                }
+            for (int g = 0; g < 16; ++g) {
+                if (g < NRQ) {
+                    const float pv = __expf(p[g] - l4[g >> 2][g & 3]);
+                    p[g] = pv;
+                    ds[g] = pv * (ds[g] - d4[g >> 2][g & 3]);                                // dS x 4
+                } else { p[g] = 0.f; ds[g] = 0.f; }
+            }
+#pragma unroll
+            for (int a4 = 0; a4 < 4; ++a4) {                      // dS block [key][query] for the transposed read-back; rows of keys past L are zero
                 float v4[4] = {ds[4 * a4], ds[4 * a4 + 1], ds[4 * a4 + 2], ds[4 * a4 + 3]};
-                store4(blk + r * 32 + 8 * a4 + 4 * hh, v4);                                  // dS block [key][query] for the transposed read-back
+                if (!keyok) { v4[0] = 0.f; v4[1] = 0.f; v4[2] = 0.f; v4[3] = 0.f; }
+                store4(blk + r * KT_LD + 8 * a4 + 4 * hh, v4);
             }
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {                      // contraction over the 32 queries of this tile, operands straight from the registers
-                dv = mfma32(tr_frag(sD, 2 * qt + ks), pack8(p, ks), dv);                     // dV^T[d][key] += d_o^T . P
-                dk = mfma32(tr_frag(sQ, 2 * qt + ks), pack8(ds, ks), dk);                    // dK^T[d][key] += Q^T . dS
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the block was written by other lanes of this wave
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) dq[qt] = mfma32(tr_frag(sK, 2 * kt + ks), tr_frag32(blk, ks), dq[qt]);      // dQ^T[d][query] += K^T . dS^T
+            dv = mfma32(dt0, pack8(p, 0), dv);                    // dV^T[d][key] += d_o^T . P      (contraction over the tile's 32 queries, operands
+            dk = mfma32(qt0, pack8(ds, 0), dk);                   // dK^T[d][key] += (Q / 4)^T . 4 dS     straight from the registers)
+            dv = mfma32(dt1, pack8(p, 1), dv);
+            dk = mfma32(qt1, pack8(ds, 1), dk);
+            // (same-wave LDS requests are served in issue order and the transposed reads below are memory reads of `blk` to the compiler: no explicit wait)
+            dq[qt] = mfma32(kt0, tr_frag32s<KT_LD>(blk, 0), dq[qt]);                         // 4 dQ^T[d][query] += K^T . (4 dS)^T
+            dq[qt] = mfma32(kt1, tr_frag32s<KT_LD>(blk, 1), dq[qt]);
         }
         const int j = 32 * kt + r;
         if (j < L) {
@@ -529,7 +582,11 @@ __global__ __launch_bounds__(512, 2) void k_attn_bwd_kt(const bf16* __restrict__
 #pragma unroll
     for (int qt = 0; qt < NKT; ++qt) {
         const int i = 32 * qt + r;
-        if (i < L) store_t(dQ + tok_of(G, i, Tn, mode) * lddq + h * 16, dq[qt], hh);
+        if (i < L) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dq[qt][e] *= 0.25f;
+            store_t(dQ + tok_of(G, i, Tn, mode) * lddq + h * 16, dq[qt], hh);
+        }
     }
 }
 
@@ -745,10 +802,16 @@ bool kasf_launch_attn_bwd_fused_do(hipStream_t s, const void* q, int64_t ldq, co
     if (L > 32) {                                       // three-tile groups (temporal attention at T = 81): one workgroup = the 8 heads of one group
         if (form == 1) return false;                    // (the one-group-per-workgroup comparison form exists for one-tile groups only)
         if (o_saved != nullptr && lse != nullptr) {     // key-tile-outer kernel: statistics and delta from what the forward left behind
-            const size_t shk = 8 * (size_t)(3 * 96 * 16 * 2 + 2 * 32 * 32 * 2 + 2 * 96 * 4) + (size_t)96 * 128 * 2;
-            set_smem(k_attn_bwd_kt<3>, shk);
-            hipLaunchKernelGGL(k_attn_bwd_kt<3>, dim3(groups), dim3(512), shk, s, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldkv, (const bf16*)o_saved, lse,
-                               (bf16*)dq, lddq, (bf16*)dk, (bf16*)dv, lddkv, L, Tn, mode, (const bf16*)g_mid, (const bf16*)WprojTs);
+            const size_t shk = 8 * (size_t)(3 * 96 * 16 * 2 + 2 * 32 * KT_LD * 2 + 2 * 96 * 4) + (size_t)96 * 128 * 2;
+            if (L > 64 && L <= 81) {                    // last tile of at most 17 positions: 7 of its 16 query registers are dead
+                set_smem(k_attn_bwd_kt<3, 9>, shk);
+                hipLaunchKernelGGL((k_attn_bwd_kt<3, 9>), dim3(groups), dim3(512), shk, s, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldkv, (const bf16*)o_saved, lse,
+                                   (bf16*)dq, lddq, (bf16*)dk, (bf16*)dv, lddkv, L, Tn, mode, (const bf16*)g_mid, (const bf16*)WprojTs);
+            } else {
+                set_smem(k_attn_bwd_kt<3, 16>, shk);
+                hipLaunchKernelGGL((k_attn_bwd_kt<3, 16>), dim3(groups), dim3(512), shk, s, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldkv, (const bf16*)o_saved, lse,
+                                   (bf16*)dq, lddq, (bf16*)dk, (bf16*)dv, lddkv, L, Tn, mode, (const bf16*)g_mid, (const bf16*)WprojTs);
+            }
             return true;
         }
         const size_t shl = 8 * (size_t)(4 * 96 * 16 + 2 * 32 * 32) * 2 + (size_t)96 * 128 * 2;
