@@ -33,6 +33,8 @@ _pi64, _pi32 = C.POINTER(C.c_int64), C.POINTER(C.c_int32)
 SIGNATURES = {
     "kasf_last_error": (C.c_char_p, []),
     "kasf_version": (_i32, []),
+    "kasf_set_deterministic": (None, [_i32]),
+    "kasf_get_deterministic": (_i32, []),
     "kasf_model_create": (_i32, [C.POINTER(KasfConfig), C.POINTER(_vp)]),
     "kasf_model_destroy": (None, [_vp]),
     "kasf_model_status": (_i32, [_vp, _pi32]),

@@ -33,10 +33,13 @@ struct BlockOff {
 struct LayerOff { BlockOff blk[6]; int64_t fus_w, fus_b, begin, end; };
 struct TopOff { int64_t norm_w, norm_b, fc_w, fc_b, head_w, head_b, p_fc, p_fcT, begin, end; };
 
-// KASF_SINGLE_STREAM=1: run the three branches of a layer back to back on the caller's stream (measurement / debugging switch)
+// The three branches of a layer run on three streams unless this is set: kasf_set_deterministic(1) (or KASF_SINGLE_STREAM=1 in the environment, read once)
+// runs them back to back on the caller's stream.  That is the mode in which bf16 gradients are bit-reproducible from run to run (see
+// tests/test_gpu_determinism.py for what is not with three streams), and the mode the isolated per-kernel profiles are taken in; -4 % throughput.
+static int g_single_stream = -1;
 static bool single_stream() {
-    static const bool v = getenv("KASF_SINGLE_STREAM") != nullptr;
-    return v;
+    if (g_single_stream < 0) g_single_stream = getenv("KASF_SINGLE_STREAM") != nullptr ? 1 : 0;
+    return g_single_stream != 0;
 }
 constexpr int64_t WG_PARTIAL_FLOATS = KASF_MLP_PARTIAL_FLOATS + 65536;   // per-split weight-gradient tiles (256 workgroups x 128x128, or 64 ranges x (dW1 + dW2) of the MLP) + the per-split rows of a bias gradient
 
@@ -498,6 +501,8 @@ int check_model(const kasf_model* m) {
 extern "C" {
 
 const char* kasf_last_error(void) { return g_err.c_str(); }
+void kasf_set_deterministic(int32_t on) { g_single_stream = on ? 1 : 0; }
+int32_t kasf_get_deterministic(void) { return single_stream() ? 1 : 0; }
 int kasf_version(void) { return 4; }
 
 int kasf_model_create(const kasf_config* cfg, kasf_model** out) {

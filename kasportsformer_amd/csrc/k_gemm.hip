@@ -505,13 +505,23 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
                                                       const float* __restrict__ brow, float* __restrict__ dbias) {
     __shared__ f32x4 sPart[4][64];
     const int tile_wgs = (int)((int64_t)N * K / 256);
-    if ((int)blockIdx.x >= tile_wgs) {                   // extra workgroups: dbias[n] += sum_z brow[z][n], splits in order
-        const int n = ((int)blockIdx.x - tile_wgs) * 256 + threadIdx.x;
+    if ((int)blockIdx.x >= tile_wgs) {                   // extra workgroups (64 columns each): dbias[n] += sum_z brow[z][n] in a fixed order --
+        __shared__ float sB[4][64];                      // four split lanes per column, four independent chains per lane (the loads are what takes time)
+        const int cl = threadIdx.x & 63, zl = threadIdx.x >> 6, n = ((int)blockIdx.x - tile_wgs) * 64 + cl;
+        float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
         if (n < N) {
-            float sb = 0.f;
-            for (int z = 0; z < splits; ++z) sb += brow[(int64_t)z * N + n];
-            dbias[n] += sb;
+            int z = zl;
+            for (; z + 12 < splits; z += 16) {
+                b0 += brow[(int64_t)z * N + n];
+                b1 += brow[(int64_t)(z + 4) * N + n];
+                b2 += brow[(int64_t)(z + 8) * N + n];
+                b3 += brow[(int64_t)(z + 12) * N + n];
+            }
+            for (; z < splits; z += 4) b0 += brow[(int64_t)z * N + n];
         }
+        sB[zl][cl] = (b0 + b1) + (b2 + b3);
+        __syncthreads();
+        if (zl == 0 && n < N) dbias[n] += (sB[0][cl] + sB[1][cl]) + (sB[2][cl] + sB[3][cl]);
         return;
     }
     const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
@@ -685,8 +695,8 @@ static void wgrad_T(hipStream_t s, const void* G, int64_t ldg, int N, const void
         hipLaunchKernelGGL((k_wgrad<T, NBUF, false>), grid, dim3(256), sh, s, (const T*)G, ldg, (const T*)X, ldx, ln_g, ln_b, out, ldo, dbias, M, slice,
                            partial, brow);
     }
-    if (partial != nullptr)                              // fixed-order sum of the per-split tiles (+ (N + 255) / 256 workgroups for the bias rows)
-        hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((int64_t)N * K / 256 + (brow != nullptr ? (N + 255) / 256 : 0))), dim3(256), 0, s, partial, out, ldo, N, K,
+    if (partial != nullptr)                              // fixed-order sum of the per-split tiles (+ (N + 63) / 64 workgroups for the bias rows)
+        hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((int64_t)N * K / 256 + (brow != nullptr ? (N + 63) / 64 : 0))), dim3(256), 0, s, partial, out, ldo, N, K,
                            splits, brow, dbias);
 }
 void kasf_launch_wgrad(int dt, hipStream_t s, const void* G, int64_t ldg, int N, const void* X, int64_t ldx, int K, const float* ln_g,

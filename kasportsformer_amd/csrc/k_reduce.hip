@@ -26,38 +26,40 @@ namespace {
 constexpr int CF_LAUNCH_JOBS = 48;
 struct ColJobs {
     KasfColJob j[CF_LAUNCH_JOBS];
-    int first[CF_LAUNCH_JOBS + 1];      // first workgroup of job k (a workgroup owns 32 columns of one job)
+    int first[CF_LAUNCH_JOBS + 1];      // first workgroup of job k (a workgroup owns 16 columns of one job)
     int n;
 };
 
-// 256 threads = 8 row lanes x 32 columns.  Row lane l adds rows l, l + 8, l + 16, ... (four independent chains of stride 32 for latency, combined in a
-// fixed tree), the eight lanes meet in LDS in a fixed tree: the result depends on (rows, values) only.
+// 256 threads = 16 row lanes x 16 columns (a workgroup owns 16 columns of one job).  Row lane l adds rows l, l + 16, l + 32, ... as eight independent
+// chains (the loads of a pass are issued back to back: latency, not bandwidth, is what this kernel is made of) combined in a fixed tree, the sixteen
+// lanes meet in LDS in a fixed tree: the result depends on (rows, values) only.
 __global__ __launch_bounds__(256) void k_col_finish(const ColJobs js) {
-    __shared__ float red[8][32];
+    __shared__ float red[16][17];
     int j = 0;
     while (j + 1 < js.n && (int)blockIdx.x >= js.first[j + 1]) ++j;
     const KasfColJob jb = js.j[j];
-    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5, c = ((int)blockIdx.x - js.first[j]) * 32 + cl;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4, c = ((int)blockIdx.x - js.first[j]) * 16 + cl;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (c < jb.ncols) {
         const float* p = jb.part + c;
         int r = rl;
-        for (; r + 24 < jb.rows; r += 32) {
-            s0 += p[(int64_t)r * jb.ld];
-            s1 += p[(int64_t)(r + 8) * jb.ld];
-            s2 += p[(int64_t)(r + 16) * jb.ld];
-            s3 += p[(int64_t)(r + 24) * jb.ld];
+        for (; r + 7 * 16 < jb.rows; r += 8 * 16) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s[u] += p[(int64_t)(r + 16 * u) * jb.ld];
         }
-        for (; r < jb.rows; r += 8) s0 += p[(int64_t)r * jb.ld];
+        for (; r < jb.rows; r += 16) s[0] += p[(int64_t)r * jb.ld];
     }
-    red[rl][cl] = (s0 + s1) + (s2 + s3);
+    red[rl][cl] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
     __syncthreads();
     if (rl == 0 && c < jb.ncols) {
-        const float s = ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) + ((red[4][cl] + red[5][cl]) + (red[6][cl] + red[7][cl]));
-        if (jb.mode == 0) jb.dst[c] += s;
-        else {                          // fc2 finish: s = colsum(g);  db2 = ls2 . s;  dls2 += b2 . s   (the W2 . G term of dls2 is already there)
-            jb.dst[c] = jb.b[c] * s;
-            jb.dst2[c] += jb.a[c] * s;
+        float t[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t[k] = red[k][cl];
+        const float v = (((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]))) + (((t[8] + t[9]) + (t[10] + t[11])) + ((t[12] + t[13]) + (t[14] + t[15])));
+        if (jb.mode == 0) jb.dst[c] += v;
+        else {                          // fc2 finish: v = colsum(g);  db2 = ls2 . v;  dls2 += b2 . v   (the W2 . G term of dls2 is already there)
+            jb.dst[c] = jb.b[c] * v;
+            jb.dst2[c] += jb.a[c] * v;
         }
     }
 }
@@ -83,7 +85,7 @@ void kasf_col_flush(hipStream_t s, KasfColSink* const* sinks, int nsinks) {
             if (js.n == CF_LAUNCH_JOBS) launch();
             js.j[js.n] = sk->jobs[q];
             js.first[js.n] = wg;
-            wg += (sk->jobs[q].ncols + 31) / 32;
+            wg += (sk->jobs[q].ncols + 15) / 16;
             ++js.n;
         }
         sk->njobs = 0;
