@@ -144,15 +144,17 @@ def test_detected_keypoints_confidence_channel(cd, tol):
     assert abs(loss.item() - loss_ref.item()) < (1e-4 if cd == "fp32" else 5e-2) * max(1.0, abs(loss_ref.item()))
     ref_grads = dict(oracle.named_parameters())
     gmax = max(float(q.grad.abs().max()) for q in ref_grads.values() if q.grad is not None)
-    bad = []
+    bad, worst_e = [], 0.0
     for n, p in model.named_parameters():
         r = ref_grads[n].grad
         assert (r is None) == (p.grad is None), n
         if r is None:
             continue
         err = float((p.grad.detach().double().cpu() - r.double()).abs().max() / max(float(r.abs().max()), (1e-3 if cd == "fp32" else 0.05) * gmax))
+        worst_e = max(worst_e, err)
         if not err < tol:
             bad.append((err, n))
+    print(f"[detector confidence, {cd}] worst per-tensor gradient error {worst_e:.3e}")
     assert not bad, sorted(bad, reverse=True)[:10]
 
 
@@ -512,7 +514,7 @@ def test_full_depth_26_layers_against_oracle(cd):
 
 
 @pytest.mark.parametrize("T,B", [(243, 1), (100, 2), (33, 2), (5, 3), (4, 8), (64, 2), (96, 2), (32, 2)])      # 64 / 96: the three-tile fused temporal forward with an empty / a full last tile; 32: the largest one-tile group
-@pytest.mark.parametrize("cd,tol", [("fp32", 2e-3), ("bf16", 0.5)])
+@pytest.mark.parametrize("cd,tol", [("fp32", 2e-3), ("bf16", 0.4)])      # bf16, a handful of clips: observed 0.04-0.30 on the worst (tiny) tensor, cosine >= 0.99977, forward 1.2e-2
 def test_arbitrary_clip_lengths(cd, tol, T, B):
     """The reference builds for any n_frames (KASportsFormer.py:291-295, README.md:59): 243 is the long configuration of this model family;
     100 is past the MFMA attention cores (<= 96), 33 past the fused attention block (<= 32), 5 and 4 are the shortest clips whose rows
@@ -530,12 +532,12 @@ def test_arbitrary_clip_lengths(cd, tol, T, B):
     loss.backward()
     torch.cuda.synchronize()
     err = _abs_err(pred, ref) / max(1.0, float(ref.abs().max()))
-    assert err < (1e-3 if cd == "fp32" else 0.12), err
+    assert err < (1e-3 if cd == "fp32" else 0.025), err
     if cd == "fp32":
         assert fa.unexplained == 0, fa.summary()
     ref_grads = dict(oracle.named_parameters())
     gmax = max(float(q.grad.abs().max()) for q in ref_grads.values() if q.grad is not None)
-    bad, dots = [], [0.0, 0.0, 0.0]
+    bad, dots, WORST = [], [0.0, 0.0, 0.0], [0.0]
     for n, p in model.named_parameters():
         r = ref_grads[n].grad
         assert (r is None) == (p.grad is None), n
@@ -543,11 +545,13 @@ def test_arbitrary_clip_lengths(cd, tol, T, B):
             continue
         g = p.grad.detach().double().cpu()
         e = float((g - r.double()).abs().max() / max(float(r.abs().max()), (1e-3 if cd == "fp32" else 0.05) * gmax))
+        WORST[0] = max(WORST[0], e)
         dots[0] += float((g * r.double()).sum()); dots[1] += float((g * g).sum()); dots[2] += float((r.double() ** 2).sum())
         if not e < tol:
             bad.append((e, n))
     cosine = dots[0] / (dots[1] ** 0.5 * dots[2] ** 0.5)
-    assert cosine > (0.999999 if cd == "fp32" else 0.995), cosine
+    print(f"[clip length T={T} B={B}, {cd}] forward err {err:.3e}, gradient cosine {cosine:.6f}, worst per-tensor error {WORST[0]:.3e}")
+    assert cosine > (0.999999 if cd == "fp32" else 0.9995), cosine
     assert not bad, sorted(bad, reverse=True)[:8]
     model.eval()
     with torch.no_grad():
@@ -555,7 +559,7 @@ def test_arbitrary_clip_lengths(cd, tol, T, B):
 
 
 @pytest.mark.parametrize("heads", [4, 16, 2])
-@pytest.mark.parametrize("cd,tol", [("fp32", 2e-3), ("bf16", 0.5)])
+@pytest.mark.parametrize("cd,tol", [("fp32", 2e-3), ("bf16", 0.4)])      # bf16, two clips: observed 0.23-0.30 on the worst (tiny) tensor
 def test_other_head_counts(cd, tol, heads):
     """`KASportsFormer()` without arguments builds with num_heads=4 (KASportsFormer.py:293; every yaml overrides it with 8): head dimension 32.
     Other head counts run the generic attention kernels in both modes; forward and all gradients against the oracle."""
@@ -577,14 +581,16 @@ def test_other_head_counts(cd, tol, heads):
     assert _abs_err(pred, ref) / max(1.0, float(ref.abs().max())) < (1e-3 if cd == "fp32" else 0.12)
     ref_grads = dict(oracle.named_parameters())
     gmax = max(float(q.grad.abs().max()) for q in ref_grads.values() if q.grad is not None)
-    bad = []
+    bad, worst_e = [], 0.0
     for n, p in model.named_parameters():
         r = ref_grads[n].grad
         assert (r is None) == (p.grad is None), n
         if r is not None:
             e = float((p.grad.detach().double().cpu() - r.double()).abs().max() / max(float(r.abs().max()), (1e-3 if cd == "fp32" else 0.05) * gmax))
+            worst_e = max(worst_e, e)
             if not e < tol:
                 bad.append((e, n))
+    print(f"[heads={heads}, {cd}] worst per-tensor gradient error {worst_e:.3e}")
     assert not bad, sorted(bad, reverse=True)[:8]
 
 
