@@ -18,7 +18,7 @@ p, d = qkv.data_ptr(), dqkv.data_ptr()
 for mode in (0, 1):
     for form in (1, 0):
         def run():
-            _lib.check(lib.kasf_op_attention_bwd_fused_do(p, 384, p + 256, p + 512, 384, g.data_ptr(), w.data_ptr(), d, 384, d + 256, d + 512, 384, B, T, mode, form, st))
+            _lib.check(lib.kasf_op_attention_bwd_fused_do(p, 384, p + 256, p + 512, 384, g.data_ptr(), w.data_ptr(), d, 384, d + 256, d + 512, 384, B, T, mode, form, None, None, st))
         for _ in range(5):
             run()
         torch.cuda.synchronize()
