@@ -50,9 +50,9 @@ typedef struct kasf_config {
 } kasf_config;
 
 const char* kasf_last_error(void);
-/* Process-wide: 1 = the three branches of a layer run back to back on the caller's stream instead of on three streams.  Every gradient is then
- * bit-reproducible from run to run in both arithmetic modes (fp32 mode is with three streams as well); costs about 4 % of the training throughput.
- * Default 0 (or 1 when KASF_SINGLE_STREAM is set in the environment).  Call between steps, not while a forward / backward is being enqueued. */
+/* Process-wide: 1 = the three branches of a layer run back to back on the caller's stream instead of on three streams (the mode isolated kernel
+ * profiles are taken in; about 4 % of the training throughput).  Gradients are bit-reproducible from run to run either way, and the two settings give
+ * the same bits.  Default 0 (or 1 when KASF_SINGLE_STREAM is set in the environment).  Call between steps, not while a pass is being enqueued. */
 void kasf_set_deterministic(int32_t on);
 int32_t kasf_get_deterministic(void);
 int kasf_version(void);

@@ -34,8 +34,7 @@ struct LayerOff { BlockOff blk[6]; int64_t fus_w, fus_b, begin, end; };
 struct TopOff { int64_t norm_w, norm_b, fc_w, fc_b, head_w, head_b, p_fc, p_fcT, begin, end; };
 
 // The three branches of a layer run on three streams unless this is set: kasf_set_deterministic(1) (or KASF_SINGLE_STREAM=1 in the environment, read once)
-// runs them back to back on the caller's stream.  That is the mode in which bf16 gradients are bit-reproducible from run to run (see
-// tests/test_gpu_determinism.py for what is not with three streams), and the mode the isolated per-kernel profiles are taken in; -4 % throughput.
+// runs them back to back on the caller's stream: same results bit for bit, the mode the isolated per-kernel profiles are taken in; -4 % throughput.
 static int g_single_stream = -1;
 static bool single_stream() {
     if (g_single_stream < 0) g_single_stream = getenv("KASF_SINGLE_STREAM") != nullptr ? 1 : 0;
