@@ -14,6 +14,7 @@
 // Backward runs two passes per (group, head): pass 1 with lane = query (softmax statistics, delta, dQ), pass 2
 // with lane = key (S and dP recomputed un-transposed; dK, dV), exchanging only 3 floats per query through LDS.
 #include <cstdlib>
+#include <type_traits>
 #include "common.h"
 #include "kernels.h"
 
@@ -591,6 +592,136 @@ __global__ __launch_bounds__(512, 2) void k_attn_bwd_kt(const bf16* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Backward for groups of 97..256 positions (temporal attention of the long-clip configurations, T = 243), plain operator interface (d_o is read, nothing
+// comes from the forward), one wave per (group, head).  Neither loop order of the kernels above fits: query-tile-outer keeps 32 NKT accumulator registers
+// of dK / dV, key-tile-outer 16 NKT of dQ next to the score tiles.  Two passes over the head's tiles instead, each in the orientation whose products
+// need no transposed P or dS:
+//   pass A, lane = query (per query tile):  S^T = K . (Q/4)^T for every key tile (16 NKT registers), softmax statistics, delta = sum_keys P . dP with
+//           dP^T = V . d_o^T, then dS^T = P (dP - delta) tile by tile (dP formed again: one MFMA instead of 16 NKT more live registers) and
+//           dQ^T += K^T . dS^T with the operand straight out of the registers;  lse and delta of the query are left in LDS;
+//   pass B, lane = key (key-tile-outer):    S = (Q/4) . K^T and dP = d_o . V^T un-transposed, P = exp(S - lse), dS = P (dP - delta), and
+//           dV^T += d_o^T . P, dK^T += (Q/4)^T . dS again out of the registers: 32 accumulator registers, nothing written to LDS.
+// 11 MFMAs and two exponentials per 32 x 32 tile pair against the 8 + 1 of k_attn_bwd_kt (which needs the forward's lse and o and whole groups in LDS),
+// no block of P or dS ever goes through LDS, and the register count does not grow with the group in pass B and by 16 per tile in pass A.
+// LDS per wave: the K, V, Q/4, d_o tiles of the head (4 x NKT KB) + lse / delta.
+// ---------------------------------------------------------------------------------------------------------------
+template <int NKT>
+__global__ __launch_bounds__(256) void k_attn_bwd_2p(const bf16* __restrict__ Q, int64_t ldq, const bf16* __restrict__ K, const bf16* __restrict__ V,
+                                                     int64_t ldkv, const bf16* __restrict__ dO, bf16* __restrict__ dQ, int64_t lddq, bf16* __restrict__ dK,
+                                                     bf16* __restrict__ dV, int64_t lddkv, int L, int Tn, int mode, int units) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TILE = NKT * 32 * 16;                           // [positions][16] operand tile (bf16 elements)
+    constexpr int WAVE_BYTES = 4 * TILE * 2 + 2 * NKT * 32 * 4;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
+    const int unit = blockIdx.x * 4 + wave;
+    if (unit >= units) return;                                    // wave-uniform; no workgroup barrier below
+    const int G = unit >> 3, h = unit & 7;
+    bf16* sK = reinterpret_cast<bf16*>(smem + wave * WAVE_BYTES);
+    bf16* sV = sK + TILE;
+    bf16* sQ = sV + TILE;                                         // Q / 4 (a power of two: exact in bf16)
+    bf16* sD = sQ + TILE;
+    float* sLse = reinterpret_cast<float*>(sD + TILE);            // [32 NKT]
+    float* sDel = sLse + NKT * 32;
+    const int nt = (L + 31) >> 5;                                 // live 32-position tiles
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) {
+        if (t >= nt) break;
+        const int pos = 32 * t + r;
+        row_frag(K, ldkv, G, pos, L, Tn, mode, h, hh, sK);
+        row_frag(V, ldkv, G, pos, L, Tn, mode, h, hh, sV);
+        row_frag(dO, 128, G, pos, L, Tn, mode, h, hh, sD);
+        bf16x8 qv = row_frag(Q, ldq, G, pos, L, Tn, mode, h, hh, nullptr);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qv[e] = (bf16)((float)qv[e] * 0.25f);
+        *reinterpret_cast<bf16x8*>(sQ + pos * 16 + 8 * hh) = qv;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // the tiles were written by other lanes of this wave
+    auto rowf = [&](const bf16* tile, int t) { return *reinterpret_cast<const bf16x8*>(tile + (32 * t + r) * 16 + 8 * hh); };
+    // ---------------- pass A: lane = query ----------------
+    for (int qt = 0; qt < nt; ++qt) {
+        const int i = 32 * qt + r;
+        const bf16x8 qf = rowf(sQ, qt), dfq = rowf(sD, qt);
+        f32x16 st[NKT];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            if (kt >= nt) break;
+            st[kt] = mfma32(rowf(sK, kt), qf, zero16());          // S^T[key][query] / 4
+            if (kt == nt - 1) {
+#pragma unroll
+                for (int g = 0; g < 16; ++g) st[kt][g] = (32 * kt + pos_of(g, hh) < L) ? st[kt][g] : -INFINITY;
+            }
+#pragma unroll
+            for (int g = 0; g < 16; ++g) mx = fmaxf(mx, st[kt][g]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            if (kt >= nt) break;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) { st[kt][g] = __expf(st[kt][g] - mx); sum += st[kt][g]; }
+        }
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.0f / sum;
+        float delta = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            if (kt >= nt) break;
+            const f32x16 dp = mfma32(rowf(sV, kt), dfq, zero16());       // dP^T[key][query] = sum_d V[key][d] d_o[query][d]
+#pragma unroll
+            for (int g = 0; g < 16; ++g) { st[kt][g] *= inv; delta += st[kt][g] * dp[g]; }
+        }
+        delta += __shfl_xor(delta, 32);
+        if (hh == 0) { sLse[i] = i < L ? mx + __logf(sum) : INFINITY; sDel[i] = delta; }   // rows past L: exp(s - inf) = 0 keeps them out of pass B
+        f32x16 dq = zero16();
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            if (kt >= nt) break;
+            const f32x16 dp = mfma32(rowf(sV, kt), dfq, zero16());
+#pragma unroll
+            for (int g = 0; g < 16; ++g) st[kt][g] = st[kt][g] * (dp[g] - delta) * 0.25f;          // dS^T (scale folded)
+            dq = mfma32(tr_frag(sK, 2 * kt), pack8(st[kt], 0), dq);                                // dQ^T[d][query] += K^T . dS^T
+            dq = mfma32(tr_frag(sK, 2 * kt + 1), pack8(st[kt], 1), dq);
+        }
+        if (i < L) store_t(dQ + tok_of(G, i, Tn, mode) * lddq + h * 16, dq, hh);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // lse / delta were written by other lanes of this wave
+    // ---------------- pass B: lane = key, key-tile-outer ----------------
+    for (int kt = 0; kt < nt; ++kt) {
+        const bf16x8 kfk = rowf(sK, kt), vfk = rowf(sV, kt);
+        f32x16 dv = zero16(), dk = zero16();
+        for (int qt = 0; qt < nt; ++qt) {
+            f32x4 l4[4], d4[4];
+#pragma unroll
+            for (int a4 = 0; a4 < 4; ++a4) {                      // registers 4a .. 4a+3 = queries 32 qt + 8a + 4hh + {0..3}
+                l4[a4] = *reinterpret_cast<const f32x4*>(sLse + 32 * qt + 8 * a4 + 4 * hh);
+                d4[a4] = *reinterpret_cast<const f32x4*>(sDel + 32 * qt + 8 * a4 + 4 * hh);
+            }
+            const bf16x8 dt0 = tr_frag(sD, 2 * qt), dt1 = tr_frag(sD, 2 * qt + 1), qt0 = tr_frag(sQ, 2 * qt), qt1 = tr_frag(sQ, 2 * qt + 1);
+            f32x16 p = mfma32(rowf(sQ, qt), kfk, zero16());       // S[query][key] / 4: lane = key, registers = queries
+            f32x16 ds = mfma32(rowf(sD, qt), vfk, zero16());      // dP[query][key]
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const float pv = __expf(p[g] - l4[g >> 2][g & 3]);
+                p[g] = pv;
+                ds[g] = pv * (ds[g] - d4[g >> 2][g & 3]);
+            }
+            dv = mfma32(dt0, pack8(p, 0), dv);                    // dV^T[d][key] += d_o^T . P
+            dk = mfma32(qt0, pack8(ds, 0), dk);                   // dK^T[d][key] += (Q / 4)^T . dS
+            dv = mfma32(dt1, pack8(p, 1), dv);
+            dk = mfma32(qt1, pack8(ds, 1), dk);
+        }
+        const int j = 32 * kt + r;
+        if (j < L) {
+            const int64_t tok = tok_of(G, j, Tn, mode);
+            store_t(dV + tok * lddkv + h * 16, dv, hh);
+            store_t(dK + tok * lddkv + h * 16, dk, hh);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Persistent form of k_attn_bwd_mfma<1, true> (groups of <= 32 positions, d_o formed in-kernel): the same arithmetic, bit for bit, but
 //   * a workgroup walks a contiguous range of groups: the 16 rows of the packed projection weight a wave needs stay in registers for the
 //     whole launch (the one-group-per-workgroup form re-read 32 KB of weights per group: 221 MB of L2 traffic per launch, more than the
@@ -753,8 +884,10 @@ __global__ __launch_bounds__(512, 4) void k_attn_bwd_pers(const bf16* __restrict
     flush(g0 + ng - 1);
 }
 
-template <typename K> void set_smem(K k, size_t bytes) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+template <typename K> bool set_smem(K k, size_t bytes) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) kasf_set_error(1000 + (int)e, "attention (MFMA): cannot reserve the group's LDS tiles");
+    return e == hipSuccess;
 }
 
 }  // namespace
@@ -762,29 +895,45 @@ template <typename K> void set_smem(K k, size_t bytes) {
 // returns false when the shape is outside the MFMA kernels' range (caller falls back to the VALU kernels)
 bool kasf_launch_attn_fwd_mfma(hipStream_t s, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, void* o, int B, int Tn, int mode) {
     const int L = mode == 0 ? KASF_J : Tn, groups = mode == 0 ? B * Tn : B * KASF_J, units = groups * 8;
-    if (L > 96) return false;
+    if (L > 256) return false;
     const dim3 grid((units + 3) / 4);
-    if (L <= 32) {
-        hipLaunchKernelGGL(k_attn_fwd_mfma<1>, grid, dim3(256), 4 * 1 * 32 * 16 * 2, s, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldkv, (bf16*)o, L,
+    auto go = [&](auto NK) {                            // all score tiles of a query tile stay in registers (16 per key tile): 8 tiles = 128 VGPRs
+        constexpr int NKT = decltype(NK)::value;
+        hipLaunchKernelGGL(k_attn_fwd_mfma<NKT>, grid, dim3(256), 4 * NKT * 32 * 16 * 2, s, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldkv, (bf16*)o, L,
                            Tn, mode, units);
-    } else {
-        hipLaunchKernelGGL(k_attn_fwd_mfma<3>, grid, dim3(256), 4 * 3 * 32 * 16 * 2, s, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldkv, (bf16*)o, L,
-                           Tn, mode, units);
-    }
+    };
+    if (L <= 32) go(std::integral_constant<int, 1>{});
+    else if (L <= 96) go(std::integral_constant<int, 3>{});
+    else if (L <= 128) go(std::integral_constant<int, 4>{});
+    else if (L <= 192) go(std::integral_constant<int, 6>{});
+    else go(std::integral_constant<int, 8>{});
     return true;
 }
 bool kasf_launch_attn_bwd_mfma(hipStream_t s, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, const void* d_o, void* dq,
                                int64_t lddq, void* dk, void* dv, int64_t lddkv, int B, int Tn, int mode) {
     const int L = mode == 0 ? KASF_J : Tn, groups = mode == 0 ? B * Tn : B * KASF_J, units = groups * 8;
-    if (L > 96) return false;
+    if (L > 256) return false;
     const dim3 grid((units + 3) / 4);
+    if (L > 96) {                                       // two-pass kernel: 4 NKT KB of operand tiles + lse / delta per wave
+        auto go = [&](auto NK) {
+            constexpr int NKT = decltype(NK)::value;
+            const size_t sh2 = 4 * (size_t)(4 * NKT * 32 * 16 * 2 + 2 * NKT * 32 * 4);
+            if (!set_smem(k_attn_bwd_2p<NKT>, sh2)) return;
+            hipLaunchKernelGGL(k_attn_bwd_2p<NKT>, grid, dim3(256), sh2, s, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldkv, (const bf16*)d_o, (bf16*)dq,
+                               lddq, (bf16*)dk, (bf16*)dv, lddkv, L, Tn, mode, units);
+        };
+        if (L <= 128) go(std::integral_constant<int, 4>{});
+        else if (L <= 192) go(std::integral_constant<int, 6>{});
+        else go(std::integral_constant<int, 8>{});
+        return true;
+    }
     if (L <= 32) {
         const size_t sh = 4 * (3 * 32 * 16 * 2 + 32 * 16 + 2 * 32 * 32 * 2);
         hipLaunchKernelGGL((k_attn_bwd_mfma<1, false>), grid, dim3(256), sh, s, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldkv, (const bf16*)d_o,
                            (bf16*)dq, lddq, (bf16*)dk, (bf16*)dv, lddkv, L, Tn, mode, units, (const bf16*)nullptr, (const bf16*)nullptr);
     } else {
         const size_t shl = 4 * (size_t)(4 * 96 * 16 + 2 * 32 * 32) * 2;
-        set_smem(k_attn_bwd_long<3, false>, shl);
+        if (!set_smem(k_attn_bwd_long<3, false>, shl)) return true;
         hipLaunchKernelGGL((k_attn_bwd_long<3, false>), grid, dim3(256), shl, s, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldkv, (const bf16*)d_o,
                            (bf16*)dq, lddq, (bf16*)dk, (bf16*)dv, lddkv, L, Tn, mode, units, (const bf16*)nullptr, (const bf16*)nullptr);
     }
@@ -804,18 +953,18 @@ bool kasf_launch_attn_bwd_fused_do(hipStream_t s, const void* q, int64_t ldq, co
         if (o_saved != nullptr && lse != nullptr) {     // key-tile-outer kernel: statistics and delta from what the forward left behind
             const size_t shk = 8 * (size_t)(3 * 96 * 16 * 2 + 2 * 32 * KT_LD * 2 + 2 * 96 * 4) + (size_t)96 * 128 * 2;
             if (L > 64 && L <= 81) {                    // last tile of at most 17 positions: 7 of its 16 query registers are dead
-                set_smem(k_attn_bwd_kt<3, 9>, shk);
+                if (!set_smem(k_attn_bwd_kt<3, 9>, shk)) return true;
                 hipLaunchKernelGGL((k_attn_bwd_kt<3, 9>), dim3(groups), dim3(512), shk, s, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldkv, (const bf16*)o_saved, lse,
                                    (bf16*)dq, lddq, (bf16*)dk, (bf16*)dv, lddkv, L, Tn, mode, (const bf16*)g_mid, (const bf16*)WprojTs);
             } else {
-                set_smem(k_attn_bwd_kt<3, 16>, shk);
+                if (!set_smem(k_attn_bwd_kt<3, 16>, shk)) return true;
                 hipLaunchKernelGGL((k_attn_bwd_kt<3, 16>), dim3(groups), dim3(512), shk, s, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldkv, (const bf16*)o_saved, lse,
                                    (bf16*)dq, lddq, (bf16*)dk, (bf16*)dv, lddkv, L, Tn, mode, (const bf16*)g_mid, (const bf16*)WprojTs);
             }
             return true;
         }
         const size_t shl = 8 * (size_t)(4 * 96 * 16 + 2 * 32 * 32) * 2 + (size_t)96 * 128 * 2;
-        set_smem(k_attn_bwd_long<3, true>, shl);
+        if (!set_smem(k_attn_bwd_long<3, true>, shl)) return true;
         hipLaunchKernelGGL((k_attn_bwd_long<3, true>), dim3(groups), dim3(512), shl, s, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldkv, (const bf16*)nullptr,
                            (bf16*)dq, lddq, (bf16*)dk, (bf16*)dv, lddkv, L, Tn, mode, groups * 8, (const bf16*)g_mid, (const bf16*)WprojTs);
         return true;
@@ -824,18 +973,18 @@ bool kasf_launch_attn_bwd_fused_do(hipStream_t s, const void* q, int64_t ldq, co
         const size_t shp = 8 * (3 * 32 * 16 * 2 + 2 * 32 * 32 * 2) + 2 * 32 * 128 * 2;
         const dim3 grid(groups < 512 ? groups : 512);   // two workgroups per CU
         if (L <= 17) {
-            set_smem(k_attn_bwd_pers<9>, shp);
+            if (!set_smem(k_attn_bwd_pers<9>, shp)) return true;
             hipLaunchKernelGGL(k_attn_bwd_pers<9>, grid, dim3(512), shp, s, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldkv, (bf16*)dq, lddq, (bf16*)dk,
                                (bf16*)dv, lddkv, L, Tn, mode, groups, (const bf16*)g_mid, (const bf16*)WprojTs);
         } else {
-            set_smem(k_attn_bwd_pers<16>, shp);
+            if (!set_smem(k_attn_bwd_pers<16>, shp)) return true;
             hipLaunchKernelGGL(k_attn_bwd_pers<16>, grid, dim3(512), shp, s, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldkv, (bf16*)dq, lddq, (bf16*)dk,
                                (bf16*)dv, lddkv, L, Tn, mode, groups, (const bf16*)g_mid, (const bf16*)WprojTs);
         }
         return true;
     }
     const size_t sh = 8 * (3 * 32 * 16 * 2 + 32 * 16 + 2 * 32 * 32 * 2) + 32 * 128 * 2;
-    set_smem(k_attn_bwd_mfma<1, true>, sh);
+    if (!set_smem(k_attn_bwd_mfma<1, true>, sh)) return true;
     hipLaunchKernelGGL((k_attn_bwd_mfma<1, true>), dim3(groups), dim3(512), sh, s, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldkv,
                        (const bf16*)nullptr, (bf16*)dq, lddq, (bf16*)dk, (bf16*)dv, lddkv, L, Tn, mode, groups * 8, (const bf16*)g_mid, (const bf16*)WprojTs);
     return true;

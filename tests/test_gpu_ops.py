@@ -227,7 +227,9 @@ def test_dgrad_lnbwd(lib, cd, M, Kd, use_add, use_resid, accumulate, want_xn):
 
 
 @pytest.mark.parametrize("cd", ["fp32", "bf16"])
-@pytest.mark.parametrize("mode,T", [(0, 27), (1, 27), (1, 81), (1, 9)])
+@pytest.mark.parametrize("mode,T", [(0, 27), (1, 27), (1, 81), (1, 9),
+                                    (1, 97), (1, 128), (1, 129), (1, 192), (1, 193), (1, 243), (1, 256),   # bf16: 4 / 6 / 8 score tiles in registers, two-pass backward
+                                    (1, 257)])                                                              # past the MFMA cores: the LDS-resident fp32 kernels
 def test_attention_core(lib, cd, mode, T):
     from kasportsformer_amd import _lib
     from oracle.kasf_oracle import attention_core, _heads
