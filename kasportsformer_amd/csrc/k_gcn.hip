@@ -518,7 +518,7 @@ __global__ __launch_bounds__(256) void k_gcn_bwd2_temporal(const T* __restrict__
 // The instantiations above keep the whole T x T similarity matrix of a track in LDS, which stops fitting near T = 100.  Here S is produced 16
 // rows at a time (same MFMA products, same k order: still bitwise symmetric), the row's threshold / mask / degree are taken from that
 // block, and only the masks (T x MW words) and degrees of the whole track stay resident; the LN(x) tile is then overwritten by the V rows
-// for the aggregation.  One thread scans one row: a plain fallback (T = 243 and friends), not a tuned kernel.
+// for the aggregation.
 template <typename T>
 __global__ __launch_bounds__(256) void k_gcn_agg_temporal_g(const T* __restrict__ uv, const T* __restrict__ xn, T* __restrict__ y,
                                                             uint32_t* __restrict__ mask, double* __restrict__ stats, int L, int MW, int kth, int n_tracks) {
@@ -552,27 +552,62 @@ __global__ __launch_bounds__(256) void k_gcn_agg_temporal_g(const T* __restrict_
                 for (int q = 0; q < 4; ++q) sS[li * (LP + 1) + tn * 16 + 4 * lg + q] = acc[0][0][q];
             }
             __syncthreads();
-            const int r = rb * 16 + (int)threadIdx.x;
-            if (threadIdx.x < 16 && r < L) {
-                const float* row = sS + threadIdx.x * (LP + 1);
+            // k-th largest per row -> adjacency bits and degree (graph.py:104-112: ties kept).  SIXTEEN lanes per row, columns interleaved: each keeps the
+            // four largest of its columns (with multiplicity), four butterfly merges leave the row's four largest in every lane of the group; the wave then
+            // turns its four rows into mask words with one ballot per 64 columns.  (One thread per row scanned 243 columns twice with 240 threads idle:
+            // 1.46 ms per launch at T = 243, B = 32.)
+            {
+                const int rr = threadIdx.x >> 4, jl = threadIdx.x & 15;
+                const float* row = sS + rr * (LP + 1);
                 float top[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-                for (int c = 0; c < L; ++c) {
+                for (int c = jl; c < L; c += 16) {
                     float v = row[c];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (v > top[e]) { const float t = top[e]; top[e] = v; v = t; }
+                    for (int e = 0; e < 4; ++e) {          // compare-exchange as max / min (S is finite)
+                        const float hi = fmaxf(top[e], v);
+                        v = fminf(top[e], v);
+                        top[e] = hi;
+                    }
+                }
+#pragma unroll
+                for (int m = 1; m <= 8; m <<= 1) {
+                    float o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = __shfl_xor(top[e], m);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float v = o[q];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float hi = fmaxf(top[e], v);
+                            v = fminf(top[e], v);
+                            top[e] = hi;
+                        }
                     }
                 }
                 const float thr = kth <= 1 ? top[0] : (kth == 2 ? top[1] : (kth == 3 ? top[2] : top[3]));
-                int deg = 0;
-                for (int wi = 0; wi < MW; ++wi) {
-                    uint32_t wd = 0u;
-                    for (int c = wi * 32; c < L && c < wi * 32 + 32; ++c)
-                        if (row[c] >= thr) { wd |= 1u << (c & 31); ++deg; }
-                    sMask[r * MW + wi] = wd;
-                    mask[((int64_t)G * L + r) * MW + wi] = wd;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {              // the wave's four rows: lanes 16 q .. 16 q + 15 hold row 4 w + q's threshold
+                    const int rloc = 4 * w + q, r = rb * 16 + rloc;
+                    const float thr_q = __shfl(thr, 16 * q);
+                    const float* rowq = sS + rloc * (LP + 1);
+                    int deg = 0;
+                    for (int ch = 0; 2 * ch < MW; ++ch) {                // every word of the row is written (bits past L are zero)
+                        const int c = ch * 64 + lane;
+                        const bool bit = c < L && rowq[c] >= thr_q;
+                        const unsigned long long bal = __ballot(bit);
+                        deg += __popcll(bal);
+                        if (lane == 0 && r < L) {
+                            sMask[r * MW + 2 * ch] = (uint32_t)bal;
+                            mask[((int64_t)G * L + r) * MW + 2 * ch] = (uint32_t)bal;
+                            if (2 * ch + 1 < MW) {
+                                sMask[r * MW + 2 * ch + 1] = (uint32_t)(bal >> 32);
+                                mask[((int64_t)G * L + r) * MW + 2 * ch + 1] = (uint32_t)(bal >> 32);
+                            }
+                        }
+                    }
+                    if (lane == 0 && r < L) sDinv[r] = 1.0f / sqrtf((float)deg);
                 }
-                sDinv[r] = 1.0f / sqrtf((float)deg);
             }
             __syncthreads();
         }
@@ -641,14 +676,36 @@ __global__ __launch_bounds__(256) void k_gcn_bwd2_temporal_g(const T* __restrict
         sDinv[r] = 1.0f / sqrtf((float)deg);
     }
     __syncthreads();
+    // the bit matrix transposed once per track with wave ballots (lane = row), then set bits only, in ascending row order -- as k_gcn_bwd2_temporal does
+    // (testing all L rows per (column, chunk) item was 0.7 ms per launch at T = 243, B = 32)
+    uint32_t* sMaskT = sMask + L * MW;                  // [L][MW]: bit r of column c's words
+    {
+        const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        for (int c = w; c < L; c += 4) {
+            for (int h = 0; 2 * h < MW; ++h) {
+                const int r = 64 * h + lane;
+                const bool bit = r < L && ((sMask[r * MW + (c >> 5)] >> (c & 31)) & 1u);
+                const unsigned long long bal = __ballot(bit);
+                if (lane == 0) {
+                    sMaskT[c * MW + 2 * h] = (uint32_t)bal;
+                    if (2 * h + 1 < MW) sMaskT[c * MW + 2 * h + 1] = (uint32_t)(bal >> 32);
+                }
+            }
+        }
+    }
+    __syncthreads();
     for (int idx = threadIdx.x; idx < L * 16; idx += 256) {
         const int c = idx >> 4, sub = idx & 15;
         float acc[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-        for (int r = 0; r < L; ++r) {
-            if ((sMask[r * MW + (c >> 5)] >> (c & 31)) & 1u) {
-                const float wgt = sDinv[r] * sDinv[c];
+        const float dc = sDinv[c];
+        for (int wi = 0; wi < MW; ++wi) {
+            uint32_t bits = sMaskT[c * MW + wi];
+            while (bits) {
+                const int r = wi * 32 + __builtin_ctz(bits);
+                bits &= bits - 1;
+                const float wgt = sDinv[r] * dc;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) acc[e] += wgt * sDy[r * SX_LD + sub * 8 + e];
             }
@@ -719,7 +776,7 @@ void bwd2_T(hipStream_t s, const void* r, const void* y, const float* coef, cons
     else if (Tn == 9) bwd2_temporal_TL<T, 9>(s, r, y, coef, mask, duv, B, Tn, bstats, d_w, d_b, count, training);
     else {
         const int MW = kasf_gcn_mask_words(Tn);
-        const size_t sh = (size_t)(Tn * SX_LD + Tn) * sizeof(float) + (size_t)Tn * MW * sizeof(uint32_t);
+        const size_t sh = (size_t)(Tn * SX_LD + Tn) * sizeof(float) + (size_t)2 * Tn * MW * sizeof(uint32_t);
         set_smem(k_gcn_bwd2_temporal_g<T>, sh);
         hipLaunchKernelGGL((k_gcn_bwd2_temporal_g<T>), dim3(B * KASF_J), dim3(256), sh, s, (const T*)r, (const T*)y, coef, mask, (T*)duv, Tn, MW, bstats, d_w,
                            d_b, count, training);

@@ -425,7 +425,7 @@ def _mask_agreement(cd, L, T, B, seed):
     return rows, mismatched, near_tie_rows, unexplained, 100.0 * bits_equal / bits
 
 
-@pytest.mark.parametrize("L,T,B", [(2, 27, 3), (1, 81, 2), (1, 9, 4), (1, 243, 1), (1, 100, 1), (1, 5, 2)])
+@pytest.mark.parametrize("L,T,B", [(2, 27, 3), (1, 81, 2), (1, 9, 4), (1, 243, 1), (1, 100, 1), (1, 5, 2), (1, 50, 2), (1, 256, 1)])
 def test_temporal_topk_adjacency_masks_fp32_bit_exact(L, T, B):
     """fp32 mode: the stored adjacency bit masks equal torch's `sim >= topk(sim, 4)[..., -1:]` (graph.py:104-112) row for row.  The only rows
     allowed to differ are exact near-ties of the ORACLE's own similarities (4th and 5th largest within summation-order noise)."""
@@ -513,7 +513,7 @@ def test_full_depth_26_layers_against_oracle(cd):
         assert err < 0.2 and cosine > 0.92
 
 
-@pytest.mark.parametrize("T,B", [(243, 1), (100, 2), (33, 2), (5, 3), (4, 8), (64, 2), (96, 2), (32, 2)])      # 64 / 96: the three-tile fused temporal forward with an empty / a full last tile; 32: the largest one-tile group
+@pytest.mark.parametrize("T,B", [(243, 1), (100, 2), (33, 2), (5, 3), (4, 8), (64, 2), (96, 2), (32, 2), (130, 1), (200, 1), (256, 1), (50, 2)])      # 64 / 96: the three-tile fused temporal forward with an empty / a full last tile; 32: the largest one-tile group
 @pytest.mark.parametrize("cd,tol", [("fp32", 2e-3), ("bf16", 0.4)])      # bf16, a handful of clips: observed 0.04-0.30 on the worst (tiny) tensor, cosine >= 0.99977, forward 1.2e-2
 def test_arbitrary_clip_lengths(cd, tol, T, B):
     """The reference builds for any n_frames (KASportsFormer.py:291-295, README.md:59): 243 is the long configuration of this model family;
