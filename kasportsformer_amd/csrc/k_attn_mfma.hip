@@ -603,44 +603,51 @@ __global__ __launch_bounds__(512, 2) void k_attn_bwd_kt(const bf16* __restrict__
 //           dV^T += d_o^T . P, dK^T += (Q/4)^T . dS again out of the registers: 32 accumulator registers, nothing written to LDS.
 // 11 MFMAs and two exponentials per 32 x 32 tile pair against the 8 + 1 of k_attn_bwd_kt (which needs the forward's lse and o and whole groups in LDS),
 // no block of P or dS ever goes through LDS, and the register count does not grow with the group in pass B and by 16 per tile in pass A.
-// LDS per wave: the K, V, Q/4, d_o tiles of the head (4 x NKT KB) + lse / delta.
+// LDS per wave: 2 x NKT KB of operand tiles + lse / delta -- only what is read TRANSPOSED lives there (K in pass A; Q/4 and d_o in pass B, Q/4 taking
+// K's place between the passes); V stays in registers through pass A, and the row fragments each pass needs once per tile come straight from memory
+// (prefetched a tile ahead).  At 256 positions that is 18 KB per wave: two workgroups per CU, two waves per SIMD (all four tiles resident: one, and one
+// wave per SIMD issues a vector instruction every ~5 cycles at best -- the launch was 478 us at T = 243, B = 32).
 // ---------------------------------------------------------------------------------------------------------------
 template <int NKT>
-__global__ __launch_bounds__(256) void k_attn_bwd_2p(const bf16* __restrict__ Q, int64_t ldq, const bf16* __restrict__ K, const bf16* __restrict__ V,
-                                                     int64_t ldkv, const bf16* __restrict__ dO, bf16* __restrict__ dQ, int64_t lddq, bf16* __restrict__ dK,
-                                                     bf16* __restrict__ dV, int64_t lddkv, int L, int Tn, int mode, int units) {
+__global__ __launch_bounds__(256, 2) void k_attn_bwd_2p(const bf16* __restrict__ Q, int64_t ldq, const bf16* __restrict__ K, const bf16* __restrict__ V,
+                                                        int64_t ldkv, const bf16* __restrict__ dO, bf16* __restrict__ dQ, int64_t lddq, bf16* __restrict__ dK,
+                                                        bf16* __restrict__ dV, int64_t lddkv, int L, int Tn, int mode, int units) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TILE = NKT * 32 * 16;                           // [positions][16] operand tile (bf16 elements)
-    constexpr int WAVE_BYTES = 4 * TILE * 2 + 2 * NKT * 32 * 4;
+    constexpr int WAVE_BYTES = 2 * TILE * 2 + 2 * NKT * 32 * 4;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
     const int unit = blockIdx.x * 4 + wave;
     if (unit >= units) return;                                    // wave-uniform; no workgroup barrier below
     const int G = unit >> 3, h = unit & 7;
-    bf16* sK = reinterpret_cast<bf16*>(smem + wave * WAVE_BYTES);
-    bf16* sV = sK + TILE;
-    bf16* sQ = sV + TILE;                                         // Q / 4 (a power of two: exact in bf16)
-    bf16* sD = sQ + TILE;
+    bf16* sK = reinterpret_cast<bf16*>(smem + wave * WAVE_BYTES); // pass A: K;  pass B: Q / 4 (a power of two: exact in bf16)
+    bf16* sQ = sK;
+    bf16* sD = sK + TILE;
     float* sLse = reinterpret_cast<float*>(sD + TILE);            // [32 NKT]
     float* sDel = sLse + NKT * 32;
     const int nt = (L + 31) >> 5;                                 // live 32-position tiles
+    auto q4 = [&](int t) {                                        // row fragment of Q / 4 from memory
+        bf16x8 qv = row_frag(Q, ldq, G, 32 * t + r, L, Tn, mode, h, hh, nullptr);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qv[e] = (bf16)((float)qv[e] * 0.25f);
+        return qv;
+    };
+    bf16x8 vf[NKT];
 #pragma unroll
     for (int t = 0; t < NKT; ++t) {
         if (t >= nt) break;
         const int pos = 32 * t + r;
         row_frag(K, ldkv, G, pos, L, Tn, mode, h, hh, sK);
-        row_frag(V, ldkv, G, pos, L, Tn, mode, h, hh, sV);
         row_frag(dO, 128, G, pos, L, Tn, mode, h, hh, sD);
-        bf16x8 qv = row_frag(Q, ldq, G, pos, L, Tn, mode, h, hh, nullptr);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) qv[e] = (bf16)((float)qv[e] * 0.25f);
-        *reinterpret_cast<bf16x8*>(sQ + pos * 16 + 8 * hh) = qv;
+        vf[t] = row_frag(V, ldkv, G, pos, L, Tn, mode, h, hh, nullptr);
     }
+    bf16x8 qf_n = q4(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // the tiles were written by other lanes of this wave
     auto rowf = [&](const bf16* tile, int t) { return *reinterpret_cast<const bf16x8*>(tile + (32 * t + r) * 16 + 8 * hh); };
     // ---------------- pass A: lane = query ----------------
     for (int qt = 0; qt < nt; ++qt) {
         const int i = 32 * qt + r;
-        const bf16x8 qf = rowf(sQ, qt), dfq = rowf(sD, qt);
+        const bf16x8 qf = qf_n, dfq = rowf(sD, qt);
+        if (qt + 1 < nt) qf_n = q4(qt + 1);
         f32x16 st[NKT];
         float mx = -INFINITY;
 #pragma unroll
@@ -668,7 +675,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_2p(const bf16* __restrict__ Q,
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
             if (kt >= nt) break;
-            const f32x16 dp = mfma32(rowf(sV, kt), dfq, zero16());       // dP^T[key][query] = sum_d V[key][d] d_o[query][d]
+            const f32x16 dp = mfma32(vf[kt], dfq, zero16());      // dP^T[key][query] = sum_d V[key][d] d_o[query][d]
 #pragma unroll
             for (int g = 0; g < 16; ++g) { st[kt][g] *= inv; delta += st[kt][g] * dp[g]; }
         }
@@ -678,7 +685,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_2p(const bf16* __restrict__ Q,
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
             if (kt >= nt) break;
-            const f32x16 dp = mfma32(rowf(sV, kt), dfq, zero16());
+            const f32x16 dp = mfma32(vf[kt], dfq, zero16());
 #pragma unroll
             for (int g = 0; g < 16; ++g) st[kt][g] = st[kt][g] * (dp[g] - delta) * 0.25f;          // dS^T (scale folded)
             dq = mfma32(tr_frag(sK, 2 * kt), pack8(st[kt], 0), dq);                                // dQ^T[d][query] += K^T . dS^T
@@ -686,10 +693,21 @@ __global__ __launch_bounds__(256) void k_attn_bwd_2p(const bf16* __restrict__ Q,
         }
         if (i < L) store_t(dQ + tok_of(G, i, Tn, mode) * lddq + h * 16, dq, hh);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // lse / delta were written by other lanes of this wave
+    // between the passes Q / 4 takes K's place (same-wave LDS requests are served in issue order: the stores land behind pass A's last reads)
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) {
+        if (t >= nt) break;
+        *reinterpret_cast<bf16x8*>(sQ + (32 * t + r) * 16 + 8 * hh) = q4(t);
+    }
+    bf16x8 kf_n = row_frag(K, ldkv, G, r, L, Tn, mode, h, hh, nullptr), vf_n = vf[0];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // Q / 4, lse and delta were written by other lanes of this wave
     // ---------------- pass B: lane = key, key-tile-outer ----------------
     for (int kt = 0; kt < nt; ++kt) {
-        const bf16x8 kfk = rowf(sK, kt), vfk = rowf(sV, kt);
+        const bf16x8 kfk = kf_n, vfk = vf_n;
+        if (kt + 1 < nt) {
+            kf_n = row_frag(K, ldkv, G, 32 * (kt + 1) + r, L, Tn, mode, h, hh, nullptr);
+            vf_n = row_frag(V, ldkv, G, 32 * (kt + 1) + r, L, Tn, mode, h, hh, nullptr);
+        }
         f32x16 dv = zero16(), dk = zero16();
         for (int qt = 0; qt < nt; ++qt) {
             f32x4 l4[4], d4[4];
@@ -914,10 +932,10 @@ bool kasf_launch_attn_bwd_mfma(hipStream_t s, const void* q, int64_t ldq, const 
     const int L = mode == 0 ? KASF_J : Tn, groups = mode == 0 ? B * Tn : B * KASF_J, units = groups * 8;
     if (L > 256) return false;
     const dim3 grid((units + 3) / 4);
-    if (L > 96) {                                       // two-pass kernel: 4 NKT KB of operand tiles + lse / delta per wave
+    if (L > 96) {                                       // two-pass kernel: 2 NKT KB of operand tiles + lse / delta per wave
         auto go = [&](auto NK) {
             constexpr int NKT = decltype(NK)::value;
-            const size_t sh2 = 4 * (size_t)(4 * NKT * 32 * 16 * 2 + 2 * NKT * 32 * 4);
+            const size_t sh2 = 4 * (size_t)(2 * NKT * 32 * 16 * 2 + 2 * NKT * 32 * 4);
             if (!set_smem(k_attn_bwd_2p<NKT>, sh2)) return;
             hipLaunchKernelGGL(k_attn_bwd_2p<NKT>, grid, dim3(256), sh2, s, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldkv, (const bf16*)d_o, (bf16*)dq,
                                lddq, (bf16*)dk, (bf16*)dv, lddkv, L, Tn, mode, units);
