@@ -515,10 +515,13 @@ __global__ __launch_bounds__(256) void k_gcn_bwd2_temporal(const T* __restrict__
 }
 
 // ------------------------------------------------------------------ temporal aggregate / backward for ANY number of frames (4 <= T <= 256)
-// The instantiations above keep the whole T x T similarity matrix of a track in LDS, which stops fitting near T = 100.  Here S is produced 16
-// rows at a time (same MFMA products, same k order: still bitwise symmetric), the row's threshold / mask / degree are taken from that
-// block, and only the masks (T x MW words) and degrees of the whole track stay resident; the LN(x) tile is then overwritten by the V rows
-// for the aggregation.
+// The instantiations above keep the whole T x T similarity matrix of a track in LDS, which stops fitting near T = 100.  Here S never leaves the
+// registers: a wave owns 16-row blocks of the track, runs the same MFMA products in the same k order (S stays bitwise symmetric) against every
+// 16-column tile -- lane (row li, group lg) ends up with its row's columns 16 tn + 4 lg + {0..3}, up to 64 values --, keeps the four largest as they
+// come, merges them across the row's four lanes, and turns the kept values into mask words (the two tiles of a word OR-ed across the four lanes).
+// No similarity tile in LDS, no barrier per row block; only the masks (T x MW words) and degrees of the track stay resident, and the LN(x) tile is then
+// overwritten by the V rows for the aggregation.  (First version: S through LDS 16 rows at a time and one thread scanning each row: 1.46 ms per launch
+// at T = 243, B = 32; 16 lanes per row + ballots: 0.35 ms.)
 template <typename T>
 __global__ __launch_bounds__(256) void k_gcn_agg_temporal_g(const T* __restrict__ uv, const T* __restrict__ xn, T* __restrict__ y,
                                                             uint32_t* __restrict__ mask, double* __restrict__ stats, int L, int MW, int kth, int n_tracks) {
@@ -526,8 +529,7 @@ __global__ __launch_bounds__(256) void k_gcn_agg_temporal_g(const T* __restrict_
     const int LP = (L + 15) / 16 * 16, NTL = LP / 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* sX = reinterpret_cast<T*>(smem);                 // [LP][128] swizzled LN(x) rows, later [L][128] linear V rows
-    float* sS = reinterpret_cast<float*>(sX + LP * 128);   // [16][LP+1] one row block of the similarity
-    float* sDinv = sS + 16 * (LP + 1);                  // [L]
+    float* sDinv = reinterpret_cast<float*>(sX + LP * 128);   // [L]
     float* sStat = sDinv + LP;                          // [L][2]
     uint32_t* sMask = reinterpret_cast<uint32_t*>(sStat + 2 * LP);   // [L][MW]
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
@@ -543,74 +545,73 @@ __global__ __launch_bounds__(256) void k_gcn_agg_temporal_g(const T* __restrict_
             *reinterpret_cast<f32x4*>(sX + Tile<T>::chunk_off(r, ch)) = v;
         }
         __syncthreads();
-        for (int rb = 0; rb < NTL; ++rb) {
-            for (int tn = w; tn < NTL; tn += 4) {
-                f32x4 acc[1][1];
-                zero_acc(acc);
-                mma_k128<1, 1>(sX, tn * 16, sX, rb * 16, acc);      // acc[q] = S[row rb*16 + li][col tn*16 + 4*lg + q]
+        for (int rb = w; rb < NTL; rb += 4) {
+            const int r = rb * 16 + li;                 // this lane's row; it sees columns 16 tn + 4 lg + q
+            f32x4 sv[16];
+            float top[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
-                for (int q = 0; q < 4; ++q) sS[li * (LP + 1) + tn * 16 + 4 * lg + q] = acc[0][0][q];
-            }
-            __syncthreads();
-            // k-th largest per row -> adjacency bits and degree (graph.py:104-112: ties kept).  SIXTEEN lanes per row, columns interleaved: each keeps the
-            // four largest of its columns (with multiplicity), four butterfly merges leave the row's four largest in every lane of the group; the wave then
-            // turns its four rows into mask words with one ballot per 64 columns.  (One thread per row scanned 243 columns twice with 240 threads idle:
-            // 1.46 ms per launch at T = 243, B = 32.)
-            {
-                const int rr = threadIdx.x >> 4, jl = threadIdx.x & 15;
-                const float* row = sS + rr * (LP + 1);
-                float top[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-                for (int c = jl; c < L; c += 16) {
-                    float v = row[c];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {          // compare-exchange as max / min (S is finite)
-                        const float hi = fmaxf(top[e], v);
-                        v = fminf(top[e], v);
-                        top[e] = hi;
-                    }
-                }
-#pragma unroll
-                for (int m = 1; m <= 8; m <<= 1) {
-                    float o[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = __shfl_xor(top[e], m);
+            for (int tn = 0; tn < 16; ++tn) {
+                if (tn < NTL) {
+                    f32x4 acc[1][1];
+                    zero_acc(acc);
+                    mma_k128<1, 1>(sX, tn * 16, sX, rb * 16, acc);
+                    sv[tn] = acc[0][0];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        float v = o[q];
+                        float v = tn * 16 + 4 * lg + q < L ? acc[0][0][q] : -INFINITY;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
+                        for (int e = 0; e < 4; ++e) {      // compare-exchange as max / min (S is finite)
                             const float hi = fmaxf(top[e], v);
                             v = fminf(top[e], v);
                             top[e] = hi;
                         }
                     }
                 }
-                const float thr = kth <= 1 ? top[0] : (kth == 2 ? top[1] : (kth == 3 ? top[2] : top[3]));
+            }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {              // the wave's four rows: lanes 16 q .. 16 q + 15 hold row 4 w + q's threshold
-                    const int rloc = 4 * w + q, r = rb * 16 + rloc;
-                    const float thr_q = __shfl(thr, 16 * q);
-                    const float* rowq = sS + rloc * (LP + 1);
-                    int deg = 0;
-                    for (int ch = 0; 2 * ch < MW; ++ch) {                // every word of the row is written (bits past L are zero)
-                        const int c = ch * 64 + lane;
-                        const bool bit = c < L && rowq[c] >= thr_q;
-                        const unsigned long long bal = __ballot(bit);
-                        deg += __popcll(bal);
-                        if (lane == 0 && r < L) {
-                            sMask[r * MW + 2 * ch] = (uint32_t)bal;
-                            mask[((int64_t)G * L + r) * MW + 2 * ch] = (uint32_t)bal;
-                            if (2 * ch + 1 < MW) {
-                                sMask[r * MW + 2 * ch + 1] = (uint32_t)(bal >> 32);
-                                mask[((int64_t)G * L + r) * MW + 2 * ch + 1] = (uint32_t)(bal >> 32);
-                            }
-                        }
+            for (int m = 16; m <= 32; m <<= 1) {           // the row's other three lanes
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = __shfl_xor(top[e], m);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v = o[q];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float hi = fmaxf(top[e], v);
+                        v = fminf(top[e], v);
+                        top[e] = hi;
                     }
-                    if (lane == 0 && r < L) sDinv[r] = 1.0f / sqrtf((float)deg);
                 }
             }
-            __syncthreads();
+            // k-th largest of the row (with multiplicity) -> adjacency bits and degree (graph.py:104-112: ties kept)
+            const float thr = kth <= 1 ? top[0] : (kth == 2 ? top[1] : (kth == 3 ? top[2] : top[3]));
+            int deg = 0;
+#pragma unroll
+            for (int wi = 0; wi < 8; ++wi) {
+                if (wi < MW) {
+                    uint32_t bits = 0u;
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        const int tn = 2 * wi + half;
+                        if (tn < NTL) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                if (tn * 16 + 4 * lg + q < L && sv[tn][q] >= thr) bits |= 1u << (half * 16 + 4 * lg + q);
+                        }
+                    }
+                    bits |= (uint32_t)__shfl_xor((int)bits, 16);
+                    bits |= (uint32_t)__shfl_xor((int)bits, 32);
+                    deg += __popc(bits);
+                    if (lg == 0 && r < L) {
+                        sMask[r * MW + wi] = bits;
+                        mask[((int64_t)G * L + r) * MW + wi] = bits;
+                    }
+                }
+            }
+            if (lg == 0 && r < L) sDinv[r] = 1.0f / sqrtf((float)deg);
         }
+        __syncthreads();
         for (int idx = threadIdx.x; idx < L * CPR; idx += 256) {     // the similarity is done with LN(x): the tile now holds the V rows (linear)
             const int r = idx / CPR, ch = idx % CPR;
             *reinterpret_cast<f32x4*>(sX + r * 128 + ch * EPC) = *reinterpret_cast<const f32x4*>(uv + tok(r) * 256 + 128 + ch * EPC);
@@ -618,7 +619,8 @@ __global__ __launch_bounds__(256) void k_gcn_agg_temporal_g(const T* __restrict_
         __syncthreads();
         for (int idx = threadIdx.x; idx < L * 16; idx += 256) {
             const int r = idx >> 4, sub = idx & 15;
-            float acc[8];
+            float acc[8], u[8];
+            load8(uv + tok(r) * 256 + sub * 8, u);      // (issued ahead of the gather it is added to)
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[e] = 0.f;
             const float dr = sDinv[r];
@@ -634,8 +636,6 @@ __global__ __launch_bounds__(256) void k_gcn_agg_temporal_g(const T* __restrict_
                     for (int e = 0; e < 8; ++e) acc[e] += wgt * v[e];
                 }
             }
-            float u[8];
-            load8(uv + tok(r) * 256 + sub * 8, u);
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) { acc[e] += u[e]; const float q = to_f(from_f<T>(acc[e])); s1 += q; s2 += q * q; }
@@ -758,7 +758,7 @@ void agg_fwd_T(hipStream_t s, const void* uv, const void* xn, void* y, uint32_t*
     else if (Tn == 9) agg_temporal_TL<T, 9>(s, uv, xn, y, mask, stats, B, Tn);
     else {
         const int LP = (Tn + 15) / 16 * 16, MW = kasf_gcn_mask_words(Tn);
-        const size_t sh = (size_t)LP * 128 * sizeof(T) + (size_t)(16 * (LP + 1) + 3 * LP) * sizeof(float) + (size_t)Tn * MW * sizeof(uint32_t);
+        const size_t sh = (size_t)LP * 128 * sizeof(T) + (size_t)(3 * LP) * sizeof(float) + (size_t)Tn * MW * sizeof(uint32_t);
         set_smem(k_gcn_agg_temporal_g<T>, sh);
         const int tracks = B * KASF_J, per = (tracks + 1023) / 1024;
         hipLaunchKernelGGL((k_gcn_agg_temporal_g<T>), dim3((tracks + per - 1) / per), dim3(256), sh, s, (const T*)uv, (const T*)xn, (T*)y, mask, stats, Tn, MW, 4,
