@@ -384,15 +384,18 @@ __global__ __launch_bounds__(256) void k_gcn_bwd1(const T* __restrict__ g, const
 // dy of one 8-channel chunk: BN backward with the finalised per-node means
 // sC: per-node {scale, mean, rstd, c1, c2} in LDS (c1, c2 = the BatchNorm-backward means, derived per workgroup by bwd2_prologue)
 constexpr int C2_LD = 5;
-template <typename T>
-__device__ __forceinline__ void dy_chunk(const T* rbuf, const T* y, const float* sC, int64_t tok, int node, int sub, float (&dy)[8]) {
+__device__ __forceinline__ void dy_math(const float (&r)[8], const float (&c)[8], const float* sC, int node, float (&dy)[8]) {
     const float sc = sC[node * C2_LD], mean = sC[node * C2_LD + 1], rstd = sC[node * C2_LD + 2];
     const float c1 = sC[node * C2_LD + 3], c2 = sC[node * C2_LD + 4];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dy[e] = sc * (r[e] - c1 - (c[e] - mean) * rstd * c2);
+}
+template <typename T>
+__device__ __forceinline__ void dy_chunk(const T* rbuf, const T* y, const float* sC, int64_t tok, int node, int sub, float (&dy)[8]) {
     float r[8], c[8];
     load8(rbuf + tok * 128 + sub * 8, r);
     load8(y + tok * 128 + sub * 8, c);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) dy[e] = sc * (r[e] - c1 - (c[e] - mean) * rstd * c2);
+    dy_math(r, c, sC, node, dy);
 }
 
 // what k_gcn_bwd_finalize did in a one-workgroup launch: every workgroup derives the node table itself; workgroup 0 accumulates d(bn weight / bias)
@@ -538,11 +541,19 @@ __global__ __launch_bounds__(256) void k_gcn_agg_temporal_g(const T* __restrict_
         const int b = G / KASF_J, j = G % KASF_J;
         auto tok = [&](int r) { return ((int64_t)b * L + r) * KASF_J + j; };
         __syncthreads();
-        for (int idx = threadIdx.x; idx < LP * CPR; idx += 256) {
-            const int r = idx / CPR, ch = idx % CPR;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (r < L) v = *reinterpret_cast<const f32x4*>(xn + tok(r) * 128 + ch * EPC);
-            *reinterpret_cast<f32x4*>(sX + Tile<T>::chunk_off(r, ch)) = v;
+        for (int i0 = threadIdx.x; i0 < LP * CPR; i0 += 1024) {     // (four chunks' loads in flight per thread)
+            f32x4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int idx = i0 + 256 * k, r = idx / CPR, ch = idx % CPR;
+                v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (r < L) v[k] = *reinterpret_cast<const f32x4*>(xn + tok(r) * 128 + ch * EPC);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int idx = i0 + 256 * k, r = idx / CPR, ch = idx % CPR;
+                if (idx < LP * CPR) *reinterpret_cast<f32x4*>(sX + Tile<T>::chunk_off(r, ch)) = v[k];
+            }
         }
         __syncthreads();
         for (int rb = w; rb < NTL; rb += 4) {
@@ -612,15 +623,28 @@ __global__ __launch_bounds__(256) void k_gcn_agg_temporal_g(const T* __restrict_
             if (lg == 0 && r < L) sDinv[r] = 1.0f / sqrtf((float)deg);
         }
         __syncthreads();
-        for (int idx = threadIdx.x; idx < L * CPR; idx += 256) {     // the similarity is done with LN(x): the tile now holds the V rows (linear)
-            const int r = idx / CPR, ch = idx % CPR;
-            *reinterpret_cast<f32x4*>(sX + r * 128 + ch * EPC) = *reinterpret_cast<const f32x4*>(uv + tok(r) * 256 + 128 + ch * EPC);
+        for (int i0 = threadIdx.x; i0 < L * CPR; i0 += 1024) {       // the similarity is done with LN(x): the tile now holds the V rows (linear)
+            f32x4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int idx = i0 + 256 * k, r = idx / CPR, ch = idx % CPR;
+                if (idx < L * CPR) v[k] = *reinterpret_cast<const f32x4*>(uv + tok(r) * 256 + 128 + ch * EPC);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int idx = i0 + 256 * k, r = idx / CPR, ch = idx % CPR;
+                if (idx < L * CPR) *reinterpret_cast<f32x4*>(sX + r * 128 + ch * EPC) = v[k];
+            }
         }
+        float un[8];
+        if ((int)threadIdx.x < L * 16) load8(uv + tok(threadIdx.x >> 4) * 256 + (threadIdx.x & 15) * 8, un);
         __syncthreads();
         for (int idx = threadIdx.x; idx < L * 16; idx += 256) {
             const int r = idx >> 4, sub = idx & 15;
             float acc[8], u[8];
-            load8(uv + tok(r) * 256 + sub * 8, u);      // (issued ahead of the gather it is added to)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) u[e] = un[e];
+            if (idx + 256 < L * 16) load8(uv + tok((idx + 256) >> 4) * 256 + sub * 8, un);     // U of the next item rides under this item's gather
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[e] = 0.f;
             const float dr = sDinv[r];
@@ -657,18 +681,34 @@ __global__ __launch_bounds__(256) void k_gcn_bwd2_temporal_g(const T* __restrict
     __shared__ float coef[KASF_MAX_NODES * C2_LD];
     bwd2_prologue(coef, coefg, bstats, d_w, d_b, L, count, training);
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* sDy = reinterpret_cast<float*>(smem);        // [L][SX_LD]
-    float* sDinv = sDy + L * SX_LD;
+    constexpr int DY_LD = 128 + 16 / sizeof(T);         // dy rows in the storage type (bf16 mode: the rounded values dU stores; 64 KB at T = 243: two workgroups per CU)
+    T* sDy = reinterpret_cast<T*>(smem);                // [L][DY_LD]
+    float* sDinv = reinterpret_cast<float*>(sDy + L * DY_LD);
     uint32_t* sMask = reinterpret_cast<uint32_t*>(sDinv + L);
     const int G = blockIdx.x, b = G / KASF_J, j = G % KASF_J;
     auto tok = [&](int r) { return ((int64_t)b * L + r) * KASF_J + j; };
-    for (int idx = threadIdx.x; idx < L * 16; idx += 256) {
-        const int r = idx >> 4, sub = idx & 15;
-        float dy[8];
-        dy_chunk(rbuf, y, coef, tok(r), r, sub, dy);
-        store8(duv + tok(r) * 256 + sub * 8, dy);
+    // (four items' loads in flight per thread: with two workgroups per CU a load -> store chain per item pays the memory latency 15 times over at T = 243)
+    for (int i0 = threadIdx.x; i0 < L * 16; i0 += 1024) {
+        float rr[4][8], cc[4][8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) sDy[r * SX_LD + sub * 8 + e] = dy[e];
+        for (int k = 0; k < 4; ++k) {
+            const int idx = i0 + 256 * k;
+            if (idx < L * 16) {
+                load8(rbuf + tok(idx >> 4) * 128 + (idx & 15) * 8, rr[k]);
+                load8(y + tok(idx >> 4) * 128 + (idx & 15) * 8, cc[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int idx = i0 + 256 * k;
+            if (idx < L * 16) {
+                const int r = idx >> 4, sub = idx & 15;
+                float dy[8];
+                dy_math(rr[k], cc[k], coef, r, dy);
+                store8(duv + tok(r) * 256 + sub * 8, dy);
+                store8(sDy + r * DY_LD + sub * 8, dy);
+            }
+        }
     }
     for (int r = threadIdx.x; r < L; r += 256) {
         int deg = 0;
@@ -682,13 +722,20 @@ __global__ __launch_bounds__(256) void k_gcn_bwd2_temporal_g(const T* __restrict
     {
         const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
         for (int c = w; c < L; c += 4) {
-            for (int h = 0; 2 * h < MW; ++h) {
+            uint32_t wd[4];
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {               // (the column's four reads are in flight together)
                 const int r = 64 * h + lane;
-                const bool bit = r < L && ((sMask[r * MW + (c >> 5)] >> (c & 31)) & 1u);
-                const unsigned long long bal = __ballot(bit);
-                if (lane == 0) {
-                    sMaskT[c * MW + 2 * h] = (uint32_t)bal;
-                    if (2 * h + 1 < MW) sMaskT[c * MW + 2 * h + 1] = (uint32_t)(bal >> 32);
+                wd[h] = (2 * h < MW && r < L) ? sMask[r * MW + (c >> 5)] : 0u;
+            }
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                if (2 * h < MW) {
+                    const unsigned long long bal = __ballot((wd[h] >> (c & 31)) & 1u);
+                    if (lane == 0) {
+                        sMaskT[c * MW + 2 * h] = (uint32_t)bal;
+                        if (2 * h + 1 < MW) sMaskT[c * MW + 2 * h + 1] = (uint32_t)(bal >> 32);
+                    }
                 }
             }
         }
@@ -706,8 +753,10 @@ __global__ __launch_bounds__(256) void k_gcn_bwd2_temporal_g(const T* __restrict
                 const int r = wi * 32 + __builtin_ctz(bits);
                 bits &= bits - 1;
                 const float wgt = sDinv[r] * dc;
+                float v[8];
+                load8(sDy + r * DY_LD + sub * 8, v);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] += wgt * sDy[r * SX_LD + sub * 8 + e];
+                for (int e = 0; e < 8; ++e) acc[e] += wgt * v[e];
             }
         }
         store8(duv + tok(c) * 256 + 128 + sub * 8, acc);
@@ -776,7 +825,7 @@ void bwd2_T(hipStream_t s, const void* r, const void* y, const float* coef, cons
     else if (Tn == 9) bwd2_temporal_TL<T, 9>(s, r, y, coef, mask, duv, B, Tn, bstats, d_w, d_b, count, training);
     else {
         const int MW = kasf_gcn_mask_words(Tn);
-        const size_t sh = (size_t)(Tn * SX_LD + Tn) * sizeof(float) + (size_t)2 * Tn * MW * sizeof(uint32_t);
+        const size_t sh = (size_t)Tn * (128 + 16 / sizeof(T)) * sizeof(T) + (size_t)Tn * sizeof(float) + (size_t)2 * Tn * MW * sizeof(uint32_t);
         set_smem(k_gcn_bwd2_temporal_g<T>, sh);
         hipLaunchKernelGGL((k_gcn_bwd2_temporal_g<T>), dim3(B * KASF_J), dim3(256), sh, s, (const T*)r, (const T*)y, coef, mask, (T*)duv, Tn, MW, bstats, d_w,
                            d_b, count, training);
