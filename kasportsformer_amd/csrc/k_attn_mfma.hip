@@ -81,6 +81,21 @@ __device__ __forceinline__ void store_t(bf16* dst, const f32x16& t, int hh) {
     store4(dst + 8 + 4 * hh, b);
 }
 
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+    const bf16x2_t t = {(bf16)a, (bf16)b};
+    return __builtin_bit_cast(unsigned, t);
+}
+// lane = position, registers 0..7 of t = channels {4hh..4hh+3, 8+4hh..8+4hh+3}  ->  after the swap lane hh holds channels 8hh .. 8hh+7
+__device__ __forceinline__ u32x4_t swap_t16(const f32x16& t) {
+    const auto s0 = __builtin_amdgcn_permlane32_swap(pack2(t[0], t[1]), pack2(t[4], t[5]), false, false);
+    const auto s1 = __builtin_amdgcn_permlane32_swap(pack2(t[2], t[3]), pack2(t[6], t[7]), false, false);
+    return u32x4_t{s0[0], s1[0], s0[1], s1[1]};
+}
+// the same tile as ONE 16-byte store per lane (32 contiguous bytes per position and head; store_t: two 8-byte pieces per lane, 64 requests per wave store)
+__device__ __forceinline__ void store_t16(bf16* dst, const f32x16& t, int hh) { *reinterpret_cast<u32x4_t*>(dst + 8 * hh) = swap_t16(t); }
+
 template <int NKT>
 __global__ __launch_bounds__(256) void k_attn_fwd_mfma(const bf16* __restrict__ Q, int64_t ldq, const bf16* __restrict__ K, const bf16* __restrict__ V,
                                                        int64_t ldkv, bf16* __restrict__ O, int L, int Tn, int mode, int units) {
@@ -129,7 +144,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd_mfma(const bf16* __restrict__ 
             ot = mfma32(tr_frag(sV, 2 * kt), pack8(st[kt], 0), ot);
             ot = mfma32(tr_frag(sV, 2 * kt + 1), pack8(st[kt], 1), ot);
         }
-        if (i < L) store_t(O + tok_of(G, i, Tn, mode) * 128 + h * 16, ot, hh);
+        if (i < L) store_t16(O + tok_of(G, i, Tn, mode) * 128 + h * 16, ot, hh);
     }
 }
 
@@ -242,7 +257,7 @@ __global__ __launch_bounds__(FDO ? 512 : 256) void k_attn_bwd_mfma(const bf16* _
             dq = mfma32(tr_frag(sK, 2 * kt), pack8(st[kt], 0), dq);                                // dQ^T[d][query] += K^T . dS^T
             dq = mfma32(tr_frag(sK, 2 * kt + 1), pack8(st[kt], 1), dq);
         }
-        if (i < L) store_t(dQ + tok_of(G, i, Tn, mode) * lddq + h * 16, dq, hh);
+        if (i < L) store_t16(dQ + tok_of(G, i, Tn, mode) * lddq + h * 16, dq, hh);
         if (NKT == 1) {
 #pragma unroll
             for (int a4 = 0; a4 < 4; ++a4) {
@@ -262,8 +277,8 @@ __global__ __launch_bounds__(FDO ? 512 : 256) void k_attn_bwd_mfma(const bf16* _
         }
         if (j < L) {
             const int64_t tok = tok_of(G, j, Tn, mode);
-            store_t(dV + tok * lddkv + h * 16, dv, hh);
-            store_t(dK + tok * lddkv + h * 16, dk, hh);
+            store_t16(dV + tok * lddkv + h * 16, dv, hh);
+            store_t16(dK + tok * lddkv + h * 16, dk, hh);
         }
     }
 }
@@ -396,15 +411,15 @@ __global__ __launch_bounds__(FDO ? 512 : 256, 2) void k_attn_bwd_long(const bf16
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the next key tile overwrites the blocks
         }
-        if (i < L) store_t(dQ + tok_of(G, i, Tn, mode) * lddq + h * 16, dq, hh);
+        if (i < L) store_t16(dQ + tok_of(G, i, Tn, mode) * lddq + h * 16, dq, hh);
     }
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
         const int j = 32 * kt + r;
         if (j < L) {
             const int64_t tok = tok_of(G, j, Tn, mode);
-            store_t(dV + tok * lddkv + h * 16, dv[kt], hh);
-            store_t(dK + tok * lddkv + h * 16, dk[kt], hh);
+            store_t16(dV + tok * lddkv + h * 16, dv[kt], hh);
+            store_t16(dK + tok * lddkv + h * 16, dk[kt], hh);
         }
     }
 }
@@ -444,50 +459,79 @@ __global__ __launch_bounds__(512, 2) void k_attn_bwd_kt(const bf16* __restrict__
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TILE = NKT * 32 * 16;                           // [positions][16] operand tile (bf16 elements)
     constexpr int BLK = 32 * KT_LD;                               // one dS block
-    constexpr int WAVE_BYTES = 3 * TILE * 2 + 2 * BLK * 2 + 2 * NKT * 32 * 4;     // K, Q, d_o tiles; two dS blocks; lse, delta
+    constexpr int WAVE_BYTES = 4 * TILE * 2 + BLK * 2 + 2 * NKT * 32 * 4;         // K, Q, d_o, V tiles; the dS block; lse, delta
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
     const int G = blockIdx.x, h = wave;
     bf16* sK = reinterpret_cast<bf16*>(smem + wave * WAVE_BYTES);
     bf16* sQ = sK + TILE;
     bf16* sD = sQ + TILE;
-    bf16* sdS = sD + TILE;                                        // [2][32 keys][KT_LD]
-    float* sLse = reinterpret_cast<float*>(sdS + 2 * BLK);        // [32 NKT]
-    float* sDel = sLse + NKT * 32;
+    bf16* sV = sD + TILE;
+    bf16* sdS = sV + TILE;                                        // [32 keys][KT_LD]
+    float* sLse = reinterpret_cast<float*>(sdS + BLK);            // [32 NKT]  -lse
+    float* sDel = sLse + NKT * 32;                                //           -delta
     bf16* sG = reinterpret_cast<bf16*>(smem + 8 * WAVE_BYTES);    // [32 NKT][128] g_mid rows of the group (swizzled tile; rows past L zero)
-    bf16x8 kf[NKT], vf[NKT], o8[NKT];
-    float lse_r[NKT];
-    // every global load of the group is issued up front (one workgroup per CU: nothing else would cover a second round trip to memory)
+    auto wave_tile = [&](int hd, int which) { return reinterpret_cast<bf16*>(smem + hd * WAVE_BYTES) + which * TILE; };          // 0 K, 1 Q, 2 d_o, 3 V
+    auto wave_stat = [&](int hd, int which) { return reinterpret_cast<float*>(smem + hd * WAVE_BYTES + 4 * TILE * 2 + BLK * 2) + which * NKT * 32; };
+    // ---- the group's rows come in COOPERATIVELY: thread = (position, 16-byte chunk of the row), so a wave load covers whole 256-byte (q | k | v: 768-byte) rows.
+    // One wave per head loading its own 32-byte slice of each of 32 rows made every load and store 32-64 separate requests, and the launch was bound by
+    // exactly that: 55 us of its 167 for loads + stores alone, the same total whatever the occupancy, the phase of the co-resident workgroup or the
+    // number of vector instructions (in-kernel stamps: 20-30 k of a workgroup's 35-45 k cycles went by before its first loads had landed).
+    // All loads are issued before anything waits; they are distributed to the heads' tiles through LDS.
+    constexpr int ROWS = NKT * 32, NQKV = ROWS * 48 / 512, NROW = ROWS * 16 / 512;                 // 9 and 3 chunks per thread
+    bf16x8 cq[NQKV], co[NROW], cg[NROW];
+    float cl[2];
 #pragma unroll
-    for (int t = 0; t < NKT; ++t) {
-        const int pos = 32 * t + r;
-        const int64_t tokc = tok_of(G, pos < L ? pos : L - 1, Tn, mode);
-        lse_r[t] = LSE[tokc * 8 + h];
-        o8[t] = *reinterpret_cast<const bf16x8*>(O + tokc * 128 + h * 16 + 8 * hh);
-    }
-#pragma unroll
-    for (int t = 0; t < NKT; ++t) {
-        const int pos = 32 * t + r;
-        kf[t] = row_frag(K, ldkv, G, pos, L, Tn, mode, h, hh, sK);
-        vf[t] = row_frag(V, ldkv, G, pos, L, Tn, mode, h, hh, nullptr);
-        {   // Q / 4 (a power of two: exact in bf16) into the wave's tile
-            bf16x8 qv = row_frag(Q, ldq, G, pos, L, Tn, mode, h, hh, nullptr);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) qv[e] = (bf16)((float)qv[e] * 0.25f);
-            *reinterpret_cast<bf16x8*>(sQ + pos * 16 + 8 * hh) = qv;
+    for (int k = 0; k < NQKV; ++k) {
+        const int idx = threadIdx.x + 512 * k, row = idx / 48, c = idx - row * 48, part = c >> 4, ch = c & 15;
+        cq[k] = zero8();
+        if (row < L) {
+            const int64_t tk = tok_of(G, row, Tn, mode);
+            cq[k] = *reinterpret_cast<const bf16x8*>(part == 0 ? Q + tk * ldq + ch * 8 : (part == 1 ? K : V) + tk * ldkv + ch * 8);
         }
     }
+#pragma unroll
+    for (int k = 0; k < NROW; ++k) {
+        const int idx = threadIdx.x + 512 * k, row = idx >> 4, ch = idx & 15;
+        co[k] = zero8();
+        cg[k] = zero8();
+        if (row < L) {
+            const int64_t tk = tok_of(G, row, Tn, mode);
+            co[k] = *reinterpret_cast<const bf16x8*>(O + tk * 128 + ch * 8);
+            cg[k] = *reinterpret_cast<const bf16x8*>(Gmid + tk * 128 + ch * 8);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int idx = threadIdx.x + 512 * k, row = idx >> 3, hd = idx & 7;
+        cl[k] = INFINITY;                                         // rows past L: exp(s - inf) = 0 keeps them out of every product
+        if (idx < ROWS * 8 && row < L) cl[k] = LSE[tok_of(G, row, Tn, mode) * 8 + hd];
+    }
+    const int li = lane & 15, lg = lane >> 4;
+    bf16x8 wp[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) wp[ks] = *reinterpret_cast<const bf16x8*>(Wp + (int64_t)(16 * h + li) * 128 + 32 * ks + 8 * lg);
+#pragma unroll
+    for (int k = 0; k < NROW; ++k) {
+        const int idx = threadIdx.x + 512 * k, row = idx >> 4, ch = idx & 15;
+        *reinterpret_cast<bf16x8*>(sG + Tile<bf16>::chunk_off(row, ch)) = cg[k];
+    }
+#pragma unroll
+    for (int k = 0; k < NQKV; ++k) {
+        const int idx = threadIdx.x + 512 * k, row = idx / 48, c = idx - row * 48, part = c >> 4, ch = c & 15;
+        bf16x8 v = cq[k];
+        if (part == 0) {                                          // Q / 4 (a power of two: exact in bf16)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (bf16)((float)v[e] * 0.25f);
+        }
+        *reinterpret_cast<bf16x8*>(wave_tile(ch >> 1, part == 0 ? 1 : (part == 1 ? 0 : 3)) + row * 16 + 8 * (ch & 1)) = v;
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int idx = threadIdx.x + 512 * k, row = idx >> 3, hd = idx & 7;
+        if (idx < ROWS * 8) wave_stat(hd, 0)[row] = -cl[k];       // negated: lse and delta ride into the score products as initial accumulators
+    }
+    __syncthreads();
     {   // d_o = g_mid . (ls1 . Wproj)^T restricted to this head: 24 MFMAs against the wave's 16 rows of the packed weight
-        for (int c = threadIdx.x; c < NKT * 32 * 16; c += 512) {
-            const int row = c >> 4, ch = c & 15;
-            bf16x8 v = zero8();
-            if (row < L) v = *reinterpret_cast<const bf16x8*>(Gmid + tok_of(G, row, Tn, mode) * 128 + ch * 8);
-            *reinterpret_cast<bf16x8*>(sG + Tile<bf16>::chunk_off(row, ch)) = v;
-        }
-        const int li = lane & 15, lg = lane >> 4;
-        bf16x8 wp[4];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) wp[ks] = *reinterpret_cast<const bf16x8*>(Wp + (int64_t)(16 * h + li) * 128 + 32 * ks + 8 * lg);
-        __syncthreads();
 #pragma unroll
         for (int mt = 0; mt < 2 * NKT; ++mt) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -498,23 +542,23 @@ __global__ __launch_bounds__(512, 2) void k_attn_bwd_kt(const bf16* __restrict__
             store4(sD + (16 * mt + li) * 16 + 4 * lg, v);
         }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // the d_o tile was written by other lanes of this wave
+    __syncthreads();                                              // every head's d_o tile is complete
 #pragma unroll
-    for (int t = 0; t < NKT; ++t) {   // lse and delta = sum_d d_o . o of query 32 t + r (the two lane halves hold 8 channels each)
-        const int pos = 32 * t + r;
-        float lse = INFINITY, part = 0.f;                         // rows past L: exp(s - inf) = 0 keeps them out of every product
-        if (pos < L) {
-            lse = lse_r[t];
-            const bf16x8 d8 = *reinterpret_cast<const bf16x8*>(sD + pos * 16 + 8 * hh);
+    for (int k = 0; k < NROW; ++k) {   // delta = sum_d d_o . o per (position, head): the thread that loaded 8 channels of o meets the same 8 of d_o; the head's two halves are neighbours
+        const int idx = threadIdx.x + 512 * k, row = idx >> 4, ch = idx & 15;
+        const bf16x8 d8 = *reinterpret_cast<const bf16x8*>(wave_tile(ch >> 1, 2) + row * 16 + 8 * (ch & 1));
+        float part = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) part += (float)o8[t][e] * (float)d8[e];
-        }
-        part += __shfl_xor(part, 32);
-        if (hh == 0) { sLse[pos] = lse; sDel[pos] = part; }
+        for (int e = 0; e < 8; ++e) part += (float)co[k][e] * (float)d8[e];
+        part += __shfl_xor(part, 1);
+        if ((ch & 1) == 0) wave_stat(ch >> 1, 1)[row] = -part;
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
     auto rowf = [&](const bf16* tile, int t) { return *reinterpret_cast<const bf16x8*>(tile + (32 * t + r) * 16 + 8 * hh); };
     const int nt = (L + 31) >> 5;                                 // live 32-position tiles (2 or 3)
+    bf16x8 kf[NKT], vf[NKT];
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) { kf[t] = rowf(sK, t); vf[t] = rowf(sV, t); }
     f32x16 dq[NKT];
 #pragma unroll
     for (int t = 0; t < NKT; ++t) dq[t] = zero16();
@@ -523,8 +567,20 @@ __global__ __launch_bounds__(512, 2) void k_attn_bwd_kt(const bf16* __restrict__
     // NEXT pair -- is issued first, then the next pair's two score products, then the vector work, then the dS block stores (all reads of the wave's
     // tiles are ahead of them: the compiler cannot move a read across a store it cannot disambiguate), the dV / dK products and last the block's
     // transposed read-back for dQ.  sQ holds Q / 4 (exact in bf16): S and dK come out scaled, dS is stored unscaled and dQ is scaled once at the end.
-    f32x16 s_nxt = mfma32(rowf(sQ, 0), kf[0], zero16());          // S[query][key] / 4 of the first pair: lane = key, registers = queries
-    f32x16 p_nxt = mfma32(rowf(sD, 0), vf[0], zero16());          // dP[query][key] = sum_d d_o[query][d] V[key][d]
+    // -lse and -delta of a pair's 16 queries (registers 4a .. 4a+3 = queries 32 qt + 8a + 4hh + {0..3}) are the INITIAL ACCUMULATORS of its two score
+    // products: S / 4 - lse and dP - delta come out of the matrix pipe, and the vector work per element is mul (log2 e), exp2, mul -- it was
+    // sub, mul, exp2, sub, mul (1,692 -> 1,350 vector instructions per wave).
+    auto stat16 = [&](const float* st, int qt) {
+        f32x16 c;
+#pragma unroll
+        for (int a4 = 0; a4 < 4; ++a4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(st + 32 * qt + 8 * a4 + 4 * hh);
+            c[4 * a4] = v[0]; c[4 * a4 + 1] = v[1]; c[4 * a4 + 2] = v[2]; c[4 * a4 + 3] = v[3];
+        }
+        return c;
+    };
+    f32x16 s_nxt = mfma32(rowf(sQ, 0), kf[0], stat16(sLse, 0));   // S[query][key] / 4 - lse of the first pair: lane = key, registers = queries
+    f32x16 p_nxt = mfma32(rowf(sD, 0), vf[0], stat16(sDel, 0));   // dP[query][key] - delta,  dP = sum_d d_o[query][d] V[key][d]
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
         if (kt >= nt) break;
@@ -534,41 +590,35 @@ __global__ __launch_bounds__(512, 2) void k_attn_bwd_kt(const bf16* __restrict__
 #pragma unroll
         for (int qt = 0; qt < NKT; ++qt) {
             if (qt >= nt) break;
-            bf16* blk = sdS + ((kt * NKT + qt) & 1) * BLK;
-            f32x4 l4[4], d4[4];
-#pragma unroll
-            for (int a4 = 0; a4 < 4; ++a4) {                      // registers 4a .. 4a+3 = queries 32 qt + 8a + 4hh + {0..3}
-                l4[a4] = *reinterpret_cast<const f32x4*>(sLse + 32 * qt + 8 * a4 + 4 * hh);
-                d4[a4] = *reinterpret_cast<const f32x4*>(sDel + 32 * qt + 8 * a4 + 4 * hh);
-            }
+            bf16* blk = sdS;                                      // (one block: same-wave LDS requests are served in issue order, the next pair's stores land behind this pair's reads)
             const bf16x8 dt0 = tr_frag(sD, 2 * qt), dt1 = tr_frag(sD, 2 * qt + 1), qt0 = tr_frag(sQ, 2 * qt), qt1 = tr_frag(sQ, 2 * qt + 1);
             f32x16 p = s_nxt, ds = p_nxt;
             {   // the two score products of the NEXT pair (kt-major order; past the end: pair (0, 0) again, unused) run under this pair's vector work
                 const int qn = qt + 1 < nt ? qt + 1 : 0;
                 const bool same_kt = qt + 1 < nt;
                 const bf16x8 kn = same_kt ? kf[kt] : kf[kt + 1 < NKT ? kt + 1 : 0], vn = same_kt ? vf[kt] : vf[kt + 1 < NKT ? kt + 1 : 0];
-                s_nxt = mfma32(rowf(sQ, qn), kn, zero16());
-                p_nxt = mfma32(rowf(sD, qn), vn, zero16());
+                s_nxt = mfma32(rowf(sQ, qn), kn, stat16(sLse, qn));
+                p_nxt = mfma32(rowf(sD, qn), vn, stat16(sDel, qn));
             }
             const int NRQ = (qt == NKT - 1) ? NR2 : 16;           // (a constant after unrolling; NR2 < 16 is only chosen when all NKT tiles are live)
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
                 if (g < NRQ) {
-                    const float pv = __expf(p[g] - l4[g >> 2][g & 3]);
+                    const float pv = __builtin_amdgcn_exp2f(p[g] * 1.4426950408889634f);
                     p[g] = pv;
-                    ds[g] = pv * (ds[g] - d4[g >> 2][g & 3]);                                // dS x 4
+                    ds[g] = pv * ds[g];                           // dS x 4
                 } else { p[g] = 0.f; ds[g] = 0.f; }
             }
-#pragma unroll
-            for (int a4 = 0; a4 < 4; ++a4) {                      // dS block [key][query] for the transposed read-back; rows of keys past L are zero
-                float v4[4] = {ds[4 * a4], ds[4 * a4 + 1], ds[4 * a4 + 2], ds[4 * a4 + 3]};
-                if (!keyok) { v4[0] = 0.f; v4[1] = 0.f; v4[2] = 0.f; v4[3] = 0.f; }
-                store4(blk + r * KT_LD + 8 * a4 + 4 * hh, v4);
-            }
+            bf16x8 dd0 = pack8(ds, 0), dd1 = pack8(ds, 1);        // operands of dK^T and, the same bits, the block dQ^T reads back transposed
+            if (kt == NKT - 1 && !keyok) { dd0 = zero8(); dd1 = zero8(); }     // rows of keys past L are zero (they exist in the last tile only)
+            *reinterpret_cast<bf16x4*>(blk + r * KT_LD + 4 * hh) = bf16x4{dd0[0], dd0[1], dd0[2], dd0[3]};      // dS block [key][query]: registers 4a .. 4a+3 =
+            *reinterpret_cast<bf16x4*>(blk + r * KT_LD + 8 + 4 * hh) = bf16x4{dd0[4], dd0[5], dd0[6], dd0[7]};  // queries 8a + 4hh + {0..3}
+            *reinterpret_cast<bf16x4*>(blk + r * KT_LD + 16 + 4 * hh) = bf16x4{dd1[0], dd1[1], dd1[2], dd1[3]};
+            *reinterpret_cast<bf16x4*>(blk + r * KT_LD + 24 + 4 * hh) = bf16x4{dd1[4], dd1[5], dd1[6], dd1[7]};
             dv = mfma32(dt0, pack8(p, 0), dv);                    // dV^T[d][key] += d_o^T . P      (contraction over the tile's 32 queries, operands
-            dk = mfma32(qt0, pack8(ds, 0), dk);                   // dK^T[d][key] += (Q / 4)^T . 4 dS     straight from the registers)
+            dk = mfma32(qt0, dd0, dk);                            // dK^T[d][key] += (Q / 4)^T . 4 dS     straight from the registers)
             dv = mfma32(dt1, pack8(p, 1), dv);
-            dk = mfma32(qt1, pack8(ds, 1), dk);
+            dk = mfma32(qt1, dd1, dk);
             // (same-wave LDS requests are served in issue order and the transposed reads below are memory reads of `blk` to the compiler: no explicit wait)
             dq[qt] = mfma32(kt0, tr_frag32s<KT_LD>(blk, 0), dq[qt]);                         // 4 dQ^T[d][query] += K^T . (4 dS)^T
             dq[qt] = mfma32(kt1, tr_frag32s<KT_LD>(blk, 1), dq[qt]);
@@ -576,8 +626,8 @@ __global__ __launch_bounds__(512, 2) void k_attn_bwd_kt(const bf16* __restrict__
         const int j = 32 * kt + r;
         if (j < L) {
             const int64_t tok = tok_of(G, j, Tn, mode);
-            store_t(dV + tok * lddkv + h * 16, dv, hh);
-            store_t(dK + tok * lddkv + h * 16, dk, hh);
+            store_t16(dV + tok * lddkv + h * 16, dv, hh);
+            store_t16(dK + tok * lddkv + h * 16, dk, hh);
         }
     }
 #pragma unroll
@@ -586,7 +636,7 @@ __global__ __launch_bounds__(512, 2) void k_attn_bwd_kt(const bf16* __restrict__
         if (i < L) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) dq[qt][e] *= 0.25f;
-            store_t(dQ + tok_of(G, i, Tn, mode) * lddq + h * 16, dq[qt], hh);
+            store_t16(dQ + tok_of(G, i, Tn, mode) * lddq + h * 16, dq[qt], hh);
         }
     }
 }
@@ -691,7 +741,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_2p(const bf16* __restrict__
             dq = mfma32(tr_frag(sK, 2 * kt), pack8(st[kt], 0), dq);                                // dQ^T[d][query] += K^T . dS^T
             dq = mfma32(tr_frag(sK, 2 * kt + 1), pack8(st[kt], 1), dq);
         }
-        if (i < L) store_t(dQ + tok_of(G, i, Tn, mode) * lddq + h * 16, dq, hh);
+        if (i < L) store_t16(dQ + tok_of(G, i, Tn, mode) * lddq + h * 16, dq, hh);
     }
     // between the passes Q / 4 takes K's place (same-wave LDS requests are served in issue order: the stores land behind pass A's last reads)
 #pragma unroll
@@ -733,8 +783,8 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_2p(const bf16* __restrict__
         const int j = 32 * kt + r;
         if (j < L) {
             const int64_t tok = tok_of(G, j, Tn, mode);
-            store_t(dV + tok * lddkv + h * 16, dv, hh);
-            store_t(dK + tok * lddkv + h * 16, dk, hh);
+            store_t16(dV + tok * lddkv + h * 16, dv, hh);
+            store_t16(dK + tok * lddkv + h * 16, dk, hh);
         }
     }
 }
@@ -750,18 +800,6 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_2p(const bf16* __restrict__
 //     consecutive head channels of its position instead of two 4-channel pieces.
 // Two workgroups per CU (<= 128 VGPRs, 72 KB of LDS): one group's barrier and LDS round trips are covered by the other's work.
 // ---------------------------------------------------------------------------------------------------------------
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
-__device__ __forceinline__ unsigned pack2(float a, float b) {
-    const bf16x2_t t = {(bf16)a, (bf16)b};
-    return __builtin_bit_cast(unsigned, t);
-}
-// lane = position, registers 0..7 of t = channels {4hh..4hh+3, 8+4hh..8+4hh+3}  ->  after the swap lane hh holds channels 8hh .. 8hh+7
-__device__ __forceinline__ u32x4_t swap_t16(const f32x16& t) {
-    const auto s0 = __builtin_amdgcn_permlane32_swap(pack2(t[0], t[1]), pack2(t[4], t[5]), false, false);
-    const auto s1 = __builtin_amdgcn_permlane32_swap(pack2(t[2], t[3]), pack2(t[6], t[7]), false, false);
-    return u32x4_t{s0[0], s1[0], s0[1], s1[1]};
-}
 
 // NR: score registers that can hold a live key (register g holds keys (g & 3) + 8 (g >> 2) + 4 hh: 9 for groups of <= 17 positions, the spatial
 // blocks): the softmax / dS arithmetic and the P / dS tile stores skip the registers past NR, which are identically zero.
@@ -969,7 +1007,7 @@ bool kasf_launch_attn_bwd_fused_do(hipStream_t s, const void* q, int64_t ldq, co
     if (L > 32) {                                       // three-tile groups (temporal attention at T = 81): one workgroup = the 8 heads of one group
         if (form == 1) return false;                    // (the one-group-per-workgroup comparison form exists for one-tile groups only)
         if (o_saved != nullptr && lse != nullptr) {     // key-tile-outer kernel: statistics and delta from what the forward left behind
-            const size_t shk = 8 * (size_t)(3 * 96 * 16 * 2 + 2 * 32 * KT_LD * 2 + 2 * 96 * 4) + (size_t)96 * 128 * 2;
+            const size_t shk = 8 * (size_t)(4 * 96 * 16 * 2 + 32 * KT_LD * 2 + 2 * 96 * 4) + (size_t)96 * 128 * 2;
             if (L > 64 && L <= 81) {                    // last tile of at most 17 positions: 7 of its 16 query registers are dead
                 if (!set_smem(k_attn_bwd_kt<3, 9>, shk)) return true;
                 hipLaunchKernelGGL((k_attn_bwd_kt<3, 9>), dim3(groups), dim3(512), shk, s, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldkv, (const bf16*)o_saved, lse,
