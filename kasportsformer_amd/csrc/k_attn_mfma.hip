@@ -433,7 +433,10 @@ __global__ __launch_bounds__(FDO ? 512 : 256, 2) void k_attn_bwd_long(const bf16
 //     of dV^T = d_o^T . P and dK^T = Q^T . dS (the accumulator -> operand reuse of the forward core), so only ONE 2 KB block per tile pair -- dS, for
 //     dQ^T = K^T . dS^T -- goes through LDS and comes back transposed, where the query-tile-outer kernel sent P and dS both ways;
 //   * one key tile's dK / dV (32 registers) and the three query tiles' dQ (48) are live instead of 96 + 16, per tile pair 8 MFMAs instead of 9 + the
-//     statistics pass, and the dS blocks alternate between two buffers so that consecutive tile pairs overlap.
+//     statistics pass;
+//   * the group's rows (q | k | v, o, g_mid, lse) come in cooperatively, whole rows per wave load, and reach the heads' tiles through LDS; dq / dk / dv
+//     leave as 16-byte stores (see the prologue's comment: the first form, one wave per head loading its 32-byte slice of each row, was bound by the
+//     number of memory requests, not by anything the CUs did: 167 -> 142 us).
 // One wave per (group, head), the 8 heads of a group per workgroup (the group's g_mid rows are staged once for the d_o products), one workgroup per CU.
 // ---------------------------------------------------------------------------------------------------------------
 // tr_frag32 for a block whose rows are LD elements apart (LD = 36: the 72-byte row stride spreads the 32 row stores of a block over all banks;

@@ -15,8 +15,9 @@ say "single-stream traces (isolated launches)"
 export KASF_SINGLE_STREAM=1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/prof27s -o t --output-format csv -- python3 $R/tools/train_once.py 27 256 > $O/prof27s.log 2>&1 || echo "prof27s failed"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/prof81s -o t --output-format csv -- python3 $R/tools/train_once.py 81 128 > $O/prof81s.log 2>&1 || echo "prof81s failed"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/prof243s -o t --output-format csv -- python3 $R/tools/train_once.py 243 32 > $O/prof243s.log 2>&1 || echo "prof243s failed"
 unset KASF_SINGLE_STREAM
-cp $O/prof27s/t_kernel_stats.csv $O/r3_single_stream_kernel_stats.csv; cp $O/prof81s/t_kernel_stats.csv $O/r3_single_stream81_kernel_stats.csv
+cp $O/prof27s/t_kernel_stats.csv $O/r3_single_stream_kernel_stats.csv; cp $O/prof81s/t_kernel_stats.csv $O/r3_single_stream81_kernel_stats.csv; cp $O/prof243s/t_kernel_stats.csv $O/r3_single_stream243_kernel_stats.csv
 cd $R
 python tools/hbm_table.py $O/r3_single_stream_kernel_stats.csv 256 27 $O/r3_train_kernel_stats.csv > $O/r3_op_hbm.json
 python tools/hbm_table.py $O/r3_single_stream81_kernel_stats.csv 128 81 $O/r3_train81_kernel_stats.csv > $O/r3_op_hbm_t81.json
@@ -38,5 +39,5 @@ KASF_SINGLE_STREAM=1 timeout -k 10 200 python tools/bench_configs.py train27 2>/
 say "bench line (quotes the files above)"
 cp $O/r3_train_kernel_stats.csv $O/r3_pmc_step.json $O/r3_pmc_traffic.json $P/
 timeout -k 10 600 python bench.py > $O/r3_bench_b256.json 2> $O/bench.err; echo "bench rc=$?"
-rm -rf $O/prof27 $O/prof81 $O/prof27s $O/prof81s $O/profe $O/pmc_f $O/pmc_w $O/profm $R/gpurun_out/pmcs_f $R/gpurun_out/pmcs_w
+rm -rf $O/prof27 $O/prof81 $O/prof27s $O/prof81s $O/prof243s $O/profe $O/pmc_f $O/pmc_w $O/profm $R/gpurun_out/pmcs_f $R/gpurun_out/pmcs_w
 say done; ls $O
