@@ -44,7 +44,7 @@ typedef struct kasf_config {
     int32_t n_layers;            /* 26 in the shipped yaml (configs/sportspose-gt-kasportsformer.yaml:71) */
     int32_t n_frames;            /* T in [4, 256]: sizes the temporal BatchNorm1d; 9 / 27 / 81 have tuned temporal kernels, T <= 96 MFMA attention cores */
     int32_t num_heads;           /* 8 in every yaml (:84; head dim 16: MFMA attention kernels); 2 / 4 / 16 run generic kernels (4 = the constructor's default; 2: n_frames <= 157) */
-    int32_t neighbour_num;       /* top-k of the temporal GCN adjacency: must be 4 (yaml :89); other values are rejected */
+    int32_t neighbour_num;       /* top-k of the temporal GCN adjacency (graph.py:104-112), 1..4; every yaml uses 4 (:89); other values are rejected */
     int32_t use_adaptive_fusion; /* 1: softmax gate, 0: plain mean (KASportsFormer.py:284) */
     int32_t dtype;               /* KASF_DTYPE_* */
 } kasf_config;

@@ -377,7 +377,7 @@ void block_forward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void* 
     } else {
         kasf_launch_linear(c.dt, c.s, x_in, 128, c.pk(o.p_mix), 128, P + o.uv_b, c.w(sc.uv), 256, c.M, 256, P + o.n1w, P + o.n1b, c.w(w.xn), 0);
         kasf_launch_gcn_agg_fwd(c.dt, c.s, c.w(sc.uv), c.w(w.xn), c.w(w.y), w.mask >= 0 ? (uint32_t*)c.w(w.mask) : nullptr, (double*)c.w(w.stats), c.B,
-                                c.T, o.mode);
+                                c.T, o.mode, c.m->cfg.neighbour_num);
         const double count = o.mode == 0 ? (double)c.B * c.T * 128 : (double)c.B * 17 * 128;
         kasf_launch_gcn_apply(c.dt, c.s, x_in, c.w(w.xn), c.w(w.y), (const double*)c.w(w.stats), P + o.bn_w, P + o.bn_b, c.buf + o.bn_rm, c.buf + o.bn_rv,
                               (float*)c.w(w.coef), P + o.ls1, c.w(w.x_mid), c.B, c.T, o.mode, count, c.bn_train ? 1 : 0, 0.1f);
@@ -512,7 +512,7 @@ int kasf_model_create(const kasf_config* cfg, kasf_model** out) {
     // any clip length the reference can build (BatchNorm1d(n_frames), top-4 of T similarities needs T >= 4); 9 / 27 / 81 have tuned temporal
     // kernels (and T <= 96 the MFMA attention cores), other lengths run generic ones
     if (cfg->n_frames < 4 || cfg->n_frames > KASF_MAX_NODES) return kasf_set_error(3, "n_frames must be in [4, 256]");
-    if (cfg->neighbour_num != 4) return kasf_set_error(3, "neighbour_num must be 4 (every shipped yaml; the top-4 scan is what the temporal GCN kernels implement)");
+    if (cfg->neighbour_num < 1 || cfg->neighbour_num > 4) return kasf_set_error(3, "neighbour_num must be 1..4 (the temporal GCN kernels keep a row's four largest similarities; every shipped yaml uses 4)");
     // the generic attention backward (everything but 8 heads with n_frames <= 96 in bf16) keeps a track's q, k, v, d_o of one head in LDS:
     // (4 T D + 4 T) floats <= 160 KB, i.e. T (D + 1) <= 10240 -- only num_heads = 2 (D = 64) beyond 157 frames exceeds it
     if ((int64_t)cfg->n_frames * (128 / cfg->num_heads + 1) > 10240)

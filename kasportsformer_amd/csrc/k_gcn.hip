@@ -776,7 +776,7 @@ template <typename T, int L> constexpr size_t agg_smem() {
 template <int L> constexpr size_t bwd2_smem() { return (L * SX_LD + L) * sizeof(float) + 2 * L * MASK_W * sizeof(uint32_t); }
 
 template <typename T, int L>
-void agg_temporal_TL(hipStream_t s, const void* uv, const void* xn, void* y, uint32_t* mask, double* stats, int B, int Tn) {
+void agg_temporal_TL(hipStream_t s, const void* uv, const void* xn, void* y, uint32_t* mask, double* stats, int B, int Tn, int kth) {
     const size_t sh = agg_smem<T, L>();
     set_smem(k_gcn_agg_temporal<T, L>, sh);
     // persistent workgroups, equal track counts, ONE round: never more workgroups than fit on the chip at once (LDS bound; T = 81: 2 per CU -- 726
@@ -785,7 +785,7 @@ void agg_temporal_TL(hipStream_t s, const void* uv, const void* xn, void* y, uin
     per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
     const int tracks = B * KASF_J, resident = 256 * per_cu, per = (tracks + resident - 1) / resident;
     hipLaunchKernelGGL((k_gcn_agg_temporal<T, L>), dim3((tracks + per - 1) / per), dim3(256), sh, s, (const T*)uv, (const T*)xn, (T*)y, mask,
-                       stats, Tn, 4, tracks);
+                       stats, Tn, kth, tracks);
 }
 template <typename T, int L>
 void bwd2_temporal_TL(hipStream_t s, const void* r, const void* y, const float* coef, const uint32_t* mask, void* duv, int B, int Tn, const double* bstats,
@@ -796,21 +796,21 @@ void bwd2_temporal_TL(hipStream_t s, const void* r, const void* y, const float* 
 }
 
 template <typename T>
-void agg_fwd_T(hipStream_t s, const void* uv, const void* xn, void* y, uint32_t* mask, double* stats, int B, int Tn, int mode) {
+void agg_fwd_T(hipStream_t s, const void* uv, const void* xn, void* y, uint32_t* mask, double* stats, int B, int Tn, int mode, int kth) {
     const int64_t M = (int64_t)B * Tn * KASF_J;
     if (mode == 0) {
         unsigned grid = ew_grid(M);
         if (grid > 1024) grid = 1024;                    // every workgroup ends with 34 same-address fp64 atomics
         hipLaunchKernelGGL(k_gcn_agg_spatial<T>, dim3(grid), dim3(256), 0, s, (const T*)uv, (T*)y, stats, M);
-    } else if (Tn == 27) agg_temporal_TL<T, 27>(s, uv, xn, y, mask, stats, B, Tn);
-    else if (Tn == 81) agg_temporal_TL<T, 81>(s, uv, xn, y, mask, stats, B, Tn);
-    else if (Tn == 9) agg_temporal_TL<T, 9>(s, uv, xn, y, mask, stats, B, Tn);
+    } else if (Tn == 27) agg_temporal_TL<T, 27>(s, uv, xn, y, mask, stats, B, Tn, kth);
+    else if (Tn == 81) agg_temporal_TL<T, 81>(s, uv, xn, y, mask, stats, B, Tn, kth);
+    else if (Tn == 9) agg_temporal_TL<T, 9>(s, uv, xn, y, mask, stats, B, Tn, kth);
     else {
         const int LP = (Tn + 15) / 16 * 16, MW = kasf_gcn_mask_words(Tn);
         const size_t sh = (size_t)LP * 128 * sizeof(T) + (size_t)(3 * LP) * sizeof(float) + (size_t)Tn * MW * sizeof(uint32_t);
         set_smem(k_gcn_agg_temporal_g<T>, sh);
         const int tracks = B * KASF_J, per = (tracks + 1023) / 1024;
-        hipLaunchKernelGGL((k_gcn_agg_temporal_g<T>), dim3((tracks + per - 1) / per), dim3(256), sh, s, (const T*)uv, (const T*)xn, (T*)y, mask, stats, Tn, MW, 4,
+        hipLaunchKernelGGL((k_gcn_agg_temporal_g<T>), dim3((tracks + per - 1) / per), dim3(256), sh, s, (const T*)uv, (const T*)xn, (T*)y, mask, stats, Tn, MW, kth,
                            tracks);
     }
 }
@@ -856,10 +856,10 @@ void kasf_gcn_init() {
     if (dev >= 0 && dev < 64) ready[dev] = true;
 }
 
-void kasf_launch_gcn_agg_fwd(int dt, hipStream_t s, const void* uv, const void* xn, void* y, uint32_t* mask, double* stats, int B, int T, int mode) {
+void kasf_launch_gcn_agg_fwd(int dt, hipStream_t s, const void* uv, const void* xn, void* y, uint32_t* mask, double* stats, int B, int T, int mode, int kth) {
     kasf_gcn_init();
-    if (dt == KASF_F32) agg_fwd_T<float>(s, uv, xn, y, mask, stats, B, T, mode);
-    else agg_fwd_T<bf16>(s, uv, xn, y, mask, stats, B, T, mode);
+    if (dt == KASF_F32) agg_fwd_T<float>(s, uv, xn, y, mask, stats, B, T, mode, kth);
+    else agg_fwd_T<bf16>(s, uv, xn, y, mask, stats, B, T, mode, kth);
 }
 void kasf_launch_gcn_apply(int dt, hipStream_t s, const void* x_in, const void* xn, const void* y, const double* stats, const float* bn_w, const float* bn_b,
                            float* run_mean, float* run_var, float* coef, const float* ls1, void* out, int B, int T, int mode, double count, int training,

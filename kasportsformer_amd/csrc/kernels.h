@@ -113,7 +113,7 @@ bool kasf_launch_attn_bwd_mfma(hipStream_t s, const void* q, int64_t ldq, const 
 
 // ---- k_gcn.hip ----
 void kasf_gcn_init();   // uploads the skeleton table to constant memory (blocking; call once per process before capture)
-void kasf_launch_gcn_agg_fwd(int dt, hipStream_t s, const void* uv, const void* xn, void* y, uint32_t* mask, double* stats, int B, int T, int mode);
+void kasf_launch_gcn_agg_fwd(int dt, hipStream_t s, const void* uv, const void* xn, void* y, uint32_t* mask, double* stats, int B, int T, int mode, int kth = 4);
 // BatchNorm finalisation (batch sums or running statistics -> per-node affine `coef`, running-statistics update) is part of the apply kernel
 void kasf_launch_gcn_apply(int dt, hipStream_t s, const void* x_in, const void* xn, const void* y, const double* stats, const float* bn_w, const float* bn_b,
                            float* run_mean, float* run_var, float* coef, const float* ls1, void* out, int B, int T, int mode, double count, int training,

@@ -107,8 +107,8 @@ class KASportsFormer(nn.Module):
             unsupported.append("use_layer_scale=False / qkv_bias / qkv_scale / hierarchical / use_temporal_similarity=False")
         if num_heads not in (2, 4, 8, 16):
             unsupported.append("num_heads not in {2, 4, 8, 16} (8 = configs/*.yaml:84 runs the MFMA attention kernels, the others generic ones)")
-        if neighbour_num != 4 or not 4 <= n_frames <= 256:
-            unsupported.append("neighbour_num != 4 or n_frames outside [4, 256]")
+        if neighbour_num not in (1, 2, 3, 4) or not 4 <= n_frames <= 256:
+            unsupported.append("neighbour_num outside 1..4 or n_frames outside [4, 256]")
         if num_heads == 2 and n_frames > 157:
             unsupported.append("num_heads=2 with n_frames > 157 (the generic attention backward keeps a head's track in LDS)")
         if unsupported:

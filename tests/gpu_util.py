@@ -22,13 +22,13 @@ def rel_err(got: torch.Tensor, ref: torch.Tensor) -> float:
     return float((got - ref).abs().max() / (ref.abs().max() + 1e-12))
 
 
-def make_pair(n_layers, T, compute_dtype, salt=0):
+def make_pair(n_layers, T, compute_dtype, salt=0, **kw):
     """Oracle (CPU fp32) and HIP model with identical, de-identitied, name-seeded parameters."""
     import kasportsformer_amd as K
-    oracle = O.KASportsFormerOracle(n_layers=n_layers, num_heads=8, n_frames=T)
+    oracle = O.KASportsFormerOracle(n_layers=n_layers, num_heads=8, n_frames=T, **kw)
     sd = O.name_seeded_fill(oracle.state_dict(), salt)
     oracle.load_state_dict(sd, strict=True)
-    model = K.KASportsFormer(n_layers=n_layers, num_heads=8, n_frames=T, compute_dtype=compute_dtype)
+    model = K.KASportsFormer(n_layers=n_layers, num_heads=8, n_frames=T, compute_dtype=compute_dtype, **kw)
     model.load_state_dict(sd, strict=True)
     return oracle, model.cuda()
 

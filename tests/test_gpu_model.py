@@ -558,6 +558,37 @@ def test_arbitrary_clip_lengths(cd, tol, T, B):
         assert torch.isfinite(model(x.cuda())).all()
 
 
+@pytest.mark.parametrize("k,T", [(1, 27), (2, 27), (3, 81), (2, 100)])
+def test_neighbour_num_other_than_four(k, T):
+    """`neighbour_num` is a constructor argument of the reference (KASportsFormer.py:295 -> graph.py:104-112, torch.topk(k)); every yaml uses 4.  1..3 keep the
+    k-th largest similarity of a row as the threshold (ties kept): the stored masks must equal the oracle's decision row for row in fp32 mode, and forward, loss and
+    gradients must follow at the arithmetic tolerance."""
+    oracle, model = make_pair(1, T, "fp32", neighbour_num=k)
+    x, y = O.synthetic_clips(2, T, seed=23)
+    oracle.train(); model.train()
+    with forced_adjacency(model, x) as fa:
+        ref = oracle(x)
+        l_ref, _ = O.loss_total(ref, y)
+        l_ref.backward()
+    assert fa.unexplained == 0, fa.summary()
+    assert all(bool((m.sum(-1) >= k).all()) for m in fa.masks) and any(bool((m.sum(-1) == k).any()) for m in fa.masks)
+    pred = model(x.cuda())
+    loss, _ = O.loss_total(pred, y.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    assert _abs_err(pred, ref) / max(1.0, float(ref.abs().max())) < 1e-3
+    ref_grads = dict(oracle.named_parameters())
+    gmax = max(float(q.grad.abs().max()) for q in ref_grads.values() if q.grad is not None)
+    for n, p in model.named_parameters():
+        r = ref_grads[n].grad
+        assert (r is None) == (p.grad is None), n
+        if r is not None:
+            assert float((p.grad.cpu() - r).abs().max()) <= 2e-3 * max(float(r.abs().max()), 1e-3 * gmax), n
+    import kasportsformer_amd as K
+    with pytest.raises(NotImplementedError):
+        K.KASportsFormer(n_layers=1, num_heads=8, neighbour_num=5)
+
+
 @pytest.mark.parametrize("heads", [4, 16, 2])
 @pytest.mark.parametrize("cd,tol", [("fp32", 2e-3), ("bf16", 0.4)])      # bf16, two clips: observed 0.23-0.30 on the worst (tiny) tensor
 def test_other_head_counts(cd, tol, heads):
