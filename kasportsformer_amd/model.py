@@ -54,7 +54,7 @@ def _mixer_box(kind, dim, nodes):
     return b
 
 
-def _former_box(kind, dim, n_frames, mlp_ratio, ls_init):
+def _former_box(kind, dim, n_frames, mlp_ratio, ls_init, use_layer_scale=True):
     mixer, mode = kind.split("_")           # model/KASportsFormer.py:65-101
     b = _Box()
     b.norm1 = nn.LayerNorm(dim)
@@ -62,8 +62,9 @@ def _former_box(kind, dim, n_frames, mlp_ratio, ls_init):
     b.mixer = _mixer_box(mixer, dim, 17 if mode == "spatial" else n_frames)
     b.norm2 = nn.LayerNorm(dim)
     b.mlp = _mlp_box(dim, int(dim * mlp_ratio), dim)
-    b.layer_scale_1 = nn.Parameter(ls_init * torch.ones(dim))
-    b.layer_scale_2 = nn.Parameter(ls_init * torch.ones(dim))
+    if use_layer_scale:                     # KASportsFormer.py:98-101; without it the block is x + mixer(..), x + mlp(..): the kernels then see the constant 1
+        b.layer_scale_1 = nn.Parameter(ls_init * torch.ones(dim))
+        b.layer_scale_2 = nn.Parameter(ls_init * torch.ones(dim))
     return b
 
 
@@ -103,8 +104,8 @@ class KASportsFormer(nn.Module):
             unsupported.append("act_layer other than nn.GELU")
         if attn_drop or drop or drop_path:
             unsupported.append("dropout > 0 (every shipped yaml uses 0)")
-        if not use_layer_scale or qkv_bias or qkv_scale is not None or hierarchical or not use_temporal_similarity:
-            unsupported.append("use_layer_scale=False / qkv_bias / qkv_scale / hierarchical / use_temporal_similarity=False")
+        if qkv_bias or qkv_scale is not None or hierarchical or not use_temporal_similarity:
+            unsupported.append("qkv_bias / qkv_scale / hierarchical / use_temporal_similarity=False")
         if num_heads not in (2, 4, 8, 16):
             unsupported.append("num_heads not in {2, 4, 8, 16} (8 = configs/*.yaml:84 runs the MFMA attention kernels, the others generic ones)")
         if neighbour_num not in (1, 2, 3, 4) or not 4 <= n_frames <= 256:
@@ -139,7 +140,7 @@ class KASportsFormer(nn.Module):
         for _ in range(n_layers):
             layer = _Box()
             for kind in BLOCK_KINDS:
-                setattr(layer, kind, _former_box(kind, dim_feat, n_frames, mlp_ratio, layer_scale_init_value))
+                setattr(layer, kind, _former_box(kind, dim_feat, n_frames, mlp_ratio, layer_scale_init_value, use_layer_scale))
             layer.fusion_three_channel = nn.Linear(dim_feat * 3, 3)
             layer.fusion_three_channel.weight.data.fill_(0)        # model/KASportsFormer.py:264-266
             layer.fusion_three_channel.bias.data.fill_(1 / 3)
@@ -160,7 +161,10 @@ class KASportsFormer(nn.Module):
         self.n_flat = self._lib.kasf_param_count(self._layout)
         self.n_live = self._lib.kasf_param_live_count(self._layout)
         names = dict(self.named_parameters())
-        if set(names) != set(self._p_entries):
+        # use_layer_scale=False: the library's layer-scale slices stay in the flat array as the constant 1 (x + 1 * f(x) is the reference's x + f(x) bit for bit);
+        # they are not parameters: absent from state_dict / parameters(), never updated (FusedAdamW puts the 1 back after its flat update)
+        self._const_one = sorted((o, int(torch.Size(s).numel())) for n, (o, s) in self._p_entries.items() if n not in names)
+        if set(names) - set(self._p_entries) or any(".layer_scale_" not in n for n in set(self._p_entries) - set(names)) or (use_layer_scale and self._const_one):
             raise RuntimeError("native layout and module tree disagree on parameter names")
         for n, p in names.items():
             if tuple(p.shape) != tuple(self._p_entries[n][1]):
@@ -185,6 +189,10 @@ class KASportsFormer(nn.Module):
             p.data = view
             if off < self.n_live:
                 self._live.append((p, off, p.numel(), tuple(shape)))
+        self._const_index = None
+        if self._const_one:
+            self._const_index = torch.cat([torch.arange(o, o + n, device=dev) for o, n in self._const_one])
+            flat.index_fill_(0, self._const_index, 1.0)
         self._flat = flat
         fbuf = torch.zeros(self._lib.kasf_buffer_count(self._layout), dtype=torch.float32, device=dev)
         nbt = []

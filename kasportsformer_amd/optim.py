@@ -38,6 +38,8 @@ class FusedAdamW:
         _lib.check(_lib.load().kasf_adamw_step(m._flat.data_ptr(), m.flat_grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
                                                m.n_live, g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self.step_index,
                                                self.grad_scale, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        if m._const_index is not None:   # use_layer_scale=False: the layer-scale slices are the constant 1, not parameters
+            m._flat.index_fill_(0, m._const_index, 1.0)
         m.mark_weights_dirty()
 
     def state_dict(self):

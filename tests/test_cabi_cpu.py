@@ -107,6 +107,9 @@ def test_unsupported_configurations_raise_like_the_reference():
     with pytest.raises(NotImplementedError):
         K.KASportsFormer(n_layers=1, num_heads=2, n_frames=158)   # the generic attention backward keeps a head's track in LDS: rejected up front, not at the first backward()
     assert K.KASportsFormer(n_layers=1, num_heads=2, n_frames=157).n_frames == 157
+    m2 = K.KASportsFormer(n_layers=1, num_heads=8, use_layer_scale=False)          # accepted since round 3: the layer-scale slices become the constant 1, not parameters
+    assert not any("layer_scale" in k for k in m2.state_dict()) and len(m2._const_one) == 12 and bool((m2._flat[m2._const_index] == 1.0).all())
+    assert K.KASportsFormer(n_layers=1, num_heads=8, neighbour_num=2).n_frames == 27
     with pytest.raises(NotImplementedError):
         K.KASportsFormer(num_heads=8, act_layer=nn.ReLU)
     m = K.KASportsFormer(n_layers=1, num_heads=8, use_tcn=False, graph_only=False, temporal_connection_len=1)   # dead kwargs accepted

@@ -589,6 +589,51 @@ def test_neighbour_num_other_than_four(k, T):
         K.KASportsFormer(n_layers=1, num_heads=8, neighbour_num=5)
 
 
+@pytest.mark.parametrize("cd,tol", [("fp32", 2e-3), ("bf16", 0.4)])
+def test_without_layer_scale(cd, tol):
+    """use_layer_scale=False (KASportsFormer.py:98-101: x + mixer(norm1(x)), x + mlp(norm2(x)); no layer_scale_* entries in the state_dict).  The library keeps its
+    layer-scale slices as the constant 1; the module exposes exactly the reference's parameters, and two optimizer steps (flat FusedAdamW) leave the constant alone."""
+    import kasportsformer_amd as K
+    oracle, model = make_pair(2, 27, cd, use_layer_scale=False)
+    assert list(model.state_dict().keys()) == list(oracle.state_dict().keys()) and not any("layer_scale" in k for k in model.state_dict())
+    assert sum(p.numel() for p in model.parameters()) == sum(p.numel() for p in oracle.parameters())
+    x, y = O.synthetic_clips(3, 27, seed=31)
+    oracle.train(); model.train()
+    with forced_adjacency(model, x):
+        ref = oracle(x)
+        l_ref, _ = O.loss_total(ref, y)
+        l_ref.backward()
+    pred = model(x.cuda())
+    loss, _ = O.loss_total(pred, y.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    err = _abs_err(pred, ref) / max(1.0, float(ref.abs().max()))
+    assert err < (1e-3 if cd == "fp32" else 0.03), err
+    ref_grads = dict(oracle.named_parameters())
+    gmax = max(float(q.grad.abs().max()) for q in ref_grads.values() if q.grad is not None)
+    worst = 0.0
+    for n, p in model.named_parameters():
+        r = ref_grads[n].grad
+        assert (r is None) == (p.grad is None), n
+        if r is not None:
+            worst = max(worst, float((p.grad.cpu() - r).abs().max() / max(float(r.abs().max()), (1e-3 if cd == "fp32" else 0.05) * gmax)))
+    print(f"[no layer scale, {cd}] forward err {err:.3e}, worst per-tensor gradient error {worst:.3e}")
+    assert worst < tol
+    if cd == "fp32":
+        model.attach_param_grads = False
+        opt, ropt = K.FusedAdamW(model, lr=1e-3, weight_decay=0.01), torch.optim.AdamW(oracle.parameters(), lr=1e-3, weight_decay=0.01)
+        for _ in range(2):
+            opt.zero_grad(); ropt.zero_grad()
+            with forced_adjacency(model, x):
+                O.loss_total(oracle(x), y)[0].backward()
+            K.loss3(model(x.cuda()), y.cuda())[0].backward()
+            opt.step(); ropt.step()
+        torch.cuda.synchronize()
+        assert bool((model._flat[model._const_index] == 1.0).all())
+        for (n, p), (_, q) in zip(model.named_parameters(), oracle.named_parameters()):
+            assert float((p.detach().cpu() - q.detach()).abs().max()) <= 2e-3 * max(1.0, float(q.abs().max())), n
+
+
 @pytest.mark.parametrize("heads", [4, 16, 2])
 @pytest.mark.parametrize("cd,tol", [("fp32", 2e-3), ("bf16", 0.4)])      # bf16, two clips: observed 0.23-0.30 on the worst (tiny) tensor
 def test_other_head_counts(cd, tol, heads):
