@@ -164,6 +164,12 @@ int kasf_op_attention_fwd(int32_t dtype, const void* q, int64_t ldq, const void*
                           int32_t mode, void* stream);
 int kasf_op_attention_bwd(int32_t dtype, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, const void* d_o, void* dq, int64_t lddq,
                           void* dk, void* dv, int64_t lddkv, int32_t batch, int32_t n_frames, int32_t mode, void* stream);
+/* the same for num_heads in {2, 4, 8, 16} (head dimension 128 / num_heads; the two entries above are num_heads = 8): bf16 mode runs MFMA cores for 8 and 4 heads
+ * (4 = the reference constructor's default, KASportsFormer.py:293) on groups of up to 256 positions, LDS-resident fp32 cores otherwise */
+int kasf_op_attention_fwd_heads(int32_t dtype, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, void* o, int32_t batch, int32_t n_frames,
+                                int32_t mode, int32_t num_heads, void* stream);
+int kasf_op_attention_bwd_heads(int32_t dtype, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, const void* d_o, void* dq, int64_t lddq,
+                                void* dk, void* dv, int64_t lddkv, int32_t batch, int32_t n_frames, int32_t mode, int32_t num_heads, void* stream);
 /* bf16, 8 heads, groups of <= 96 positions: the same with d_o = g_mid . wproj_t_scaled^T formed inside the kernel (what the training step runs:
  * attention.py's proj + layer-scale data gradient folded in); wproj_t_scaled [128 in][128 out] = (ls1 . Wproj)^T packed bf16.
  * Groups of <= 32 positions: form 0 = persistent kernel (the engine's), 1 = one group per workgroup (the comparison point): bit-identical results.

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libkasf_hip.so")
 DTYPE_F32, DTYPE_BF16 = 0, 1
 FLAG_TRAIN, FLAG_RETURN_REP, FLAG_KEEP = 1, 2, 4
 EVAL_COLS = 22
-ABI_VERSION = 4          # kasf_version() of the library these prototypes describe (a stale in-tree .so is refused)
+ABI_VERSION = 5          # kasf_version() of the library these prototypes describe (a stale in-tree .so is refused)
 
 
 class KasfConfig(C.Structure):
@@ -68,6 +68,8 @@ SIGNATURES = {
     "kasf_op_dgrad_lnbwd": (_i32, [_i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i64, _vp, _vp, _vp]),
     "kasf_op_attention_fwd": (_i32, [_i32, _vp, _i64, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _vp]),
     "kasf_op_attention_bwd": (_i32, [_i32, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
+    "kasf_op_attention_fwd_heads": (_i32, [_i32, _vp, _i64, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "kasf_op_attention_bwd_heads": (_i32, [_i32, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
     "kasf_op_attention_bwd_fused_do": (_i32, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "kasf_op_cast": (_i32, [_i32, _vp, _vp, _i64, _i32, _vp]),
 }

@@ -502,7 +502,7 @@ extern "C" {
 const char* kasf_last_error(void) { return g_err.c_str(); }
 void kasf_set_deterministic(int32_t on) { g_single_stream = on ? 1 : 0; }
 int32_t kasf_get_deterministic(void) { return single_stream() ? 1 : 0; }
-int kasf_version(void) { return 4; }
+int kasf_version(void) { return 5; }
 
 int kasf_model_create(const kasf_config* cfg, kasf_model** out) {
     if (cfg == nullptr || out == nullptr) return kasf_set_error(2, "null argument");
@@ -913,6 +913,22 @@ int kasf_op_attention_bwd(int32_t dtype, const void* q, int64_t ldq, const void*
     OP_DT_CHECK(dtype);
     g_err.clear();
     kasf_launch_attn_bwd(dtype, (hipStream_t)stream, q, ldq, k, v, ldkv, d_o, dq, lddq, dk, dv, lddkv, batch, n_frames, mode);
+    HIPCHK(hipGetLastError());
+    return g_err.empty() ? 0 : 3;
+}
+int kasf_op_attention_fwd_heads(int32_t dtype, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, void* o, int32_t batch, int32_t n_frames,
+                                int32_t mode, int32_t num_heads, void* stream) {
+    OP_DT_CHECK(dtype);
+    g_err.clear();
+    kasf_launch_attn_fwd(dtype, (hipStream_t)stream, q, ldq, k, v, ldkv, o, batch, n_frames, mode, num_heads);
+    HIPCHK(hipGetLastError());
+    return g_err.empty() ? 0 : 3;
+}
+int kasf_op_attention_bwd_heads(int32_t dtype, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, const void* d_o, void* dq, int64_t lddq,
+                                void* dk, void* dv, int64_t lddkv, int32_t batch, int32_t n_frames, int32_t mode, int32_t num_heads, void* stream) {
+    OP_DT_CHECK(dtype);
+    g_err.clear();
+    kasf_launch_attn_bwd(dtype, (hipStream_t)stream, q, ldq, k, v, ldkv, d_o, dq, lddq, dk, dv, lddkv, batch, n_frames, mode, num_heads);
     HIPCHK(hipGetLastError());
     return g_err.empty() ? 0 : 3;
 }

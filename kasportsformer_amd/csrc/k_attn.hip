@@ -233,15 +233,17 @@ void bwd_T(hipStream_t s, const void* q, int64_t ldq, const void* k, const void*
 
 }  // namespace
 
-// heads != 8 (head dimension != 16): the generic kernels above in both modes; the MFMA cores are built around 16-wide heads
+// heads = 8 and heads = 4 (head dimensions 16 and 32) have MFMA cores in bf16 mode (k_attn_mfma.hip); 2 and 16 heads, and fp32 mode, run the kernels above
 void kasf_launch_attn_fwd(int dt, hipStream_t s, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, void* o, int B, int T,
                           int mode, int heads) {
     if (dt == KASF_F32) fwd_T<float>(s, q, ldq, k, v, ldkv, o, B, T, mode, heads);
+    else if (heads == 4 && kasf_launch_attn_fwd_mfma32(s, q, ldq, k, v, ldkv, o, B, T, mode)) return;
     else if (heads != 8 || !kasf_launch_attn_fwd_mfma(s, q, ldq, k, v, ldkv, o, B, T, mode)) fwd_T<bf16>(s, q, ldq, k, v, ldkv, o, B, T, mode, heads);
 }
 void kasf_launch_attn_bwd(int dt, hipStream_t s, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, const void* d_o, void* dq,
                           int64_t lddq, void* dk, void* dv, int64_t lddkv, int B, int T, int mode, int heads) {
     if (dt == KASF_F32) bwd_T<float>(s, q, ldq, k, v, ldkv, d_o, dq, lddq, dk, dv, lddkv, B, T, mode, heads);
+    else if (heads == 4 && kasf_launch_attn_bwd_mfma32(s, q, ldq, k, v, ldkv, d_o, dq, lddq, dk, dv, lddkv, B, T, mode)) return;
     else if (heads != 8 || !kasf_launch_attn_bwd_mfma(s, q, ldq, k, v, ldkv, d_o, dq, lddq, dk, dv, lddkv, B, T, mode))
         bwd_T<bf16>(s, q, ldq, k, v, ldkv, d_o, dq, lddq, dk, dv, lddkv, B, T, mode, heads);
 }

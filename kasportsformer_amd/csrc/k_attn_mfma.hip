@@ -943,6 +943,223 @@ __global__ __launch_bounds__(512, 4) void k_attn_bwd_pers(const bf16* __restrict
     flush(g0 + ng - 1);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Head dimension 32 (num_heads = 4: the reference constructor's default, KASportsFormer.py:293).  Same orientation rules as above; what changes:
+// two k-steps per score product (32 channels), the [positions][32] operand tiles are read transposed with tr_frag32 and fill all 32 rows of the
+// d-indexed products (the 16-wide heads use half of them), the scale 32^-0.5 is not a power of two and stays an fp32 multiply, and a lane's 16
+// output registers are 4 x 4 channels that leave as two 16-byte stores after the half swap.  One wave per (group, head), the 4 heads of a group per
+// workgroup.  Forward: k_attn_fwd_mfma's program.  Backward: k_attn_bwd_2p's two passes for every group length up to 256 (V in registers through
+// pass A: 8 VGPRs per key tile, so the long instantiations run one wave per SIMD).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bf16x8 row_frag32(const bf16* base, int64_t ld, int G, int pos, int L, int Tn, int mode, int h, int s, int hh, bf16* s_tile) {
+    bf16x8 v = zero8();
+    if (pos < L) v = *reinterpret_cast<const bf16x8*>(base + tok_of(G, pos, Tn, mode) * ld + h * 32 + 16 * s + 8 * hh);
+    if (s_tile != nullptr) *reinterpret_cast<bf16x8*>(s_tile + pos * 32 + 16 * s + 8 * hh) = v;
+    return v;
+}
+// lane = position, registers 4a .. 4a+3 = channels 8a + 4hh + {0..3} (a = 0..3)  ->  lane half hh stores channels 8hh .. 8hh+7 and 16 + 8hh .. 16 + 8hh+7
+__device__ __forceinline__ void store_t32(bf16* dst, const f32x16& t, int hh) {
+    const auto s0 = __builtin_amdgcn_permlane32_swap(pack2(t[0], t[1]), pack2(t[4], t[5]), false, false);
+    const auto s1 = __builtin_amdgcn_permlane32_swap(pack2(t[2], t[3]), pack2(t[6], t[7]), false, false);
+    const auto s2 = __builtin_amdgcn_permlane32_swap(pack2(t[8], t[9]), pack2(t[12], t[13]), false, false);
+    const auto s3 = __builtin_amdgcn_permlane32_swap(pack2(t[10], t[11]), pack2(t[14], t[15]), false, false);
+    *reinterpret_cast<u32x4_t*>(dst + 8 * hh) = u32x4_t{s0[0], s1[0], s0[1], s1[1]};
+    *reinterpret_cast<u32x4_t*>(dst + 16 + 8 * hh) = u32x4_t{s2[0], s3[0], s2[1], s3[1]};
+}
+constexpr float SCALE32 = 0.17677669529663687f;                  // 32 ** -0.5 (selfattention.py:12)
+
+template <int NKT>
+__global__ __launch_bounds__(256) void k_attn_fwd_mfma32(const bf16* __restrict__ Q, int64_t ldq, const bf16* __restrict__ K, const bf16* __restrict__ V,
+                                                         int64_t ldkv, bf16* __restrict__ O, int L, int Tn, int mode, int units) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
+    const int unit = blockIdx.x * 4 + wave;
+    if (unit >= units) return;                                   // wave-uniform; no workgroup barrier below
+    const int G = unit >> 2, h = unit & 3;
+    bf16* sV = reinterpret_cast<bf16*>(smem) + wave * (NKT * 32 * 32);
+    bf16x8 kf[NKT][2];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            kf[kt][s] = row_frag32(K, ldkv, G, 32 * kt + r, L, Tn, mode, h, s, hh, nullptr);
+            row_frag32(V, ldkv, G, 32 * kt + r, L, Tn, mode, h, s, hh, sV);
+        }
+#pragma unroll
+    for (int qt = 0; qt < NKT; ++qt) {
+        if (32 * qt >= L) break;
+        const int i = 32 * qt + r;
+        const bf16x8 qf0 = row_frag32(Q, ldq, G, i, L, Tn, mode, h, 0, hh, nullptr), qf1 = row_frag32(Q, ldq, G, i, L, Tn, mode, h, 1, hh, nullptr);
+        f32x16 st[NKT];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            st[kt] = mfma32(kf[kt][1], qf1, mfma32(kf[kt][0], qf0, zero16()));       // S^T[key][query]
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const float sv = (32 * kt + pos_of(g, hh) < L) ? st[kt][g] * SCALE32 : -INFINITY;
+                st[kt][g] = sv;
+                mx = fmaxf(mx, sv);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) { st[kt][g] = __expf(st[kt][g] - mx); sum += st[kt][g]; }
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.0f / sum;
+        f32x16 ot = zero16();
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+            for (int g = 0; g < 16; ++g) st[kt][g] *= inv;
+            ot = mfma32(tr_frag32(sV + kt * 1024, 0), pack8(st[kt], 0), ot);        // O^T[d][query] += V^T . P^T, all 32 rows live
+            ot = mfma32(tr_frag32(sV + kt * 1024, 1), pack8(st[kt], 1), ot);
+        }
+        if (i < L) store_t32(O + tok_of(G, i, Tn, mode) * 128 + h * 32, ot, hh);
+    }
+}
+
+template <int NKT>
+__global__ __launch_bounds__(256) void k_attn_bwd_2p32(const bf16* __restrict__ Q, int64_t ldq, const bf16* __restrict__ K, const bf16* __restrict__ V,
+                                                       int64_t ldkv, const bf16* __restrict__ dO, bf16* __restrict__ dQ, int64_t lddq, bf16* __restrict__ dK,
+                                                       bf16* __restrict__ dV, int64_t lddkv, int L, int Tn, int mode, int units) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TILE = NKT * 32 * 32;                           // [positions][32] operand tile (bf16 elements)
+    constexpr int WAVE_BYTES = 2 * TILE * 2 + 2 * NKT * 32 * 4;
+    constexpr float C2 = SCALE32 * 1.4426950408889634f;           // scale . log2(e)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
+    const int unit = blockIdx.x * 4 + wave;
+    if (unit >= units) return;                                    // wave-uniform; no workgroup barrier below
+    const int G = unit >> 2, h = unit & 3;
+    bf16* sK = reinterpret_cast<bf16*>(smem + wave * WAVE_BYTES); // pass A: K;  pass B: Q
+    bf16* sQ = sK;
+    bf16* sD = sK + TILE;
+    float* sLse = reinterpret_cast<float*>(sD + TILE);            // [32 NKT]  -lse . log2(e)
+    float* sDel = sLse + NKT * 32;                                //           -delta
+    const int nt = (L + 31) >> 5;
+    bf16x8 vf[NKT][2];
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) {
+        if (t >= nt) break;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            row_frag32(K, ldkv, G, 32 * t + r, L, Tn, mode, h, s, hh, sK);
+            row_frag32(dO, 128, G, 32 * t + r, L, Tn, mode, h, s, hh, sD);
+            vf[t][s] = row_frag32(V, ldkv, G, 32 * t + r, L, Tn, mode, h, s, hh, nullptr);
+        }
+    }
+    bf16x8 qn0 = row_frag32(Q, ldq, G, r, L, Tn, mode, h, 0, hh, nullptr), qn1 = row_frag32(Q, ldq, G, r, L, Tn, mode, h, 1, hh, nullptr);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // the tiles were written by other lanes of this wave
+    auto rowf = [&](const bf16* tile, int t, int s) { return *reinterpret_cast<const bf16x8*>(tile + (32 * t + r) * 32 + 16 * s + 8 * hh); };
+    // ---------------- pass A: lane = query ----------------
+    for (int qt = 0; qt < nt; ++qt) {
+        const int i = 32 * qt + r;
+        const bf16x8 qf0 = qn0, qf1 = qn1, df0 = rowf(sD, qt, 0), df1 = rowf(sD, qt, 1);
+        if (qt + 1 < nt) {
+            qn0 = row_frag32(Q, ldq, G, i + 32, L, Tn, mode, h, 0, hh, nullptr);
+            qn1 = row_frag32(Q, ldq, G, i + 32, L, Tn, mode, h, 1, hh, nullptr);
+        }
+        f32x16 st[NKT];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            if (kt >= nt) break;
+            st[kt] = mfma32(rowf(sK, kt, 1), qf1, mfma32(rowf(sK, kt, 0), qf0, zero16()));       // S^T[key][query]
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const float sv = (kt < nt - 1 || 32 * kt + pos_of(g, hh) < L) ? st[kt][g] * SCALE32 : -INFINITY;
+                st[kt][g] = sv;
+                mx = fmaxf(mx, sv);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            if (kt >= nt) break;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) { st[kt][g] = __expf(st[kt][g] - mx); sum += st[kt][g]; }
+        }
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.0f / sum;
+        float delta = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            if (kt >= nt) break;
+            const f32x16 dp = mfma32(vf[kt][1], df1, mfma32(vf[kt][0], df0, zero16()));          // dP^T[key][query]
+#pragma unroll
+            for (int g = 0; g < 16; ++g) { st[kt][g] *= inv; delta += st[kt][g] * dp[g]; }
+        }
+        delta += __shfl_xor(delta, 32);
+        if (hh == 0) { sLse[i] = i < L ? -(mx + __logf(sum)) * 1.4426950408889634f : -INFINITY; sDel[i] = -delta; }   // rows past L: exp2(-inf) = 0 in pass B
+        f32x16 dq = zero16();
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            if (kt >= nt) break;
+            const f32x16 dp = mfma32(vf[kt][1], df1, mfma32(vf[kt][0], df0, zero16()));
+#pragma unroll
+            for (int g = 0; g < 16; ++g) st[kt][g] = st[kt][g] * (dp[g] - delta) * SCALE32;        // dS^T (scale folded)
+            dq = mfma32(tr_frag32(sK + kt * 1024, 0), pack8(st[kt], 0), dq);                       // dQ^T[d][query] += K^T . dS^T
+            dq = mfma32(tr_frag32(sK + kt * 1024, 1), pack8(st[kt], 1), dq);
+        }
+        if (i < L) store_t32(dQ + tok_of(G, i, Tn, mode) * lddq + h * 32, dq, hh);
+    }
+    // between the passes Q takes K's place (same-wave LDS requests are served in issue order: the stores land behind pass A's last reads)
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) {
+        if (t >= nt) break;
+        row_frag32(Q, ldq, G, 32 * t + r, L, Tn, mode, h, 0, hh, sQ);
+        row_frag32(Q, ldq, G, 32 * t + r, L, Tn, mode, h, 1, hh, sQ);
+    }
+    bf16x8 kn0 = row_frag32(K, ldkv, G, r, L, Tn, mode, h, 0, hh, nullptr), kn1 = row_frag32(K, ldkv, G, r, L, Tn, mode, h, 1, hh, nullptr);
+    bf16x8 vn0 = vf[0][0], vn1 = vf[0][1];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // Q, lse and delta were written by other lanes of this wave
+    auto stat16 = [&](const float* stp, int qt) {
+        f32x16 c;
+#pragma unroll
+        for (int a4 = 0; a4 < 4; ++a4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(stp + 32 * qt + 8 * a4 + 4 * hh);
+            c[4 * a4] = v[0]; c[4 * a4 + 1] = v[1]; c[4 * a4 + 2] = v[2]; c[4 * a4 + 3] = v[3];
+        }
+        return c;
+    };
+    // ---------------- pass B: lane = key, key-tile-outer ----------------
+    for (int kt = 0; kt < nt; ++kt) {
+        const bf16x8 kf0 = kn0, kf1 = kn1, vk0 = vn0, vk1 = vn1;
+        if (kt + 1 < nt) {
+            kn0 = row_frag32(K, ldkv, G, 32 * (kt + 1) + r, L, Tn, mode, h, 0, hh, nullptr);
+            kn1 = row_frag32(K, ldkv, G, 32 * (kt + 1) + r, L, Tn, mode, h, 1, hh, nullptr);
+            vn0 = row_frag32(V, ldkv, G, 32 * (kt + 1) + r, L, Tn, mode, h, 0, hh, nullptr);
+            vn1 = row_frag32(V, ldkv, G, 32 * (kt + 1) + r, L, Tn, mode, h, 1, hh, nullptr);
+        }
+        f32x16 dv = zero16(), dk = zero16();
+        for (int qt = 0; qt < nt; ++qt) {
+            const f32x16 nl = stat16(sLse, qt);
+            f32x16 p = mfma32(rowf(sQ, qt, 1), kf1, mfma32(rowf(sQ, qt, 0), kf0, zero16()));          // S[query][key]: lane = key, registers = queries
+            f32x16 ds = mfma32(rowf(sD, qt, 1), vk1, mfma32(rowf(sD, qt, 0), vk0, stat16(sDel, qt)));  // dP[query][key] - delta (delta rides in as the initial accumulator)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(p[g], C2, nl[g]));
+                p[g] = pv;
+                ds[g] = pv * ds[g] * SCALE32;
+            }
+            dv = mfma32(tr_frag32(sD + qt * 1024, 0), pack8(p, 0), dv);                // dV^T[d][key] += d_o^T . P
+            dk = mfma32(tr_frag32(sQ + qt * 1024, 0), pack8(ds, 0), dk);               // dK^T[d][key] += Q^T . dS
+            dv = mfma32(tr_frag32(sD + qt * 1024, 1), pack8(p, 1), dv);
+            dk = mfma32(tr_frag32(sQ + qt * 1024, 1), pack8(ds, 1), dk);
+        }
+        const int j = 32 * kt + r;
+        if (j < L) {
+            const int64_t tok = tok_of(G, j, Tn, mode);
+            store_t32(dV + tok * lddkv + h * 32, dv, hh);
+            store_t32(dK + tok * lddkv + h * 32, dk, hh);
+        }
+    }
+}
+
 template <typename K> bool set_smem(K k, size_t bytes) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) kasf_set_error(1000 + (int)e, "attention (MFMA): cannot reserve the group's LDS tiles");
@@ -1046,5 +1263,41 @@ bool kasf_launch_attn_bwd_fused_do(hipStream_t s, const void* q, int64_t ldq, co
     if (!set_smem(k_attn_bwd_mfma<1, true>, sh)) return true;
     hipLaunchKernelGGL((k_attn_bwd_mfma<1, true>), dim3(groups), dim3(512), sh, s, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldkv,
                        (const bf16*)nullptr, (bf16*)dq, lddq, (bf16*)dk, (bf16*)dv, lddkv, L, Tn, mode, groups * 8, (const bf16*)g_mid, (const bf16*)WprojTs);
+    return true;
+}
+
+// num_heads = 4 (head dimension 32): groups of up to 256 positions.  false: shape not covered (the caller runs the LDS-resident fp32 cores)
+bool kasf_launch_attn_fwd_mfma32(hipStream_t s, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, void* o, int B, int Tn, int mode) {
+    const int L = mode == 0 ? KASF_J : Tn, groups = mode == 0 ? B * Tn : B * KASF_J, units = groups * 4;
+    if (L > 256) return false;
+    auto go = [&](auto NK) {
+        constexpr int NKT = decltype(NK)::value;
+        const size_t sh = 4 * (size_t)NKT * 32 * 32 * 2;
+        if (!set_smem(k_attn_fwd_mfma32<NKT>, sh)) return;
+        hipLaunchKernelGGL(k_attn_fwd_mfma32<NKT>, dim3(groups), dim3(256), sh, s, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldkv, (bf16*)o, L, Tn, mode, units);
+    };
+    if (L <= 32) go(std::integral_constant<int, 1>{});
+    else if (L <= 96) go(std::integral_constant<int, 3>{});
+    else if (L <= 128) go(std::integral_constant<int, 4>{});
+    else if (L <= 192) go(std::integral_constant<int, 6>{});
+    else go(std::integral_constant<int, 8>{});
+    return true;
+}
+bool kasf_launch_attn_bwd_mfma32(hipStream_t s, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, const void* d_o, void* dq,
+                                 int64_t lddq, void* dk, void* dv, int64_t lddkv, int B, int Tn, int mode) {
+    const int L = mode == 0 ? KASF_J : Tn, groups = mode == 0 ? B * Tn : B * KASF_J, units = groups * 4;
+    if (L > 256) return false;
+    auto go = [&](auto NK) {
+        constexpr int NKT = decltype(NK)::value;
+        const size_t sh = 4 * (size_t)(2 * NKT * 32 * 32 * 2 + 2 * NKT * 32 * 4);
+        if (!set_smem(k_attn_bwd_2p32<NKT>, sh)) return;
+        hipLaunchKernelGGL(k_attn_bwd_2p32<NKT>, dim3(groups), dim3(256), sh, s, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldkv, (const bf16*)d_o, (bf16*)dq, lddq,
+                           (bf16*)dk, (bf16*)dv, lddkv, L, Tn, mode, units);
+    };
+    if (L <= 32) go(std::integral_constant<int, 1>{});
+    else if (L <= 96) go(std::integral_constant<int, 3>{});
+    else if (L <= 128) go(std::integral_constant<int, 4>{});
+    else if (L <= 192) go(std::integral_constant<int, 6>{});
+    else go(std::integral_constant<int, 8>{});
     return true;
 }

@@ -110,6 +110,9 @@ void kasf_launch_attn_bwd(int dt, hipStream_t s, const void* q, int64_t ldq, con
 bool kasf_launch_attn_fwd_mfma(hipStream_t s, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, void* o, int B, int T, int mode);
 bool kasf_launch_attn_bwd_mfma(hipStream_t s, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, const void* d_o, void* dq,
                                int64_t lddq, void* dk, void* dv, int64_t lddkv, int B, int T, int mode);
+bool kasf_launch_attn_fwd_mfma32(hipStream_t s, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, void* o, int B, int T, int mode);   // num_heads = 4
+bool kasf_launch_attn_bwd_mfma32(hipStream_t s, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, const void* d_o, void* dq, int64_t lddq,
+                                 void* dk, void* dv, int64_t lddkv, int B, int T, int mode);
 
 // ---- k_gcn.hip ----
 void kasf_gcn_init();   // uploads the skeleton table to constant memory (blocking; call once per process before capture)

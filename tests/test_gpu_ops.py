@@ -254,6 +254,33 @@ def test_attention_core(lib, cd, mode, T):
     assert rel_err(_back(dqkv), qr.grad) < TOL[cd]
 
 
+@pytest.mark.parametrize("cd", ["fp32", "bf16"])
+@pytest.mark.parametrize("heads,mode,T", [(4, 0, 27), (4, 1, 27), (4, 1, 9), (4, 1, 32), (4, 1, 33), (4, 1, 81), (4, 1, 96), (4, 1, 97), (4, 1, 130), (4, 1, 243), (4, 1, 256),
+                                          (4, 1, 257), (16, 1, 27), (2, 0, 27)])
+def test_attention_core_other_head_counts(lib, cd, heads, mode, T):
+    """num_heads = 4 is the reference constructor's default (KASportsFormer.py:293; head dimension 32, scale 32 ** -0.5): bf16 mode runs MFMA cores of its own
+    (k_attn_fwd_mfma32 / k_attn_bwd_2p32: 1, 3, 4, 6, 8 key tiles; 257 positions fall back to the LDS-resident cores, like 2 and 16 heads and fp32 mode)."""
+    from kasportsformer_amd import _lib
+    from oracle.kasf_oracle import attention_core, _heads
+    B = 2
+    qkv = _rand(B, T, 17, 384, seed=24)
+    do = _rand(B, T, 17, 128, seed=25)
+    qd, dod = _dev(qkv, cd), _dev(do, cd)
+    o = torch.empty(B, T, 17, 128, device="cuda", dtype=DT[cd][1])
+    dqkv = torch.zeros_like(qd)
+    es, base, db = qd.element_size(), qd.data_ptr(), dqkv.data_ptr()
+    _lib.check(lib.kasf_op_attention_fwd_heads(DT[cd][0], base, 384, base + 128 * es, base + 256 * es, 384, ptr(o), B, T, mode, heads, stream()))
+    _lib.check(lib.kasf_op_attention_bwd_heads(DT[cd][0], base, 384, base + 128 * es, base + 256 * es, 384, ptr(dod), db, 384, db + 128 * es, db + 256 * es, 384,
+                                               B, T, mode, heads, stream()))
+    torch.cuda.synchronize()
+    qr = _back(qd).requires_grad_(True)
+    q, k, v = _heads(qr, 3, heads)
+    ref = attention_core(q, k, v, "spatial" if mode == 0 else "temporal", (128 // heads) ** -0.5)
+    ref.backward(_back(dod))
+    assert rel_err(_back(o), ref) < TOL[cd]
+    assert rel_err(_back(dqkv), qr.grad) < TOL[cd]
+
+
 @pytest.mark.parametrize("bone", [False, True])
 @pytest.mark.parametrize("mode,T,B", [(0, 27, 2), (1, 27, 3), (1, 9, 2), (0, 27, 41), (1, 32, 67), (0, 4, 1)])     # 41 x 27 = 1,107 groups: three per persistent
 def test_attention_backward_fused_do(lib, bone, mode, T, B):                                                     # workgroup, last range short; 67 x 17 = 1,139
