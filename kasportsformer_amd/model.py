@@ -25,7 +25,7 @@ class _Box(nn.Module):
     """Parameter container: mirrors a reference sub-module's registration order, has no forward."""
 
     def forward(self, *a, **k):  # pragma: no cover
-        raise RuntimeError("kasportsformer_amd sub-modules hold parameters only; call the top-level KASportsFormer")
+        raise RuntimeError("kasportsformer_amd sub-modules hold parameters only; call the top-level KASportsFormer (intermediate activations: model.stage_outputs(x))")
 
 
 def _mlp_box(d_in, d_hidden, d_out):
@@ -276,6 +276,32 @@ class KASportsFormer(nn.Module):
         if self.training:
             self._nbt += 1                      # BatchNorm num_batches_tracked (graph.py:37)
         return out, ws, flags
+
+    @torch.no_grad()
+    def stage_outputs(self, x):
+        """The forward pass is ONE library call, so forward hooks on the sub-modules never fire (their `forward` raises).  This is the replacement for
+        hook-based inspection: runs the forward in the module's current mode and returns `(out, stages)` where `stages` maps the reference's module names
+        to what a forward hook on that module would have seen as its output -- `layers_with_bone.<l>.<kind>` (the six FormerModules of a layer,
+        KASportsFormer.py:204-286), `layers_with_bone.<l>` (the gated sum) -- plus `joints_embed` / `bone_embed` / `limb_embed` (the three streams entering
+        layer 0, position embeddings added) and `rep_logit`.  Tensors are fp32 copies `[B, T, 17, C]`; bf16 mode returns the stored bf16 values widened.
+        Training mode also updates the BatchNorm running statistics once, like any forward."""
+        self._check_input(x)
+        out, ws, flags = self._launch_forward(x, False, keep=True)
+        B, T = x.shape[0], self.n_frames
+        ents = _lib.ws_entries(self._device_handle(), B, flags)
+        act = torch.bfloat16 if self.compute_dtype == "bf16" else torch.float32
+        def get(name, width=128):
+            off, numel, kind = ents[name]
+            dt = {0: act, 1: torch.float32}[kind]
+            nbytes = numel * torch.empty((), dtype=dt).element_size()
+            return ws[off:off + nbytes].view(dt).float().view(B, T, 17, width).clone()
+        stages = {"joints_embed": get("x_joint"), "bone_embed": get("x_bone"), "limb_embed": get("x_limb")}
+        for l in range(self.n_layers):
+            for kind in BLOCK_KINDS:
+                stages[f"layers_with_bone.{l}.{kind}"] = get(f"L{l}.{kind}.x_out")
+            stages[f"layers_with_bone.{l}"] = get(f"L{l}.gate_out")
+        stages["rep_logit"] = get("rep", 512)
+        return out, stages
 
     def _launch_backward(self, ws, dout, B, flags):
         h = self._device_handle()

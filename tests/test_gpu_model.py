@@ -57,6 +57,35 @@ def test_fp32_forward_matches_reference_golden(name, tol):
             assert _abs_err(sd[k[4:]].to(ref.dtype), ref) < 1e-4, k
 
 
+def test_stage_outputs_equal_forward_hooks_on_the_reference_modules():
+    """`model.stage_outputs(x)` (the replacement for hook-based inspection: the sub-modules are parameter holders, the forward is one library call) returns, under the
+    reference's module names, what forward hooks on those modules capture in the oracle -- in training and in evaluation mode -- and the same `out` as `model(x)`."""
+    oracle, model = make_pair(2, 27, "fp32")
+    x, _ = O.synthetic_clips(2, 27, seed=5)
+    for train in (True, False):
+        oracle.train(train); model.train(train)
+        cap = {}
+        for li, layer in enumerate(oracle.layers_with_bone):
+            for kind in O.BLOCK_KINDS:
+                getattr(layer, kind).register_forward_hook(lambda m, i, o, k=f"layers_with_bone.{li}.{kind}": cap.__setitem__(k, o.detach()))
+            layer.register_forward_hook(lambda m, i, o, k=f"layers_with_bone.{li}": cap.__setitem__(k, o.detach()))
+        oracle.rep_logit.register_forward_hook(lambda m, i, o: cap.__setitem__("rep_logit", o.detach()))
+        buf = model._flat_buffers.clone()
+        with forced_adjacency(model, x):
+            ref = oracle(x)
+        out, stages = model.stage_outputs(x.cuda())
+        if train:
+            model._flat_buffers.copy_(buf)
+        assert set(cap) <= set(stages) and {"joints_embed", "bone_embed", "limb_embed"} <= set(stages)
+        for name, r in cap.items():
+            assert _abs_err(stages[name], r) / max(1.0, float(r.abs().max())) < 1e-3, (name, train)
+        assert _abs_err(out, ref) / max(1.0, float(ref.abs().max())) < 1e-3
+        with torch.no_grad():
+            assert torch.equal(out, model(x.cuda())) or train      # (training mode: the second forward sees updated running statistics only in its buffers, not in `out`)
+        with pytest.raises(RuntimeError):
+            model.layers_with_bone[0].att_spatial(x.cuda())
+
+
 @pytest.mark.parametrize("cd,tol", [("fp32", 1e-3), ("bf16", 0.05)])      # bf16: observed 2.5e-2 (x 2)
 def test_stage_by_stage_against_oracle(cd, tol):
     """Every FormerModule / layer output of a 2-layer model (layer 0 exercises the bone-embedding start)."""
