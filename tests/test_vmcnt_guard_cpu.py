@@ -61,7 +61,7 @@ def compile_to_asm(src: str) -> str:
     deps = [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in ("common.h", "kernels.h", "tile_ops.h")]
     if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
         return out
-    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
            "--cuda-device-only", "-S", "-o", out, os.path.join(CSRC, src)]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
