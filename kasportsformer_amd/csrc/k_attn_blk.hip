@@ -11,6 +11,7 @@
 // HBM traffic per token: 256 B in (512 B for the bone form), 256 B out, plus -- in training only -- q|k|v and the attention output,
 // which the backward pass needs (written once).  The unfused path moved 2.8 KB per token.
 #include <type_traits>
+#include <cstdio>
 #include "common.h"
 #include "kernels.h"
 #include "tile_ops.h"
@@ -232,23 +233,26 @@ __global__ __launch_bounds__(AB_THR, BONE ? KASF_RP_BONE_WAVES : 4) void k_attn_
 #pragma unroll
             for (int e = 0; e < 16; ++e) z[e] = 0.f;
             f32x16 st = mfma32(kf, qf, z);               // S^T[key][query]
+            // softmax with the fewest vector instructions per score (as in k_attn_blk_fwd_rp3): max over the raw scores, scale and log2(e) in one fma,
+            // 1 / sum applied to the 8 outputs of the lane instead of its 16 probabilities
             float mx = -INFINITY;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const float sv = pos_of(e, hh) < L ? st[e] * 0.25f : -INFINITY;
-                st[e] = sv;
-                mx = fmaxf(mx, sv);
+                st[e] = pos_of(e, hh) < L ? st[e] : -INFINITY;
+                mx = fmaxf(mx, st[e]);
             }
             mx = fmaxf(mx, __shfl_xor(mx, 32));
+            constexpr float C2 = 0.25f * 1.4426950408889634f;     // scale . log2(e)
+            const float nm = -mx * C2;
             float sum = 0.f;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) { st[e] = __expf(st[e] - mx); sum += st[e]; }
+            for (int e = 0; e < 16; ++e) { st[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[e], C2, nm)); sum += st[e]; }
             sum += __shfl_xor(sum, 32);
             const float inv = 1.0f / sum;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) st[e] *= inv;
             f32x16 ot = mfma32(tr_frag(sVh, 0), pack8(st, 0), z);
             ot = mfma32(tr_frag(sVh, 1), pack8(st, 1), ot);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ot[e] *= inv;
             float o0[4] = {ot[0], ot[1], ot[2], ot[3]}, o1[4] = {ot[4], ot[5], ot[6], ot[7]};
             store4(sO + Tile<bf16>::off4(r32, 16 * w + 4 * hh), o0);
             store4(sO + Tile<bf16>::off4(r32, 16 * w + 8 + 4 * hh), o1);
@@ -392,7 +396,16 @@ __global__ __launch_bounds__(AB_THR, 2) void k_attn_blk_fwd_rp3(const AttnBlkArg
     };
     fetch(0);
     __syncthreads();                                     // sLn
+#ifdef RP3_PROF
+    long long acc_t[8] = {0,0,0,0,0,0,0,0};
+#define RT(k) do { const long long n_ = clock64(); acc_t[k] += n_ - t_; t_ = n_; } while (0)
+#else
+#define RT(k) do {} while (0)
+#endif
     for (int t = 0; t < ng; ++t) {
+#ifdef RP3_PROF
+        long long t_ = clock64();
+#endif
         const int G = g0 + t;
         const bf16x8 zero = {};
         bf16x8 lc[NKT];
@@ -405,7 +418,9 @@ __global__ __launch_bounds__(AB_THR, 2) void k_attn_blk_fwd_rp3(const AttnBlkArg
             layernorm(xc, row, sLn, sLn + 128);
         }
         if (t + 1 < ng) fetch(t + 1);
+        RT(0);
         __syncthreads();                                 // B1: raw and LN(x) tiles complete; every wave finished the copy-out of the previous group
+        RT(1);
         if (BONE) {
             project(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});          // q_h from LN(x)
             __syncthreads();                             // every wave is done with LN(x)
@@ -417,6 +432,7 @@ __global__ __launch_bounds__(AB_THR, 2) void k_attn_blk_fwd_rp3(const AttnBlkArg
             project(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{});
         }
         lds_fence();
+        RT(2);
         if (a.Qs != nullptr) {   // training: the backward pass reads q | k | v
 #pragma unroll
             for (int jb = 0; jb < NKT; ++jb) {
@@ -437,6 +453,7 @@ __global__ __launch_bounds__(AB_THR, 2) void k_attn_blk_fwd_rp3(const AttnBlkArg
                 }
             }
         }
+        RT(3);
         {   // ---- attention core of head w (k_attn_fwd_mfma<3>) ----
             bf16x8 kf[NKT];
 #pragma unroll
@@ -448,42 +465,49 @@ __global__ __launch_bounds__(AB_THR, 2) void k_attn_blk_fwd_rp3(const AttnBlkArg
             for (int qt = 0; qt < NKT; ++qt) {
                 if (32 * qt >= L) break;
                 const bf16x8 qf = *reinterpret_cast<const bf16x8*>(sQh + (32 * qt + r32) * 16 + 8 * hh);
+                // Softmax with the fewest vector instructions per score (the core is bound by their issue: in-kernel stamps, 41 % of the launch): the maximum is taken
+                // over the RAW scores (a positive scale commutes with max), the scale and the log2(e) of the exponential are one fma, only the tile that can hold
+                // keys past L is masked, and the 1 / sum is applied to the 16 outputs instead of the 48 probabilities (P <= 1 either way: same bf16 range).
                 f32x16 st[NKT];
                 float mx = -INFINITY;
 #pragma unroll
                 for (int kt = 0; kt < NKT; ++kt) {
                     st[kt] = mfma32(kf[kt], qf, z);
+                    if (kt > 0) {                             // (keys 0..31 are live for every group this kernel takes: L > 32)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const float sv = (32 * kt + pos_of(e, hh) < L) ? st[kt][e] * 0.25f : -INFINITY;
-                        st[kt][e] = sv;
-                        mx = fmaxf(mx, sv);
+                        for (int e = 0; e < 16; ++e) st[kt][e] = (32 * kt + pos_of(e, hh) < L) ? st[kt][e] : -INFINITY;
                     }
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) mx = fmaxf(mx, st[kt][e]);
                 }
                 mx = fmaxf(mx, __shfl_xor(mx, 32));
+                constexpr float C2 = 0.25f * 1.4426950408889634f;     // scale . log2(e)
+                const float nm = -mx * C2;
                 float sum = 0.f;
 #pragma unroll
                 for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) { st[kt][e] = __expf(st[kt][e] - mx); sum += st[kt][e]; }
+                    for (int e = 0; e < 16; ++e) { st[kt][e] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kt][e], C2, nm)); sum += st[kt][e]; }
                 sum += __shfl_xor(sum, 32);
                 const float inv = 1.0f / sum;
                 if (a.LSE != nullptr && hh == 0 && 32 * qt + r32 < L)      // the backward pass rebuilds P = exp(s - lse) tile by tile without a statistics pass
-                    a.LSE[(size_t)(unsigned)(base_of(G) + (32 * qt + r32) * stride) * 8u + w] = mx + __logf(sum);
+                    a.LSE[(size_t)(unsigned)(base_of(G) + (32 * qt + r32) * stride) * 8u + w] = mx * 0.25f + __logf(sum);
                 f32x16 ot = z;
 #pragma unroll
                 for (int kt = 0; kt < NKT; ++kt) {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) st[kt][e] *= inv;
                     ot = mfma32(tr_frag(sVh, 2 * kt), pack8(st[kt], 0), ot);
                     ot = mfma32(tr_frag(sVh, 2 * kt + 1), pack8(st[kt], 1), ot);
                 }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ot[e] *= inv;
                 float o0[4] = {ot[0], ot[1], ot[2], ot[3]}, o1[4] = {ot[4], ot[5], ot[6], ot[7]};
                 store4(sO + Tile<bf16>::off4(32 * qt + r32, 16 * w + 4 * hh), o0);
                 store4(sO + Tile<bf16>::off4(32 * qt + r32, 16 * w + 8 + 4 * hh), o1);
             }
         }
+        RT(4);
         __syncthreads();                                 // B2: all heads in sO; sA has no readers left
+        RT(5);
         {   // ---- output projection + layer-scale + residual: 16 channels x 96 positions per wave, x_mid staged in sA ----
             const f32x4 bpv = *reinterpret_cast<const f32x4*>(sLn + 512 + 16 * w + 4 * g), lsv = *reinterpret_cast<const f32x4*>(sLn + 640 + 16 * w + 4 * g);
 #pragma unroll
@@ -504,6 +528,7 @@ __global__ __launch_bounds__(AB_THR, 2) void k_attn_blk_fwd_rp3(const AttnBlkArg
                 }
             }
         }
+        RT(6);
         __syncthreads();                                 // B3: x_mid tile complete
 #pragma unroll
         for (int j = 0; j < NKT; ++j) {   // ---- full-row stores: x_mid always; o only when the backward pass will need it ----
@@ -516,7 +541,11 @@ __global__ __launch_bounds__(AB_THR, 2) void k_attn_blk_fwd_rp3(const AttnBlkArg
             }
         }
         __syncthreads();                                 // B4: the next group's LayerNorm overwrites sA
+        RT(7);
     }
+#ifdef RP3_PROF
+    if (blockIdx.x == 77 && (threadIdx.x == 0 || threadIdx.x == 320)) printf("rp3 prof bone %d wave %d groups %d: LN %lld B1 %lld project %lld qkvstore %lld core %lld B2 %lld proj %lld copyout+B3+B4 %lld\n", (int)BONE, w, ng, acc_t[0], acc_t[1], acc_t[2], acc_t[3], acc_t[4], acc_t[5], acc_t[6], acc_t[7]);
+#endif
 }
 
 }  // namespace

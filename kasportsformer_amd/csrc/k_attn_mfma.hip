@@ -116,6 +116,8 @@ __global__ __launch_bounds__(256) void k_attn_fwd_mfma(const bf16* __restrict__ 
         if (32 * qt >= L) break;
         const int i = 32 * qt + r;
         const bf16x8 qf = row_frag(Q, ldq, G, i, L, Tn, mode, h, hh, nullptr);
+        // softmax with the fewest vector instructions per score (the cores are bound by their issue): max over the RAW scores (a positive scale commutes with
+        // max), scale and log2(e) in one fma, and 1 / sum applied to the lane's 8 outputs instead of its 16 NKT probabilities
         f32x16 st[NKT];
         float mx = -INFINITY;
 #pragma unroll
@@ -123,27 +125,28 @@ __global__ __launch_bounds__(256) void k_attn_fwd_mfma(const bf16* __restrict__ 
             st[kt] = mfma32(kf[kt], qf, zero16());
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
-                const float s = (32 * kt + pos_of(g, hh) < L) ? st[kt][g] * 0.25f : -INFINITY;
-                st[kt][g] = s;
-                mx = fmaxf(mx, s);
+                st[kt][g] = (32 * kt + pos_of(g, hh) < L) ? st[kt][g] : -INFINITY;
+                mx = fmaxf(mx, st[kt][g]);
             }
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
+        constexpr float C2 = 0.25f * 1.4426950408889634f;             // scale . log2(e)
+        const float nm = -mx * C2;
         float sum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-            for (int g = 0; g < 16; ++g) { st[kt][g] = __expf(st[kt][g] - mx); sum += st[kt][g]; }
+            for (int g = 0; g < 16; ++g) { st[kt][g] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kt][g], C2, nm)); sum += st[kt][g]; }
         sum += __shfl_xor(sum, 32);
         const float inv = 1.0f / sum;
         f32x16 ot = zero16();
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
-#pragma unroll
-            for (int g = 0; g < 16; ++g) st[kt][g] *= inv;
             ot = mfma32(tr_frag(sV, 2 * kt), pack8(st[kt], 0), ot);
             ot = mfma32(tr_frag(sV, 2 * kt + 1), pack8(st[kt], 1), ot);
         }
+#pragma unroll
+        for (int g = 0; g < 8; ++g) ot[g] *= inv;
         if (i < L) store_t16(O + tok_of(G, i, Tn, mode) * 128 + h * 16, ot, hh);
     }
 }
@@ -997,27 +1000,28 @@ __global__ __launch_bounds__(256) void k_attn_fwd_mfma32(const bf16* __restrict_
             st[kt] = mfma32(kf[kt][1], qf1, mfma32(kf[kt][0], qf0, zero16()));       // S^T[key][query]
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
-                const float sv = (32 * kt + pos_of(g, hh) < L) ? st[kt][g] * SCALE32 : -INFINITY;
-                st[kt][g] = sv;
-                mx = fmaxf(mx, sv);
+                st[kt][g] = (32 * kt + pos_of(g, hh) < L) ? st[kt][g] : -INFINITY;
+                mx = fmaxf(mx, st[kt][g]);
             }
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
+        constexpr float C2 = SCALE32 * 1.4426950408889634f;           // scale . log2(e): the softmax of k_attn_fwd_mfma
+        const float nm = -mx * C2;
         float sum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-            for (int g = 0; g < 16; ++g) { st[kt][g] = __expf(st[kt][g] - mx); sum += st[kt][g]; }
+            for (int g = 0; g < 16; ++g) { st[kt][g] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kt][g], C2, nm)); sum += st[kt][g]; }
         sum += __shfl_xor(sum, 32);
         const float inv = 1.0f / sum;
         f32x16 ot = zero16();
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
-#pragma unroll
-            for (int g = 0; g < 16; ++g) st[kt][g] *= inv;
             ot = mfma32(tr_frag32(sV + kt * 1024, 0), pack8(st[kt], 0), ot);        // O^T[d][query] += V^T . P^T, all 32 rows live
             ot = mfma32(tr_frag32(sV + kt * 1024, 1), pack8(st[kt], 1), ot);
         }
+#pragma unroll
+        for (int g = 0; g < 16; ++g) ot[g] *= inv;
         if (i < L) store_t32(O + tok_of(G, i, Tn, mode) * 128 + h * 32, ot, hh);
     }
 }
