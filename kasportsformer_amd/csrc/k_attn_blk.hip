@@ -151,7 +151,16 @@ __global__ __launch_bounds__(AB_THR, BONE ? KASF_RP_BONE_WAVES : 4) void k_attn_
     };
     fetch(0);
     __syncthreads();                                     // sLn
+#ifdef RP_PROF
+    long long acc_t[8] = {0,0,0,0,0,0,0,0};
+#define RQ(k) do { const long long n_ = clock64(); acc_t[k] += n_ - t_; t_ = n_; } while (0)
+#else
+#define RQ(k) do {} while (0)
+#endif
     for (int t = 0; t < ng; ++t) {
+#ifdef RP_PROF
+        long long t_ = clock64();
+#endif
         const int G = g0 + t;
         const bf16x8 zero = {};
         const bf16x8 xc = rl < L ? xN : zero;
@@ -159,7 +168,9 @@ __global__ __launch_bounds__(AB_THR, BONE ? KASF_RP_BONE_WAVES : 4) void k_attn_
         layernorm(xc, sA, sLn, sLn + 128);
         if (BONE) layernorm(rl < L ? lN : zero, sA + AB_TILE, sLn + 256, sLn + 384);
         if (t + 1 < ng) fetch(t + 1);
+        RQ(0);
         __syncthreads();                                 // B1: raw and LN tiles complete; every wave finished the copy-out of the previous group
+        RQ(1);
         if (BONE) {   // ---- q_h from LN(x), then k_h, v_h from LN_limb(x_limb): two phases keep the live accumulators + operand fragments under the 128-VGPR cap ----
             {
                 f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -213,6 +224,7 @@ __global__ __launch_bounds__(AB_THR, BONE ? KASF_RP_BONE_WAVES : 4) void k_attn_
                 }
         }
         lds_fence();
+        RQ(2);
         const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sKh + r32 * 16 + 8 * hh);
         const bf16x8 qf = *reinterpret_cast<const bf16x8*>(sQh + r32 * 16 + 8 * hh);
         if (a.Qs != nullptr && r32 < L) {   // training: the backward pass reads q | k | v; each lane stores the 16 bytes it is about to use as an operand
@@ -228,6 +240,7 @@ __global__ __launch_bounds__(AB_THR, BONE ? KASF_RP_BONE_WAVES : 4) void k_attn_
                 *reinterpret_cast<bf16x8*>(a.Qs + (size_t)(tok * 384u + 256 + 16 * w + 8 * hh)) = vf;
             }
         }
+        RQ(3);
         {   // ---- attention core of head w (k_attn_mfma.hip, one 32x32 score tile) ----
             f32x16 z;
 #pragma unroll
@@ -257,7 +270,9 @@ __global__ __launch_bounds__(AB_THR, BONE ? KASF_RP_BONE_WAVES : 4) void k_attn_
             store4(sO + Tile<bf16>::off4(r32, 16 * w + 4 * hh), o0);
             store4(sO + Tile<bf16>::off4(r32, 16 * w + 8 + 4 * hh), o1);
         }
+        RQ(4);
         __syncthreads();                                 // B2: all heads in sO
+        RQ(5);
         {   // ---- output projection + layer-scale + residual: 16 channels x 32 positions per wave ----
             f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
@@ -275,6 +290,7 @@ __global__ __launch_bounds__(AB_THR, BONE ? KASF_RP_BONE_WAVES : 4) void k_attn_
                 store4(sOut + Tile<bf16>::off4(16 * mt + i, 16 * w + 4 * g), v);
             }
         }
+        RQ(6);
         __syncthreads();                                 // B3: x_mid tile complete
         if (rl < L) {   // ---- full-row stores: x_mid always; o only when the backward pass will need it ----
             const unsigned tok = (unsigned)(base_of(G) + rl * stride);
@@ -282,7 +298,11 @@ __global__ __launch_bounds__(AB_THR, BONE ? KASF_RP_BONE_WAVES : 4) void k_attn_
             *reinterpret_cast<f32x4*>(a.OUT + (size_t)(tok * 128u + sub * 8)) = *reinterpret_cast<const f32x4*>(sOut + co);
             if (a.Qs != nullptr) *reinterpret_cast<f32x4*>(a.Os + (size_t)(tok * 128u + sub * 8)) = *reinterpret_cast<const f32x4*>(sO + co);
         }
+        RQ(7);
     }
+#ifdef RP_PROF
+    if (blockIdx.x == 77 && (threadIdx.x == 0 || threadIdx.x == 320)) printf("rp prof bone %d mode %d wave %d groups %d: LN %lld B1 %lld project %lld qkvstore %lld core %lld B2 %lld proj %lld B3+copyout %lld\n", (int)BONE, a.mode, w, ng, acc_t[0], acc_t[1], acc_t[2], acc_t[3], acc_t[4], acc_t[5], acc_t[6], acc_t[7]);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------
