@@ -704,6 +704,8 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_2p(const bf16* __restrict__
         const int i = 32 * qt + r;
         const bf16x8 qf = qf_n, dfq = rowf(sD, qt);
         if (qt + 1 < nt) qf_n = q4(qt + 1);
+        // (vector instructions per score kept low, as in the forward cores: exp2 of one fma, the probabilities stay UN-normalised -- e = exp(s - max) --
+        //  and 1 / sum enters once per query: delta = (sum e . dP) / sum, dS = e (dP - delta) . (scale / sum))
         f32x16 st[NKT];
         float mx = -INFINITY;
 #pragma unroll
@@ -718,12 +720,13 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_2p(const bf16* __restrict__
             for (int g = 0; g < 16; ++g) mx = fmaxf(mx, st[kt][g]);
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float nm = -mx * 1.4426950408889634f;
         float sum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
             if (kt >= nt) break;
 #pragma unroll
-            for (int g = 0; g < 16; ++g) { st[kt][g] = __expf(st[kt][g] - mx); sum += st[kt][g]; }
+            for (int g = 0; g < 16; ++g) { st[kt][g] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kt][g], 1.4426950408889634f, nm)); sum += st[kt][g]; }
         }
         sum += __shfl_xor(sum, 32);
         const float inv = 1.0f / sum;
@@ -733,17 +736,18 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_2p(const bf16* __restrict__
             if (kt >= nt) break;
             const f32x16 dp = mfma32(vf[kt], dfq, zero16());      // dP^T[key][query] = sum_d V[key][d] d_o[query][d]
 #pragma unroll
-            for (int g = 0; g < 16; ++g) { st[kt][g] *= inv; delta += st[kt][g] * dp[g]; }
+            for (int g = 0; g < 16; ++g) delta = __builtin_fmaf(st[kt][g], dp[g], delta);
         }
-        delta += __shfl_xor(delta, 32);
+        delta = (delta + __shfl_xor(delta, 32)) * inv;
         if (hh == 0) { sLse[i] = i < L ? mx + __logf(sum) : INFINITY; sDel[i] = delta; }   // rows past L: exp(s - inf) = 0 keeps them out of pass B
+        const float ks = 0.25f * inv;
         f32x16 dq = zero16();
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
             if (kt >= nt) break;
             const f32x16 dp = mfma32(vf[kt], dfq, zero16());
 #pragma unroll
-            for (int g = 0; g < 16; ++g) st[kt][g] = st[kt][g] * (dp[g] - delta) * 0.25f;          // dS^T (scale folded)
+            for (int g = 0; g < 16; ++g) st[kt][g] = st[kt][g] * (dp[g] - delta) * ks;             // dS^T (scale and 1 / sum folded)
             dq = mfma32(tr_frag(sK, 2 * kt), pack8(st[kt], 0), dq);                                // dQ^T[d][query] += K^T . dS^T
             dq = mfma32(tr_frag(sK, 2 * kt + 1), pack8(st[kt], 1), dq);
         }
@@ -1072,20 +1076,21 @@ __global__ __launch_bounds__(256) void k_attn_bwd_2p32(const bf16* __restrict__ 
         for (int kt = 0; kt < NKT; ++kt) {
             if (kt >= nt) break;
             st[kt] = mfma32(rowf(sK, kt, 1), qf1, mfma32(rowf(sK, kt, 0), qf0, zero16()));       // S^T[key][query]
+            if (kt == nt - 1) {
 #pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const float sv = (kt < nt - 1 || 32 * kt + pos_of(g, hh) < L) ? st[kt][g] * SCALE32 : -INFINITY;
-                st[kt][g] = sv;
-                mx = fmaxf(mx, sv);
+                for (int g = 0; g < 16; ++g) st[kt][g] = (32 * kt + pos_of(g, hh) < L) ? st[kt][g] : -INFINITY;
             }
+#pragma unroll
+            for (int g = 0; g < 16; ++g) mx = fmaxf(mx, st[kt][g]);                                // (max over the RAW scores; softmax as in k_attn_bwd_2p)
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float nm = -mx * C2;
         float sum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
             if (kt >= nt) break;
 #pragma unroll
-            for (int g = 0; g < 16; ++g) { st[kt][g] = __expf(st[kt][g] - mx); sum += st[kt][g]; }
+            for (int g = 0; g < 16; ++g) { st[kt][g] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kt][g], C2, nm)); sum += st[kt][g]; }
         }
         sum += __shfl_xor(sum, 32);
         const float inv = 1.0f / sum;
@@ -1095,17 +1100,18 @@ __global__ __launch_bounds__(256) void k_attn_bwd_2p32(const bf16* __restrict__ 
             if (kt >= nt) break;
             const f32x16 dp = mfma32(vf[kt][1], df1, mfma32(vf[kt][0], df0, zero16()));          // dP^T[key][query]
 #pragma unroll
-            for (int g = 0; g < 16; ++g) { st[kt][g] *= inv; delta += st[kt][g] * dp[g]; }
+            for (int g = 0; g < 16; ++g) delta = __builtin_fmaf(st[kt][g], dp[g], delta);
         }
-        delta += __shfl_xor(delta, 32);
-        if (hh == 0) { sLse[i] = i < L ? -(mx + __logf(sum)) * 1.4426950408889634f : -INFINITY; sDel[i] = -delta; }   // rows past L: exp2(-inf) = 0 in pass B
+        delta = (delta + __shfl_xor(delta, 32)) * inv;
+        if (hh == 0) { sLse[i] = i < L ? -(mx * C2 + __logf(sum) * 1.4426950408889634f) : -INFINITY; sDel[i] = -delta; }   // rows past L: exp2(-inf) = 0 in pass B
+        const float ks = SCALE32 * inv;
         f32x16 dq = zero16();
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
             if (kt >= nt) break;
             const f32x16 dp = mfma32(vf[kt][1], df1, mfma32(vf[kt][0], df0, zero16()));
 #pragma unroll
-            for (int g = 0; g < 16; ++g) st[kt][g] = st[kt][g] * (dp[g] - delta) * SCALE32;        // dS^T (scale folded)
+            for (int g = 0; g < 16; ++g) st[kt][g] = st[kt][g] * (dp[g] - delta) * ks;             // dS^T (scale and 1 / sum folded)
             dq = mfma32(tr_frag32(sK + kt * 1024, 0), pack8(st[kt], 0), dq);                       // dQ^T[d][query] += K^T . dS^T
             dq = mfma32(tr_frag32(sK + kt * 1024, 1), pack8(st[kt], 1), dq);
         }
