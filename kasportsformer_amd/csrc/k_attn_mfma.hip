@@ -739,7 +739,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_2p(const bf16* __restrict__
             for (int g = 0; g < 16; ++g) delta = __builtin_fmaf(st[kt][g], dp[g], delta);
         }
         delta = (delta + __shfl_xor(delta, 32)) * inv;
-        if (hh == 0) { sLse[i] = i < L ? mx + __logf(sum) : INFINITY; sDel[i] = delta; }   // rows past L: exp(s - inf) = 0 keeps them out of pass B
+        if (hh == 0) { sLse[i] = i < L ? -(mx + __logf(sum)) : -INFINITY; sDel[i] = -delta; }   // negated: they are pass B's initial accumulators; rows past L: exp(-inf) = 0
         const float ks = 0.25f * inv;
         f32x16 dq = zero16();
 #pragma unroll
@@ -770,20 +770,21 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_2p(const bf16* __restrict__
         }
         f32x16 dv = zero16(), dk = zero16();
         for (int qt = 0; qt < nt; ++qt) {
-            f32x4 l4[4], d4[4];
+            f32x16 cl, cd;                                        // -lse and -delta of the tile's queries (registers 4a .. 4a+3 = queries 32 qt + 8a + 4hh + {0..3})
 #pragma unroll
-            for (int a4 = 0; a4 < 4; ++a4) {                      // registers 4a .. 4a+3 = queries 32 qt + 8a + 4hh + {0..3}
-                l4[a4] = *reinterpret_cast<const f32x4*>(sLse + 32 * qt + 8 * a4 + 4 * hh);
-                d4[a4] = *reinterpret_cast<const f32x4*>(sDel + 32 * qt + 8 * a4 + 4 * hh);
+            for (int a4 = 0; a4 < 4; ++a4) {
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(sLse + 32 * qt + 8 * a4 + 4 * hh), d4 = *reinterpret_cast<const f32x4*>(sDel + 32 * qt + 8 * a4 + 4 * hh);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { cl[4 * a4 + e] = l4[e]; cd[4 * a4 + e] = d4[e]; }
             }
             const bf16x8 dt0 = tr_frag(sD, 2 * qt), dt1 = tr_frag(sD, 2 * qt + 1), qt0 = tr_frag(sQ, 2 * qt), qt1 = tr_frag(sQ, 2 * qt + 1);
-            f32x16 p = mfma32(rowf(sQ, qt), kfk, zero16());       // S[query][key] / 4: lane = key, registers = queries
-            f32x16 ds = mfma32(rowf(sD, qt), vfk, zero16());      // dP[query][key]
+            f32x16 p = mfma32(rowf(sQ, qt), kfk, cl);             // S[query][key] / 4 - lse: the statistics ride in as the products' initial accumulators
+            f32x16 ds = mfma32(rowf(sD, qt), vfk, cd);            // dP[query][key] - delta
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
-                const float pv = __expf(p[g] - l4[g >> 2][g & 3]);
+                const float pv = __builtin_amdgcn_exp2f(p[g] * 1.4426950408889634f);
                 p[g] = pv;
-                ds[g] = pv * (ds[g] - d4[g >> 2][g & 3]);
+                ds[g] = pv * ds[g];
             }
             dv = mfma32(dt0, pack8(p, 0), dv);                    // dV^T[d][key] += d_o^T . P
             dk = mfma32(qt0, pack8(ds, 0), dk);                   // dK^T[d][key] += (Q / 4)^T . dS
