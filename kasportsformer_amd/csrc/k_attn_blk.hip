@@ -141,12 +141,12 @@ __global__ __launch_bounds__(AB_THR, BONE ? KASF_RP_BONE_WAVES : 4) void k_attn_
         const float mean = reduce16(s) * (1.0f / 128.0f);
         float q = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { v[e] -= mean; q += v[e] * v[e]; }
+        for (int e = 0; e < 8; ++e) { v[e] -= mean; q = __builtin_fmaf(v[e], v[e], q); }        // (explicit fma: the library is built with -ffp-contract=off)
         const float rstd = rsqrtf(reduce16(q) * (1.0f / 128.0f) + KASF_LN_EPS);
         const f32x4 g0v = *reinterpret_cast<const f32x4*>(gp + sub * 8), g1v = *reinterpret_cast<const f32x4*>(gp + sub * 8 + 4);
         const f32x4 b0v = *reinterpret_cast<const f32x4*>(bp + sub * 8), b1v = *reinterpret_cast<const f32x4*>(bp + sub * 8 + 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] = v[e] * rstd * g0v[e] + b0v[e]; v[4 + e] = v[4 + e] * rstd * g1v[e] + b1v[e]; }
+        for (int e = 0; e < 4; ++e) { v[e] = __builtin_fmaf(v[e], rstd * g0v[e], b0v[e]); v[4 + e] = __builtin_fmaf(v[4 + e], rstd * g1v[e], b1v[e]); }
         tile_store8(dst, rl, sub * 8, v);
     };
     fetch(0);
@@ -381,12 +381,12 @@ __global__ __launch_bounds__(AB_THR, 2) void k_attn_blk_fwd_rp3(const AttnBlkArg
         const float mean = reduce16(s) * (1.0f / 128.0f);
         float q = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { v[e] -= mean; q += v[e] * v[e]; }
+        for (int e = 0; e < 8; ++e) { v[e] -= mean; q = __builtin_fmaf(v[e], v[e], q); }        // (explicit fma: the library is built with -ffp-contract=off)
         const float rstd = rsqrtf(reduce16(q) * (1.0f / 128.0f) + KASF_LN_EPS);
         const f32x4 g0v = *reinterpret_cast<const f32x4*>(gp + sub * 8), g1v = *reinterpret_cast<const f32x4*>(gp + sub * 8 + 4);
         const f32x4 b0v = *reinterpret_cast<const f32x4*>(bp + sub * 8), b1v = *reinterpret_cast<const f32x4*>(bp + sub * 8 + 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] = v[e] * rstd * g0v[e] + b0v[e]; v[4 + e] = v[4 + e] * rstd * g1v[e] + b1v[e]; }
+        for (int e = 0; e < 4; ++e) { v[e] = __builtin_fmaf(v[e], rstd * g0v[e], b0v[e]); v[4 + e] = __builtin_fmaf(v[4 + e], rstd * g1v[e], b1v[e]); }
         tile_store8(sA, row, sub * 8, v);
     };
     // feature tiles [nt0, nt0 + NN) of this head out of the rows in sA -> the wave-private tiles
