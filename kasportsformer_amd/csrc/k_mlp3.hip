@@ -189,10 +189,10 @@ __global__ __launch_bounds__(S_THR) void k_mlp_fwd_s(const bf16* __restrict__ X,
                 const float mean = reduce16(s) * (1.0f / 128.0f);
                 float qv = 0.f;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { v[e] -= mean; qv += v[e] * v[e]; }
+                for (int e = 0; e < 8; ++e) { v[e] -= mean; qv = __builtin_fmaf(v[e], v[e], qv); }
                 const float rstd = rsqrtf(reduce16(qv) * (1.0f / 128.0f) + KASF_LN_EPS);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { v[e] = v[e] * rstd * g0[e] + c0[e]; v[4 + e] = v[4 + e] * rstd * g1[e] + c1[e]; }
+                for (int e = 0; e < 4; ++e) { v[e] = __builtin_fmaf(v[e], rstd * g0[e], c0[e]); v[4 + e] = __builtin_fmaf(v[4 + e], rstd * g1[e], c1[e]); }
                 tile_store8(sA + (int)(t & 1) * TL, r, sub * 8, v);
                 if (xn_out != nullptr) {                 // training: the backward pass streams LN(x) instead of recomputing it
                     const int64_t row = (tile0 + t) * S_BM + r;
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(S_THR) void k_mlp_fwd_s(const bf16* __restrict__ X,
                             float x[4], y[4];
                             load4(cX + Tile<bf16>::off4(mt * 16 + i, col), x);      // residual from the raw tile still in LDS
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) y[r] = x[r] + lsv[r] * acc2[n2][mt][r];
+                            for (int r = 0; r < 4; ++r) y[r] = __builtin_fmaf(lsv[r], acc2[n2][mt][r], x[r]);
                             store4(out + row * 128 + col, y);
                         }
                     }
