@@ -14,6 +14,7 @@
 // Backward runs two passes per (group, head): pass 1 with lane = query (softmax statistics, delta, dQ), pass 2
 // with lane = key (S and dP recomputed un-transposed; dK, dV), exchanging only 3 floats per query through LDS.
 #include <cstdlib>
+#include <cstdio>
 #include <type_traits>
 #include "common.h"
 #include "kernels.h"
@@ -872,8 +873,17 @@ __global__ __launch_bounds__(512, 4) void k_attn_bwd_pers(const bf16* __restrict
             store4(sdS + r * 32 + 8 * a4 + 4 * hh, z4);
         }
     }
+#ifdef PERS_PROF
+    long long acc_t[6] = {0,0,0,0,0,0};
+#define PQ(k) do { const long long n_ = clock64(); acc_t[k] += n_ - t_; t_ = n_; } while (0)
+#else
+#define PQ(k) do {} while (0)
+#endif
     fetch(0);
     for (int t = 0; t < ng; ++t) {
+#ifdef PERS_PROF
+        long long t_ = clock64();
+#endif
         const bf16x8 kf = r < L ? kfN : zero8(), vf = r < L ? vfN : zero8(), qf = r < L ? qfN : zero8();
         bf16* sGt = sG + (t & 1) * (32 * 128);
         *reinterpret_cast<bf16x8*>(sGt + Tile<bf16>::chunk_off(grow, gch)) = grow < L ? gcN : zero8();
@@ -881,7 +891,9 @@ __global__ __launch_bounds__(512, 4) void k_attn_bwd_pers(const bf16* __restrict
         *reinterpret_cast<bf16x8*>(sQ + r * 16 + 8 * hh) = qf;
         if (t > 0) flush(g0 + t - 1);
         if (t + 1 < ng) fetch(t + 1);
+        PQ(0);
         __syncthreads();          // g_mid rows of group t visible; every wave is past its reads of the other buffer (group t-1)
+        PQ(1);
         bf16x8 df;
         {   // d_o of this head: [32 positions][16 channels] = g_mid . (ls1 . Wproj)^T rows 16h .. 16h+15
             f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -899,6 +911,7 @@ __global__ __launch_bounds__(512, 4) void k_attn_bwd_pers(const bf16* __restrict
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             df = *reinterpret_cast<const bf16x8*>(sD + r * 16 + 8 * hh);
         }
+        PQ(2);
         // ---------------- pass 1: lane = query ----------------
         f32x16 st = mfma32(kf, qf, zero16());                    // S^T[key][query]
         f32x16 dp = mfma32(vf, df, zero16());                    // dP^T[key][query]
@@ -935,6 +948,7 @@ __global__ __launch_bounds__(512, 4) void k_attn_bwd_pers(const bf16* __restrict
             float v4[4] = {st[4 * a4], st[4 * a4 + 1], st[4 * a4 + 2], st[4 * a4 + 3]};
             store4(sdS + r * 32 + 8 * a4 + 4 * hh, v4);
         }
+        PQ(3);
         // ---------------- pass 2: dV^T = dO^T . P, dK^T = Q^T . dS with P / dS read back transposed (lane = key) ----------------
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the tiles were written by other lanes of this wave (LDS is in order per wave)
         f32x16 dv = zero16(), dk = zero16();
@@ -947,8 +961,12 @@ __global__ __launch_bounds__(512, 4) void k_attn_bwd_pers(const bf16* __restrict
         pv = swap_t16(dv);       // never has this group's stores (issued a moment ago) ahead of it in the in-order vmcnt queue
         pk = swap_t16(dk);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's LDS reads are done before the next group's tile writes
+        PQ(4);
     }
     flush(g0 + ng - 1);
+#ifdef PERS_PROF
+    if (blockIdx.x == 77 && (threadIdx.x == 0 || threadIdx.x == 320)) printf("pers prof NR %d mode %d wave %d groups %d: top(wait loads, LDS writes, flush, fetch) %lld barrier %lld d_o %lld pass1 %lld pass2 %lld\n", NR, mode, wave, ng, acc_t[0], acc_t[1], acc_t[2], acc_t[3], acc_t[4]);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------
