@@ -1,6 +1,6 @@
 """Training fidelity of the arithmetic modes at FULL depth on a LEARNABLE task.
 
-    python tools/train_fidelity.py [steps=1000] [modes=fp32,bf16,bf16] > profiles/r3_train_fidelity.json
+    python tools/train_fidelity.py [steps=1000] [modes=fp32,bf16,bf16@1,bf16@2] > profiles/r3_train_fidelity.json
 
 The shipped 26-layer model, batch 256, T = 27, reference default init under the yaml seed, the reference's optimiser / warm-up
 (train_and_evaluate_sp.py:270-272,325-329 with an "epoch" = one pass over the 16-batch clip pool), labels = ``teacher_labels`` (a fixed seeded
@@ -17,7 +17,7 @@ import torch
 import kasportsformer_amd as K
 
 STEPS = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
-MODES = (sys.argv[2] if len(sys.argv) > 2 else "fp32,bf16,bf16").split(",")
+MODES = (sys.argv[2] if len(sys.argv) > 2 else "fp32,bf16,bf16@1,bf16@2").split(",")
 L, T, B, POOL, NTEST = int(os.environ.get("FID_LAYERS", 26)), 27, int(os.environ.get("FID_BATCH", 256)), 16, 512
 LR, WARM_EPOCHS = 5e-4, 10
 EVAL_EVERY = max(1, STEPS // 10)
