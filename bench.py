@@ -316,7 +316,7 @@ def main():
                      "note": "forward only, same model and batch per GPU, evaluation mode; not part of value"},
             "parity": "26-layer forward vs the oracle with the same top-4 neighbour decisions: fp32 mode 4e-6, gradient cosine 1.0000000 (3 near-tie rows of "
                       "23,868 differ); bf16 mode (this line's) 0.10 / 0.958 on de-identitied weights (tests/test_gpu_model.py::test_full_depth_26_layers_against_oracle); "
-                      "training fidelity on a LEARNABLE task at full depth, 1,000 steps, B = 256: test MPJPE over the last ten checkpoints bf16 31.76 +- 0.84 mm (7 samples) vs fp32 mode 31.72 mm, from 208 mm "
+                      "training fidelity on a LEARNABLE task at full depth, 1,000 steps, B = 256: test MPJPE over the last ten checkpoints bf16 31.76 +- 0.84 mm (7 samples) vs fp32 mode 32.44 +- 1.03 mm (4 samples), from 208 mm; training loss +0.8 % "
                       "(profiles/r3_train_fidelity.json); fp32 mode vs the CPU oracle after 16 steps: 1e-4 mm",
             "model_mfma_frac": value / world * FLOP_PER_CLIP_TRAIN / (PEAK_BF16_TFLOPS * 1e12),
         }
