@@ -18,7 +18,7 @@ import kasportsformer_amd as K
 
 STEPS = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 MODES = (sys.argv[2] if len(sys.argv) > 2 else "fp32,bf16,bf16@1,bf16@2").split(",")
-L, T, B, POOL, NTEST = int(os.environ.get("FID_LAYERS", 26)), 27, int(os.environ.get("FID_BATCH", 256)), 16, 512
+L, T, B, POOL, NTEST = int(os.environ.get("FID_LAYERS", 26)), int(os.environ.get("FID_T", 27)), int(os.environ.get("FID_BATCH", 256)), 16, 512
 LR, WARM_EPOCHS = 5e-4, 10
 EVAL_EVERY = max(1, STEPS // 10)
 
