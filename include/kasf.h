@@ -58,6 +58,9 @@ int32_t kasf_get_deterministic(void);
 int kasf_version(void);
 
 int kasf_model_create(const kasf_config* cfg, kasf_model** out);
+/* the same handle without touching a device: answers every layout / size query below (kasf_param_*, kasf_buffer_*, kasf_workspace_bytes, kasf_stage_grad_range ...);
+ * what a host-side binding uses to build its module tree before any GPU exists (kasportsformer_amd/model.py does) */
+int kasf_model_create_layout_only(const kasf_config* cfg, kasf_model** out);
 void kasf_model_destroy(kasf_model* m);
 
 /* 0 = healthy.  Non-zero: a kernel's bounded wait on another workgroup ran out (the affected gradient rows were poisoned with NaN instead of

@@ -36,6 +36,7 @@ SIGNATURES = {
     "kasf_set_deterministic": (None, [_i32]),
     "kasf_get_deterministic": (_i32, []),
     "kasf_model_create": (_i32, [C.POINTER(KasfConfig), C.POINTER(_vp)]),
+    "kasf_model_create_layout_only": (_i32, [C.POINTER(KasfConfig), C.POINTER(_vp)]),
     "kasf_model_destroy": (None, [_vp]),
     "kasf_model_status": (_i32, [_vp, _pi32]),
     "kasf_param_count": (_i64, [_vp]),
@@ -73,8 +74,7 @@ SIGNATURES = {
     "kasf_op_attention_bwd_fused_do": (_i32, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "kasf_op_cast": (_i32, [_i32, _vp, _vp, _i64, _i32, _vp]),
 }
-# not in the public header: host-only layout handle used by CPU tests / tooling
-_EXTRA = {"kasf_model_create_layout_only": (_i32, [C.POINTER(KasfConfig), C.POINTER(_vp)])}
+_EXTRA = {}
 
 _lib = None
 

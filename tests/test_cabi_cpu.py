@@ -25,6 +25,41 @@ def test_header_symbols_are_exported():
     assert lib.kasf_version() == _lib.ABI_VERSION
 
 
+def test_header_is_plain_c_and_links_against_the_library(tmp_path):
+    """The boundary is a C ABI: include/kasf.h must compile as C99 (no C++ in the signatures) and a C program that only includes it must link against the
+    library and run the two calls that need no GPU -- what a cgo / JNI / Rust-FFI binding of the reference's host language would do first."""
+    import shutil
+    import subprocess
+    from kasportsformer_amd import _lib
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("gcc not available")
+    hdr = os.path.join(ROOT, "include", "kasf.h")
+    r = subprocess.run([gcc, "-std=c99", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    src = tmp_path / "probe.c"
+    src.write_text('''#include <stdio.h>
+#include "kasf.h"
+int main(void) {
+    kasf_config cfg = {26, 27, 8, 4, 1, KASF_DTYPE_BF16};
+    kasf_model* m = 0;
+    if (kasf_model_create_layout_only(&cfg, &m) != 0) { printf("create failed: %s\\n", kasf_last_error()); return 2; }
+    printf("%d %lld %lld\\n", kasf_version(), (long long)kasf_param_count(m), (long long)kasf_param_live_count(m));
+    kasf_model_destroy(m);
+    return 0;
+}
+''')
+    exe = tmp_path / "probe"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    r = subprocess.run([gcc, "-std=c99", "-Werror=implicit-function-declaration", "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe), "-L" + libdir, "-l:libkasf_hip.so", "-Wl,-rpath," + libdir,
+                        "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    ver, n, live = r.stdout.split()
+    assert int(ver) == _lib.ABI_VERSION and int(n) >= 29365668 and int(n) % 4 == 0 and 0 < int(live) < int(n)      # (the flat array is padded to a multiple of 4)
+
+
 def test_layout_covers_reference_state_dict(golden_dir):
     from kasportsformer_amd import _lib
     lib = _lib.load()
