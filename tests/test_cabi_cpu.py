@@ -23,6 +23,14 @@ def test_header_symbols_are_exported():
         assert hasattr(lib, name), f"{name} declared in include/kasf.h but not exported"
         assert name in _lib.SIGNATURES, f"{name} has no ctypes prototype"
     assert lib.kasf_version() == _lib.ABI_VERSION
+    # ... and the other way round: nothing with C linkage leaves the library without a declaration in the header (the host module may only use what is declared)
+    import shutil
+    import subprocess
+    nm = shutil.which("nm")
+    if nm is not None:
+        out = subprocess.run([nm, "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+        exported = set(re.findall(r" T (kasf_[a-z0-9_]+)$", out, flags=re.M))
+        assert exported and not exported - declared, sorted(exported - declared)
 
 
 def test_header_is_plain_c_and_links_against_the_library(tmp_path):
