@@ -281,6 +281,42 @@ def test_attention_core_other_head_counts(lib, cd, heads, mode, T):
     assert rel_err(_back(dqkv), qr.grad) < TOL[cd]
 
 
+def _random_attention_cases(n=14, seed=20261004):
+    import random
+    rnd = random.Random(seed)
+    cases = []
+    for _ in range(n):
+        heads = rnd.choice([4, 8])
+        mode = rnd.choice([0, 1, 1, 1])                       # temporal groups have the shape-dependent kernels
+        T = rnd.choice([rnd.randint(4, 32), rnd.randint(33, 96), rnd.randint(97, 256)])
+        cases.append((heads, mode, T, rnd.randint(1, 3)))
+    return cases
+
+
+@pytest.mark.parametrize("heads,mode,T,B", _random_attention_cases())
+def test_attention_core_random_shapes_bf16(lib, heads, mode, T, B):
+    """Seeded random (head count, mode, clip length, batch) over everything the MFMA cores take: 1 / 3 / 4 / 6 / 8 key tiles, ragged last tiles, 4 and 8 heads."""
+    from kasportsformer_amd import _lib
+    from oracle.kasf_oracle import attention_core, _heads
+    cd = "bf16"
+    qkv = _rand(B, T, 17, 384, seed=100 + T)
+    do = _rand(B, T, 17, 128, seed=200 + T)
+    qd, dod = _dev(qkv, cd), _dev(do, cd)
+    o = torch.empty(B, T, 17, 128, device="cuda", dtype=DT[cd][1])
+    dqkv = torch.zeros_like(qd)
+    es, base, db = qd.element_size(), qd.data_ptr(), dqkv.data_ptr()
+    _lib.check(lib.kasf_op_attention_fwd_heads(DT[cd][0], base, 384, base + 128 * es, base + 256 * es, 384, ptr(o), B, T, mode, heads, stream()))
+    _lib.check(lib.kasf_op_attention_bwd_heads(DT[cd][0], base, 384, base + 128 * es, base + 256 * es, 384, ptr(dod), db, 384, db + 128 * es, db + 256 * es, 384,
+                                               B, T, mode, heads, stream()))
+    torch.cuda.synchronize()
+    qr = _back(qd).requires_grad_(True)
+    q, k, v = _heads(qr, 3, heads)
+    ref = attention_core(q, k, v, "spatial" if mode == 0 else "temporal", (128 // heads) ** -0.5)
+    ref.backward(_back(dod))
+    assert rel_err(_back(o), ref) < TOL[cd]
+    assert rel_err(_back(dqkv), qr.grad) < TOL[cd]
+
+
 @pytest.mark.parametrize("bone", [False, True])
 @pytest.mark.parametrize("mode,T,B", [(0, 27, 2), (1, 27, 3), (1, 9, 2), (0, 27, 41), (1, 32, 67), (0, 4, 1)])     # 41 x 27 = 1,107 groups: three per persistent
 def test_attention_backward_fused_do(lib, bone, mode, T, B):                                                     # workgroup, last range short; 67 x 17 = 1,139
