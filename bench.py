@@ -91,13 +91,13 @@ PROFILES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
 
 
 def _profile(name):
-    """Newest committed round of a profile file (profiles/r3_<name>, else r2_<name>): counters cannot be read from inside the process, so the bench
+    """Newest committed round of a profile file (profiles/r4_<name>, else r3_ / r2_<name>): counters cannot be read from inside the process, so the bench
     line QUOTES the committed summaries of separate rocprofv3 runs of the same launches (tools/refresh_profiles_r3.sh) and says so (`*_source`)."""
-    for rnd in ("r3", "r2"):
+    for rnd in ("r4", "r3", "r2"):
         f = os.path.join(PROFILES, f"{rnd}_{name}")
         if os.path.exists(f):
             return f
-    return os.path.join(PROFILES, f"r3_{name}")
+    return os.path.join(PROFILES, f"r4_{name}")
 
 
 TRAFFIC_FILE = _profile("pmc_traffic.json")            # tools/pmc_traffic.py (two --pmc passes over tools/mlp_bench.py)
@@ -192,12 +192,45 @@ def cpu_baseline(batch=8, steps=8):
             "sample": f"{steps} timed train steps (1 warm-up) of the 26-layer fp32 CPU oracle at batch {batch}, T={T}"}
 
 
+def workload_name(args, world, strong):
+    data = "WorldPose-det style (detector-confidence input)" if args.det_conf else "SportsPose-GT"
+    if strong:
+        tag = " = BASELINE.json configs[2]" if (args.det_conf and args.global_batch == 256 and world == 8) else ""
+        return f"{data} 27-frame bf16 training, ONE global batch of {args.global_batch} split over {world} GPU(s) ({args.batch} clips per rank; strong scaling){tag}"
+    tag = " (BASELINE.json configs[1])" if (args.batch == BATCH_PER_GPU and not args.det_conf) else ""
+    return f"{data} 27-frame bf16 training, batch={args.batch} per GPU{tag}"
+
+
+def parity_summary():
+    """What the parity tests OBSERVED on the shipped kernels, read from the files tests/test_gpu_model.py::test_full_depth_26_layers_against_oracle writes
+    (gpurun_out/r4_parity_26layers_<mode>.json, committed as profiles/...): nothing in this string is typed in."""
+    out = {}
+    for cd in ("fp32", "bf16"):
+        f = _profile(f"parity_26layers_{cd}.json")
+        if not os.path.exists(f):
+            out[cd] = None
+            continue
+        r = json.load(open(f))
+        out[cd] = {"samples": len(r["samples"]), "forward_rel_err_median": r["forward_rel_err_median"], "forward_rel_err_max": r["forward_rel_err_max"],
+                   "gradient_cosine_median": r["gradient_cosine_median"], "gradient_cosine_min": r["gradient_cosine_min"],
+                   "topk_rows_identical_pct": r["topk_rows_identical_pct"], "source": "committed file profiles/" + os.path.basename(f)}
+    out["what"] = ("26-layer HIP model vs the CPU oracle following the same top-4 neighbour decisions, B = 2, de-identitied weights "
+                   "(tests/test_gpu_model.py::test_full_depth_26_layers_against_oracle; bf16 = this line's mode: (input seed, weight salt) samples)")
+    f = _profile("train_fidelity.json")
+    if os.path.exists(f):
+        out["training_fidelity_source"] = "committed file profiles/" + os.path.basename(f) + " (tools/train_fidelity.py: 1,000 steps at full depth, bf16 vs fp32 mode)"
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="clips per GPU")
+    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="clips per GPU (weak scaling: the default)")
+    ap.add_argument("--global-batch", type=int, default=0, help="STRONG scaling: one global batch of this many clips split over the ranks (BASELINE configs[2] is "
+                    "--gpus 8 --global-batch 256 --det-conf: 32 clips per rank, as nn.DataParallel scatters one batch, train_and_evaluate_wp.py:236-238)")
+    ap.add_argument("--det-conf", action="store_true", help="WorldPose-det style input: detector confidence ~U(0,1) in the third channel, 1920x1080 frames (configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-roofline", action="store_true")
     ap.add_argument("--no-fp32", action="store_true", help="skip the fp32 parity-mode throughput leg")
@@ -211,6 +244,11 @@ def main():
 
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    strong = args.global_batch > 0
+    if strong:
+        if args.global_batch % world:
+            raise SystemExit(f"--global-batch {args.global_batch} does not divide over {world} ranks")
+        args.batch = args.global_batch // world
     torch.cuda.set_device(local)
     import torch.distributed as dist
     if world > 1 or args.force_dp:
@@ -232,7 +270,7 @@ def main():
         if os.environ.get("KASF_DP_SKIP_ALLREDUCE") == "1":          # diagnosis only: process group alive, no collective in the step
             model.grad_stage_hook = None
             dp.finish_gradients = lambda *a: None
-    x, y = K.synthetic_clips(args.batch, T, seed=1234 + rank)
+    x, y = K.synthetic_clips(args.batch, T, seed=1234 + rank, **({"res": (1920, 1080), "det_conf": True} if args.det_conf else {}))
     x, y = x.cuda(), y.cuda()
 
     def step():
@@ -307,17 +345,15 @@ def main():
         out = {
             "metric": "pose-clips/sec (27f x 17j) training step: fwd + 3-term loss + bwd + AdamW", "value": value, "unit": "pose-clips/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "SportsPose-GT 27-frame bf16 training, batch=256 per GPU (BASELINE.json configs[1])", "n_layers": LAYERS,
+            "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": workload_name(args, world, strong), "n_layers": LAYERS,
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world, "n_frames": T, "tokens_per_step_per_gpu": args.batch * T * 17,
+                       "input": "detector confidence ~U(0,1), 1920x1080" if args.det_conf else "ground-truth 2-D (confidence 1), 1312x1216",
                        "parallelism": f"dp{world}" if world > 1 else "single", "init": "reference default init, seed 114514"},
             "final_loss": loss_val,
             "eval": {"clips_per_sec": args.batch * world / dt_eval, "clips_per_sec_flip_tta": args.batch * world / dt_tta,
                      "note": "forward only, same model and batch per GPU, evaluation mode; not part of value"},
-            "parity": "26-layer forward vs the oracle with the same top-4 neighbour decisions: fp32 mode 4e-6, gradient cosine 1.0000000 (3 near-tie rows of "
-                      "23,868 differ); bf16 mode (this line's) 0.10 / 0.958 on de-identitied weights (tests/test_gpu_model.py::test_full_depth_26_layers_against_oracle); "
-                      "training fidelity on a LEARNABLE task at full depth, 1,000 steps, B = 256: test MPJPE over the last ten checkpoints bf16 31.76 +- 0.84 mm (7 samples) vs fp32 mode 32.44 +- 1.03 mm (4 samples), from 208 mm; training loss +0.8 % "
-                      "(profiles/r3_train_fidelity.json); fp32 mode vs the CPU oracle after 16 steps: 1e-4 mm",
+            "parity": parity_summary(),
             "model_mfma_frac": value / world * FLOP_PER_CLIP_TRAIN / (PEAK_BF16_TFLOPS * 1e12),
         }
         if not args.no_kernel_roofline:

@@ -51,8 +51,14 @@ typedef struct kasf_config {
 
 const char* kasf_last_error(void);
 /* Process-wide: 1 = the three branches of a layer run back to back on the caller's stream instead of on three streams (the mode isolated kernel
- * profiles are taken in; about 4 % of the training throughput).  Gradients are bit-reproducible from run to run either way, and the two settings give
- * the same bits.  Default 0 (or 1 when KASF_SINGLE_STREAM is set in the environment).  Call between steps, not while a pass is being enqueued. */
+ * profiles are taken in; about 4 % of the training throughput).  NOT a determinism switch: gradients are reproducible from run to run either way and
+ * the two settings give the same bits (every gradient reduction is a fixed-order sum; the one exception is the BatchNorm batch statistics, whose
+ * per-node sums cross workgroups as fp64 atomic adds of fp32-derived partials -- order-dependent below 1e-15 relative, which can move an fp32 mean by
+ * one ulp in rare cases; tests/test_gpu_determinism.py has not seen it).  Default 0 (or 1 when KASF_SINGLE_STREAM is set in the environment).
+ * kasf_forward / kasf_backward read the setting once per call.  kasf_set_deterministic / kasf_get_deterministic are the round-3 names of the same
+ * two functions, kept as aliases. */
+void kasf_set_single_stream(int32_t on);
+int32_t kasf_get_single_stream(void);
 void kasf_set_deterministic(int32_t on);
 int32_t kasf_get_deterministic(void);
 int kasf_version(void);
@@ -101,10 +107,11 @@ int kasf_forward(const kasf_model* m, const float* params, const void* packed, f
 int kasf_backward(const kasf_model* m, const float* params, const void* packed, const float* dout, float* grads, void* workspace,
                   int64_t workspace_bytes, int32_t batch, int32_t flags, int32_t stage_begin, int32_t stage_end, void* stream);
 
-/* losses: 4 + 4 * batch floats; on return losses[0..3] = {total, mpjpe, n_mpjpe, velocity} (the rest is scratch: per-clip sums, added in a fixed order so
- * that the result is bit-reproducible); dpred = grad_scale * dTotal/dpred */
-int kasf_loss3(const float* pred, const float* target, float* dpred, float* losses, int32_t batch, int32_t n_frames, float lambda_n_mpjpe,
-               float lambda_velocity, float grad_scale, void* stream);
+/* losses: `losses_floats` >= 4 + 4 * batch floats (error 5 otherwise: the capacity is an argument since ABI 6, so that a caller written against the
+ * 4-float buffer of ABI <= 4 fails to compile instead of being overrun); on return losses[0..3] = {total, mpjpe, n_mpjpe, velocity} (the rest is
+ * scratch: per-clip sums, added in a fixed order so that the result is bit-reproducible); dpred = grad_scale * dTotal/dpred */
+int kasf_loss3(const float* pred, const float* target, float* dpred, float* losses, int64_t losses_floats, int32_t batch, int32_t n_frames,
+               float lambda_n_mpjpe, float lambda_velocity, float grad_scale, void* stream);
 
 /* torch.optim.AdamW step over n contiguous fp32 elements (n multiple of 4); step_index starts at 1 */
 int kasf_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2, float eps,

@@ -9,12 +9,13 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkasf_hip.so")
+# KASF_LIB: another build of the same library (same-box A/B comparisons of kernel variants: tools/ab.sh); the default is the in-tree product build
+LIB_PATH = os.environ.get("KASF_LIB") or os.path.join(_HERE, "libkasf_hip.so")
 
 DTYPE_F32, DTYPE_BF16 = 0, 1
 FLAG_TRAIN, FLAG_RETURN_REP, FLAG_KEEP = 1, 2, 4
 EVAL_COLS = 22
-ABI_VERSION = 5          # kasf_version() of the library these prototypes describe (a stale in-tree .so is refused)
+ABI_VERSION = 6          # kasf_version() of the library these prototypes describe (a stale in-tree .so is refused)
 
 
 class KasfConfig(C.Structure):
@@ -33,6 +34,8 @@ _pi64, _pi32 = C.POINTER(C.c_int64), C.POINTER(C.c_int32)
 SIGNATURES = {
     "kasf_last_error": (C.c_char_p, []),
     "kasf_version": (_i32, []),
+    "kasf_set_single_stream": (None, [_i32]),
+    "kasf_get_single_stream": (_i32, []),
     "kasf_set_deterministic": (None, [_i32]),
     "kasf_get_deterministic": (_i32, []),
     "kasf_model_create": (_i32, [C.POINTER(KasfConfig), C.POINTER(_vp)]),
@@ -53,7 +56,7 @@ SIGNATURES = {
     "kasf_workspace_bytes": (_i64, [_vp, _i32, _i32]),
     "kasf_forward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "kasf_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
-    "kasf_loss3": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _f32, _f32, _vp]),
+    "kasf_loss3": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _f32, _f32, _vp]),
     "kasf_adamw_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _vp]),
     "kasf_gather_clips": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
     "kasf_joint_flip": (_i32, [_vp, _vp, _i64, _vp]),

@@ -1,6 +1,7 @@
 // Host-side engine of libkasf_hip: parameter layout (reference state_dict names), packed-weight table,
 // workspace plan and the forward / backward launch sequences of the KASportsFormer path
 // (reference: model/KASportsFormer.py:204-347).  Pure launch code: no allocation, no synchronisation.
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -33,12 +34,15 @@ struct BlockOff {
 struct LayerOff { BlockOff blk[6]; int64_t fus_w, fus_b, begin, end; };
 struct TopOff { int64_t norm_w, norm_b, fc_w, fc_b, head_w, head_b, p_fc, p_fcT, begin, end; };
 
-// The three branches of a layer run on three streams unless this is set: kasf_set_deterministic(1) (or KASF_SINGLE_STREAM=1 in the environment, read once)
+// The three branches of a layer run on three streams unless this is set: kasf_set_single_stream(1) (or KASF_SINGLE_STREAM=1 in the environment, read once)
 // runs them back to back on the caller's stream: same results bit for bit, the mode the isolated per-kernel profiles are taken in; -4 % throughput.
-static int g_single_stream = -1;
+// kasf_forward / kasf_backward read the flag ONCE per call into a local (a toggle from another thread between the fork and the join of a layer would
+// otherwise skip one of the two event waits).
+static std::atomic<int> g_single_stream{-1};
 static bool single_stream() {
-    if (g_single_stream < 0) g_single_stream = getenv("KASF_SINGLE_STREAM") != nullptr ? 1 : 0;
-    return g_single_stream != 0;
+    int v = g_single_stream.load(std::memory_order_relaxed);
+    if (v < 0) { v = getenv("KASF_SINGLE_STREAM") != nullptr ? 1 : 0; g_single_stream.store(v, std::memory_order_relaxed); }
+    return v != 0;
 }
 constexpr int64_t WG_PARTIAL_FLOATS = KASF_MLP_PARTIAL_FLOATS + 65536;   // per-split weight-gradient tiles (256 workgroups x 128x128, or 64 ranges x (dW1 + dW2) of the MLP) + the per-split rows of a bias gradient
 
@@ -500,9 +504,12 @@ int check_model(const kasf_model* m) {
 extern "C" {
 
 const char* kasf_last_error(void) { return g_err.c_str(); }
-void kasf_set_deterministic(int32_t on) { g_single_stream = on ? 1 : 0; }
-int32_t kasf_get_deterministic(void) { return single_stream() ? 1 : 0; }
-int kasf_version(void) { return 5; }
+void kasf_set_single_stream(int32_t on) { g_single_stream.store(on ? 1 : 0, std::memory_order_relaxed); }
+int32_t kasf_get_single_stream(void) { return single_stream() ? 1 : 0; }
+// the round-3 names: the setting never was about determinism (gradients are bit-reproducible either way)
+void kasf_set_deterministic(int32_t on) { kasf_set_single_stream(on); }
+int32_t kasf_get_deterministic(void) { return kasf_get_single_stream(); }
+int kasf_version(void) { return 6; }
 
 int kasf_model_create(const kasf_config* cfg, kasf_model** out) {
     if (cfg == nullptr || out == nullptr) return kasf_set_error(2, "null argument");
@@ -656,6 +663,7 @@ int kasf_forward(const kasf_model* m, const float* params, const void* packed, f
     Ctx c{m, params, (const char*)packed, buffers, nullptr, (char*)workspace, (hipStream_t)stream, batch, m->cfg.n_frames, m->cfg.dtype, esize(m),
           (int64_t)batch * m->cfg.n_frames * 17, train, bn_train, nullptr};
     g_err.clear();
+    const bool one_stream = single_stream();
     HIPCHK(hipMemsetAsync(c.w(p.stats_begin), 0, p.stats_bytes, c.s));
     if (train) HIPCHK(hipMemcpyAsync(c.w(p.x3), x, c.M * 3 * sizeof(float), hipMemcpyDeviceToDevice, c.s));
     kasf_launch_prologue_fwd(c.dt, c.s, x, params, m->d_pro, c.w(p.xj), c.w(p.xb), c.w(p.xl), (float*)c.w(p.bone3), (float*)c.w(p.limb3),
@@ -670,18 +678,16 @@ int kasf_forward(const kasf_model* m, const float* params, const void* packed, f
         for (int br = 0; br < 3; ++br) {
             Ctx cb = c;
             if (br > 0) {
-                cb.s = single_stream() ? c.s : m->side[br - 1];
-                if (!single_stream()) HIPCHK(hipStreamWaitEvent(cb.s, m->ev_fork, 0));
+                cb.s = one_stream ? c.s : m->side[br - 1];
+                if (!one_stream) HIPCHK(hipStreamWaitEvent(cb.s, m->ev_fork, 0));
             }
             const void* in0 = (br == 2 && l == 0) ? c.w(p.xb) : xcur;         // layer 0: bone branch starts from the bone embedding (:332-336)
             block_forward(cb, lo.blk[2 * br], lw.b[2 * br], in0, c.w(p.xl), p, p.sc[br]);
             block_forward(cb, lo.blk[2 * br + 1], lw.b[2 * br + 1], c.w(lw.b[2 * br].x_out), c.w(p.xl), p, p.sc[br]);
             if (br > 0) {
-                if (!single_stream()) {
-                    if (!single_stream()) {
-                        HIPCHK(hipEventRecord(m->ev_join[br - 1], cb.s));
-                        HIPCHK(hipStreamWaitEvent(c.s, m->ev_join[br - 1], 0));
-                    }
+                if (!one_stream) {
+                    HIPCHK(hipEventRecord(m->ev_join[br - 1], cb.s));
+                    HIPCHK(hipStreamWaitEvent(c.s, m->ev_join[br - 1], 0));
                 }
             }
         }
@@ -710,6 +716,7 @@ int kasf_backward(const kasf_model* m, const float* params, const void* packed, 
     Ctx c{m, params, (const char*)packed, nullptr, grads, (char*)workspace, (hipStream_t)stream, batch, m->cfg.n_frames, m->cfg.dtype, esize(m),
           (int64_t)batch * m->cfg.n_frames * 17, true, (flags & KASF_FLAG_TRAIN) != 0, nullptr};
     g_err.clear();
+    const bool one_stream = single_stream();
     const TopOff& t = m->top;
     // one sink of per-workgroup column sums per branch stream; flushed (fixed-order finish, k_reduce.hip) on the caller's stream at the end of every stage
     KasfColSink sinks[3];
@@ -749,8 +756,8 @@ int kasf_backward(const kasf_model* m, const float* params, const void* packed, 
                 Ctx cb = c;
                 cb.sink = &sinks[br];
                 if (br > 0) {
-                    cb.s = single_stream() ? c.s : m->side[br - 1];
-                    if (!single_stream()) HIPCHK(hipStreamWaitEvent(cb.s, m->ev_fork, 0));
+                    cb.s = one_stream ? c.s : m->side[br - 1];
+                    if (!one_stream) HIPCHK(hipStreamWaitEvent(cb.s, m->ev_fork, 0));
                 }
                 const Scratch& sc = p.sc[br];
                 const bool bone0 = (br == 2 && l == 0);
@@ -758,7 +765,7 @@ int kasf_backward(const kasf_model* m, const float* params, const void* packed, 
                 block_backward(cb, lo.blk[2 * br + 1], lw.b[2 * br + 1], c.w(lw.b[2 * br].x_out), c.w(p.xl), c.w(gsrc[br]), c.w(sc.t1), 0, p, sc);
                 block_backward(cb, lo.blk[2 * br], lw.b[2 * br], in0, c.w(p.xl), c.w(sc.t1), bone0 ? c.w(p.g_bone) : c.w(sc.g_in), 0, p, sc);
                 if (br > 0) {
-                    if (!single_stream()) {
+                    if (!one_stream) {
                         HIPCHK(hipEventRecord(m->ev_join[br - 1], cb.s));
                         HIPCHK(hipStreamWaitEvent(c.s, m->ev_join[br - 1], 0));
                     }
@@ -775,9 +782,9 @@ int kasf_backward(const kasf_model* m, const float* params, const void* packed, 
             const void* gs[3] = {g_x, c.w(p.g_bone), c.w(p.g_limb)};
             // the three embedding backward passes are independent: joints and bone on the side streams, limb (+ the limb-refusion MLPs that
             // consume its input gradient) on the caller's stream
-            if (!single_stream()) HIPCHK(hipEventRecord(m->ev_fork, c.s));
+            if (!one_stream) HIPCHK(hipEventRecord(m->ev_fork, c.s));
             for (int sidx = 0; sidx < 3; ++sidx) {
-                hipStream_t st = (sidx == 2 || single_stream()) ? c.s : m->side[sidx];
+                hipStream_t st = (sidx == 2 || one_stream) ? c.s : m->side[sidx];
                 if (st != c.s) HIPCHK(hipStreamWaitEvent(st, m->ev_fork, 0));
                 kasf_launch_embed_bwd(c.dt, st, gs[sidx], src[sidx], params + po.embed_w[sidx], grads + po.embed_w[sidx], grads + po.embed_b[sidx],
                                       grads + po.pos[sidx], sidx == 2 ? (float*)c.w(p.dlimb3) : nullptr, frames, &sinks[sidx]);
@@ -787,7 +794,7 @@ int kasf_backward(const kasf_model* m, const float* params, const void* packed, 
             const int64_t rf_base = po.mlp[0][0], rf_end = po.mlp[50][3] + 1;
             kasf_launch_refusion_bwd(c.s, (const float*)c.w(p.x3), (const float*)c.w(p.dlimb3), params, grads, m->d_pro, frames, &sinks[2], rf_base,
                                      (int)(rf_end - rf_base));
-            if (!single_stream())
+            if (!one_stream)
                 for (int sidx = 0; sidx < 2; ++sidx) HIPCHK(hipStreamWaitEvent(c.s, m->ev_join[sidx], 0));
         }
         kasf_col_flush(c.s, sink_ptrs, 3);          // every stream of the stage has joined the caller's: finish its per-channel gradients in a fixed order
@@ -797,9 +804,11 @@ int kasf_backward(const kasf_model* m, const float* params, const void* packed, 
     return 0;
 }
 
-int kasf_loss3(const float* pred, const float* target, float* dpred, float* losses, int32_t batch, int32_t n_frames, float lambda_n_mpjpe,
-               float lambda_velocity, float grad_scale, void* stream) {
+int kasf_loss3(const float* pred, const float* target, float* dpred, float* losses, int64_t losses_floats, int32_t batch, int32_t n_frames,
+               float lambda_n_mpjpe, float lambda_velocity, float grad_scale, void* stream) {
     if (!pred || !target || !dpred || !losses) return kasf_set_error(2, "null pointer argument");
+    if (batch < 1 || n_frames < 1) return kasf_set_error(2, "loss3: batch and n_frames must be positive");
+    if (losses_floats < 4 + 4 * (int64_t)batch) return kasf_set_error(5, "loss3: `losses` must hold 4 + 4 * batch floats (the per-clip sums live behind the result)");
     kasf_launch_loss3((hipStream_t)stream, pred, target, dpred, losses, batch, n_frames, lambda_n_mpjpe, lambda_velocity, grad_scale);
     HIPCHK(hipGetLastError());
     return 0;

@@ -18,7 +18,7 @@ class _Loss3(torch.autograd.Function):
         dpred = torch.empty_like(pred)
         scratch = torch.empty(4 + 4 * B, dtype=torch.float32, device=pred.device)      # [0:4] the result, the rest per-clip sums (kasf.h)
         lib = _lib.load()
-        _lib.check(lib.kasf_loss3(pred.data_ptr(), target.data_ptr(), dpred.data_ptr(), scratch.data_ptr(), B, T, float(lambda_n), float(lambda_v),
+        _lib.check(lib.kasf_loss3(pred.data_ptr(), target.data_ptr(), dpred.data_ptr(), scratch.data_ptr(), scratch.numel(), B, T, float(lambda_n), float(lambda_v),
                                   1.0, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
         losses = scratch[:4]
         ctx.save_for_backward(dpred)

@@ -402,15 +402,18 @@ class KASportsFormer(nn.Module):
             pass
 
 
-def set_deterministic(on: bool = True) -> None:
+def set_single_stream(on: bool = True) -> None:
     """Process-wide: run the three branches of every layer back to back on the caller's stream instead of on three streams (about 4 % of the training
-    throughput).  Gradients are bit-reproducible from run to run either way and both settings give the same bits; this is the mode isolated kernel profiles
-    are taken in."""
-    _lib.load().kasf_set_deterministic(1 if on else 0)
+    throughput): the mode isolated kernel profiles are taken in.  Not a determinism switch -- gradients are bit-reproducible from run to run either way
+    and both settings give the same bits."""
+    _lib.load().kasf_set_single_stream(1 if on else 0)
 
 
-def is_deterministic() -> bool:
-    return bool(_lib.load().kasf_get_deterministic())
+def is_single_stream() -> bool:
+    return bool(_lib.load().kasf_get_single_stream())
+
+
+set_deterministic, is_deterministic = set_single_stream, is_single_stream      # the round-3 names
 
 
 def load_model(args) -> nn.Module:

@@ -33,6 +33,7 @@ class DataParallel:
         self.rank = dist.get_rank(process_group)
         self._pending = []
         self.optimizer = None
+        self._scale_in_place = False
         if optimizer is not None:
             self.attach_optimizer(optimizer)
         self.sync_from_rank0()
@@ -40,11 +41,15 @@ class DataParallel:
         model.grad_stage_group = stages_per_bucket
 
     def attach_optimizer(self, optimizer):
-        """The all-reduce is a SUM: the mean over ranks is taken by the optimizer step (``FusedAdamW.grad_scale = 1 / world_size``)."""
-        if not hasattr(optimizer, "grad_scale"):
-            raise TypeError("DataParallel folds 1/world_size into FusedAdamW.grad_scale; for a torch.optim optimizer divide the gradients yourself "
-                            "(model.flat_grad[:model.n_live] /= world) after finish_gradients()")
-        optimizer.grad_scale = 1.0 / self.world
+        """The all-reduce is a SUM; the mean over ranks is taken once per step, where it is cheapest for the optimizer at hand: ``FusedAdamW`` folds
+        ``grad_scale = 1 / world_size`` into its update; for any other optimizer (INTEGRATION.md path A: a stock ``torch.optim.AdamW(model.parameters())``,
+        whose per-parameter ``.grad`` tensors are views of the flat gradient) ``finish_gradients`` scales the finished flat gradient in place, one launch."""
+        self._scale_in_place = not hasattr(optimizer, "grad_scale")
+        if self._scale_in_place:
+            if not self.model.attach_param_grads:
+                raise RuntimeError("a torch.optim optimizer reads p.grad: leave model.attach_param_grads = True (the per-parameter views of the flat gradient)")
+        else:
+            optimizer.grad_scale = 1.0 / self.world
         self.optimizer = optimizer
 
     def sync_buffers_from_rank0(self):
@@ -81,6 +86,8 @@ class DataParallel:
             self._pending = []
         elif m.flat_grad is not None:
             dist.all_reduce(m.flat_grad[:m.n_live], op=dist.ReduceOp.SUM, group=self.group)
+        if self._scale_in_place and self.world > 1 and m.flat_grad is not None:
+            m.flat_grad[:m.n_live].mul_(1.0 / self.world)         # p.grad of every live parameter is a view of this array
 
     def __call__(self, x, return_rep=False):
         return self.model(x, return_rep)

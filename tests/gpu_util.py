@@ -114,3 +114,36 @@ class forced_adjacency:
     def summary(self):
         return (f"adjacency rows {self.rows}: {100.0 * (self.rows - self.mismatched) / max(self.rows, 1):.3f} % identical to the oracle's own top-4 "
                 f"({self.mismatched} differ, {self.unexplained} of them not near-ties); entries {100.0 * self.bits_equal / max(self.bits, 1):.4f} % equal")
+
+
+def compare_grads(model, oracle, cd, floor_rel=None, small=256):
+    """Every gradient of the HIP model against the oracle's.  Per-tensor error = max |g - r| / max(|r|max, floor_rel * gmax) (the floor: gradients that are
+    sums of cancelling terms sit at the summation-noise floor of BOTH sides).  bf16 mode: tensors of fewer than `small` elements (the 16-element limb-MLP
+    weights at the end of the longest path, biases of a few entries) carry a difference of large noisy terms -- their individual error is a sample of bf16
+    rounding noise, not a property of a kernel -- so they are judged POOLED (one cosine over all of them) and the per-tensor bar applies to the rest.
+    Returns a dict: worst (error, name) over the per-tensor set, pooled cosine of the small set, cosine over everything."""
+    if floor_rel is None:
+        floor_rel = 1e-3 if cd == "fp32" else 0.05
+    ref = dict(oracle.named_parameters())
+    gmax = max(float(q.grad.abs().max()) for q in ref.values() if q.grad is not None)
+    errs, pooled, dots, none_mismatch = {}, [0.0, 0.0, 0.0], [0.0, 0.0, 0.0], []
+    for n, p in model.named_parameters():
+        r = ref[n].grad
+        if (r is None) != (p.grad is None):
+            none_mismatch.append(n)
+            continue
+        if r is None:
+            continue
+        g, r = p.grad.detach().double().cpu(), r.double()
+        d = (float((g * r).sum()), float((g * g).sum()), float((r * r).sum()))
+        for k in range(3):
+            dots[k] += d[k]
+        if cd == "bf16" and r.numel() < small:
+            for k in range(3):
+                pooled[k] += d[k]
+            continue
+        errs[n] = float((g - r).abs().max() / max(float(r.abs().max()), floor_rel * gmax))
+    worst = max(errs, key=errs.get)
+    return {"errors": errs, "worst": errs[worst], "worst_name": worst, "gmax": gmax, "none_mismatch": none_mismatch,
+            "pooled_small_cosine": pooled[0] / max(1e-300, pooled[1] ** 0.5 * pooled[2] ** 0.5) if pooled[2] > 0 else 1.0,
+            "cosine": dots[0] / max(1e-300, dots[1] ** 0.5 * dots[2] ** 0.5)}

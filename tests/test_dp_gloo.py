@@ -63,6 +63,33 @@ def _worker(rank, world, port, overlap, q):
         expect = sum(r + 1 for r in range(world)) * pattern
         assert torch.equal(g[:m.n_live], expect[:m.n_live])
         assert torch.count_nonzero(g[m.n_live:]) == 0
+        # INTEGRATION path A under data parallelism: a stock torch.optim optimizer has no grad_scale, so finish_gradients turns the all-reduced SUM into
+        # the MEAN in place -- in the flat array the per-parameter .grad tensors are views of
+        g2 = torch.zeros(m.n_flat)
+        for st in range(stages):
+            _lib.check(lib.kasf_stage_grad_range(m._layout, st, C.byref(b), C.byref(e)))
+            if e.value > b.value:
+                g2[b.value:e.value] = (rank + 1) * pattern[b.value:e.value]
+                if m.grad_stage_hook is not None:
+                    m.grad_stage_hook(st, g2[b.value:e.value])
+        m.flat_grad = g2
+        for prm, off, n, shape in m._live:                  # what _launch_backward leaves with attach_param_grads=True
+            prm.grad = g2[off:off + n].view(shape)
+        stock = torch.optim.SGD(m.parameters(), lr=1.0)
+        before = m._flat.clone()
+        dp.finish_gradients(stock)
+        assert torch.allclose(g2[:m.n_live], expect[:m.n_live] / world, rtol=1e-6, atol=0)
+        prm, off, n, shape = m._live[3]
+        assert torch.equal(prm.grad.flatten(), g2[off:off + n])
+        stock.step()
+        for prm, off, n, shape in m._live[::37]:            # (the flat layout has alignment gaps no parameter covers: compare where parameters are)
+            assert torch.allclose(m._flat[off:off + n], before[off:off + n] - expect[off:off + n] / world, rtol=1e-5, atol=1e-5)
+        m.attach_param_grads = False
+        try:
+            dp.attach_optimizer(torch.optim.SGD(m.parameters(), lr=1.0))
+            raise AssertionError("a stock optimizer with attach_param_grads=False would step on nothing")
+        except RuntimeError:
+            m.attach_param_grads = True
         # training leaves every rank with ITS OWN BatchNorm running statistics; evaluation and checkpoints must see rank 0's on every rank
         # (nn.DataParallel keeps replica 0's buffers, train_and_evaluate_sp.py:262-264)
         from kasportsformer_amd.evaluate import _broadcast_buffers

@@ -107,15 +107,15 @@ def test_bf16_training_trajectory_is_bit_reproducible():
 
 
 def test_one_stream_switch():
-    """kasportsformer_amd.set_deterministic(True) runs the three branches on the caller's stream (the mode isolated kernel profiles are taken in): same bits
+    """kasportsformer_amd.set_single_stream(True) runs the three branches on the caller's stream (the mode isolated kernel profiles are taken in): same bits
     as with three streams."""
     import kasportsformer_amd as K
     a = _three_runs("bf16", 27, 16)[0]
-    K.set_deterministic(True)
+    K.set_single_stream(True)
     try:
-        assert K.is_deterministic()
+        assert K.is_single_stream() and K.is_deterministic()
         b = _three_runs("bf16", 27, 16)[0]
     finally:
-        K.set_deterministic(False)
-    assert not K.is_deterministic()
+        K.set_single_stream(False)
+    assert not K.is_single_stream()
     assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from oracle import kasf_oracle as O
-from tests.gpu_util import decode_masks, forced_adjacency, make_pair, oracle_stage_hooks, rel_err, ws_tensor
+from tests.gpu_util import compare_grads, decode_masks, forced_adjacency, make_pair, oracle_stage_hooks, rel_err, ws_tensor
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -113,8 +113,11 @@ def test_stage_by_stage_against_oracle(cd, tol):
     assert _abs_err(limb, oracle.bone_refusion(x)) < 1e-5
 
 
+BF16_TENSOR_TOL = 0.12      # bf16, per-tensor bar for tensors of >= 256 elements (smaller ones are judged pooled: tests/gpu_util.py compare_grads); observed x 2, see each test's print
+
+
 @pytest.mark.parametrize("L,T,B", [(2, 27, 2), (1, 81, 2), (1, 9, 3), (1, 27, 37), (1, 27, 101)])      # B=37: 531 tiles, two per persistent workgroup; B=101: 1,449 tiles (six per workgroup: ring slots reused, steady-state look-ahead waits), both with a ragged last tile
-@pytest.mark.parametrize("cd,tol", [("fp32", 2e-3), ("bf16", 0.35)])
+@pytest.mark.parametrize("cd,tol", [("fp32", 2e-3), ("bf16", BF16_TENSOR_TOL)])
 def test_backward_matches_oracle(cd, tol, L, T, B):
     oracle, model = make_pair(L, T, cd)
     x, y = O.synthetic_clips(B, T)
@@ -127,36 +130,22 @@ def test_backward_matches_oracle(cd, tol, L, T, B):
     loss.backward()
     torch.cuda.synchronize()
     assert abs(loss.item() - loss_ref.item()) < (1e-4 if cd == "fp32" else 5e-2) * max(1.0, abs(loss_ref.item()))
-    ref_grads = dict(oracle.named_parameters())
-    gmax = max(float(q.grad.abs().max()) for q in ref_grads.values() if q.grad is not None)
-    worst, none_mismatch, dots = {}, [], [0.0, 0.0, 0.0]
-    for n, p in model.named_parameters():
-        r = ref_grads[n].grad
-        if (r is None) != (p.grad is None):
-            none_mismatch.append(n)
-            continue
-        if r is None:
-            continue
-        g = p.grad.detach().double().cpu()
-        if cd == "fp32":   # floor: gradients that are sums of cancelling terms (constant-confidence limb MLPs) carry fp32 summation-order noise on both sides
-            # (at B=101 these sums run over 46k tokens and the noise of the cancelling limb-MLP gradients, which sit at 1e-4..1e-2 of gmax, grows with
-            # it: the floor is raised there; the small batches keep the tight floor for exactly those tensors)
-            worst[n] = float((g - r.double()).abs().max() / max(float(r.abs().max()), (1e-3 if B <= 37 else 2e-2) * gmax))
-        else:   # bf16: tiny gradients (16-element limb-refusion tensors fed through a bf16-accumulated g_limb) sit at the bf16 noise floor -> floor the scale
-            worst[n] = float((g - r.double()).abs().max() / max(float(r.abs().max()), 0.05 * gmax))
-        dots[0] += float((g * r.double()).sum()); dots[1] += float((g * g).sum()); dots[2] += float((r.double() ** 2).sum())
-    assert not none_mismatch, none_mismatch
+    # fp32 floor: gradients that are sums of cancelling terms (constant-confidence limb MLPs) carry fp32 summation-order noise on both sides (at B=101 these
+    # sums run over 46k tokens and the noise of the cancelling limb-MLP gradients, which sit at 1e-4..1e-2 of gmax, grows with it: the floor is raised there)
+    rep = compare_grads(model, oracle, cd, floor_rel=(1e-3 if B <= 37 else 2e-2) if cd == "fp32" else 0.05)
+    assert not rep["none_mismatch"], rep["none_mismatch"]
     assert sum(1 for p in model.parameters() if p.grad is None) == 8 * L   # 8 dead norm1_limb tensors per layer
-    cosine = dots[0] / (dots[1] ** 0.5 * dots[2] ** 0.5)
-    print(f"[backward, {cd}, L={L} T={T} B={B}] gradient cosine {cosine:.7f}, worst per-tensor error {max(worst.values()):.3e} ({max(worst, key=worst.get)})")
-    assert cosine > (0.999999 if cd == "fp32" else 0.999), cosine                  # bf16: observed >= 0.9995
+    print(f"[backward, {cd}, L={L} T={T} B={B}] gradient cosine {rep['cosine']:.7f}, worst per-tensor error {rep['worst']:.3e} ({rep['worst_name']}), "
+          f"pooled cosine of the tensors below 256 elements {rep['pooled_small_cosine']:.5f}")
+    assert rep["cosine"] > (0.999999 if cd == "fp32" else 0.999), rep["cosine"]                  # bf16: observed >= 0.9995
+    assert rep["pooled_small_cosine"] > 0.99, rep["pooled_small_cosine"]
     if cd == "bf16" and B * T >= 900:
-        tol = 0.06       # per-tensor bf16 error with >= 15k tokens behind every sum: observed 2.5e-2 (x 2); the handful-of-clips cases reach 0.29
-    bad = sorted(((v, k, float(ref_grads[k].grad.abs().max()) / gmax) for k, v in worst.items() if not v < tol), reverse=True)
-    assert not bad, f"{len(bad)} gradients above {tol}; worst (err, name, |g|max/gmax): {bad[:12]}"
+        tol = 0.06       # per-tensor bf16 error with >= 15k tokens behind every sum: observed 2.5e-2 (x 2)
+    bad = sorted(((v, k) for k, v in rep["errors"].items() if not v < tol), reverse=True)
+    assert not bad, f"{len(bad)} gradients above {tol}; worst (err, name): {bad[:12]}"
 
 
-@pytest.mark.parametrize("cd,tol", [("fp32", 2e-3), ("bf16", 0.35)])
+@pytest.mark.parametrize("cd,tol", [("fp32", 2e-3), ("bf16", BF16_TENSOR_TOL)])
 def test_detected_keypoints_confidence_channel(cd, tol):
     """SURVEY config 3 ("WorldPose-det"): the third input channel is a detector confidence ~U(0,1) instead of the constant 1 of ground-truth 2-D
     input, so the confidence-channel limb MLPs and the third embedding column see real data: forward and every gradient against the oracle."""
@@ -171,20 +160,13 @@ def test_detected_keypoints_confidence_channel(cd, tol):
     loss.backward()
     torch.cuda.synchronize()
     assert abs(loss.item() - loss_ref.item()) < (1e-4 if cd == "fp32" else 5e-2) * max(1.0, abs(loss_ref.item()))
-    ref_grads = dict(oracle.named_parameters())
-    gmax = max(float(q.grad.abs().max()) for q in ref_grads.values() if q.grad is not None)
-    bad, worst_e = [], 0.0
-    for n, p in model.named_parameters():
-        r = ref_grads[n].grad
-        assert (r is None) == (p.grad is None), n
-        if r is None:
-            continue
-        err = float((p.grad.detach().double().cpu() - r.double()).abs().max() / max(float(r.abs().max()), (1e-3 if cd == "fp32" else 0.05) * gmax))
-        worst_e = max(worst_e, err)
-        if not err < tol:
-            bad.append((err, n))
-    print(f"[detector confidence, {cd}] worst per-tensor gradient error {worst_e:.3e}")
-    assert not bad, sorted(bad, reverse=True)[:10]
+    rep = compare_grads(model, oracle, cd)
+    assert not rep["none_mismatch"], rep["none_mismatch"]
+    print(f"[detector confidence, {cd}] gradient cosine {rep['cosine']:.7f}, worst per-tensor error {rep['worst']:.3e} ({rep['worst_name']}), pooled cosine of the "
+          f"tensors below 256 elements {rep['pooled_small_cosine']:.5f}")
+    bad = sorted(((v, k) for k, v in rep["errors"].items() if not v < tol), reverse=True)
+    assert not bad, bad[:10]
+    assert rep["pooled_small_cosine"] > 0.99 and rep["cosine"] > (0.999999 if cd == "fp32" else 0.999)
 
 
 def test_zero_length_bones_and_static_clip():
@@ -497,14 +479,13 @@ def test_bone_gather_is_bit_exact_on_integer_coordinates():
 # ---------------------------------------------------------------------------------------------------------------
 # Full depth: the shipped 26-layer model against the oracle, both compute modes (every other oracle comparison is <= 2 layers)
 # ---------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("cd", ["fp32", "bf16"])
-def test_full_depth_26_layers_against_oracle(cd):
-    """The shipped depth, de-identitied weights, HIP vs oracle: (1) every top-4 neighbour decision of the 26 temporal GCN blocks row by row,
+def _full_depth_sample(cd, seed, salt):
+    """One (input seed, weight salt) sample of the 26-layer comparison: (1) every top-4 neighbour decision of the 26 temporal GCN blocks row by row,
     (2) forward, per-layer activations, loss and all gradients with the oracle following the HIP path's neighbour decisions (tests/gpu_util.py
     forced_adjacency says why), (3) the free-running end-to-end deviation, reported."""
-    oracle, model = make_pair(26, 27, cd)
+    oracle, model = make_pair(26, 27, cd, salt=salt)
     cap = oracle_stage_hooks(oracle)
-    x, y = O.synthetic_clips(2, 27, seed=5)
+    x, y = O.synthetic_clips(2, 27, seed=seed)
     oracle.train(); model.train()
     with torch.no_grad():
         free = oracle(x)                                          # the oracle's own decisions: for the report only
@@ -532,22 +513,56 @@ def test_full_depth_26_layers_against_oracle(cd):
             g, r = p.grad.detach().double().cpu(), q.grad.double()
             dots[0] += float((g * r).sum()); dots[1] += float((g * g).sum()); dots[2] += float((r * r).sum())
     cosine = dots[0] / (dots[1] ** 0.5 * dots[2] ** 0.5)
-    print(f"[26 layers, {cd}] {fa.summary()}\n    same neighbour decisions: forward rel err {err:.3e}, loss {loss.item():.6f} vs {l_ref.item():.6f}, gradient cosine "
-          f"{cosine:.7f}, per-layer drift max {max(drift):.3e} (layer {drift.index(max(drift))}), first/last {drift[0]:.2e}/{drift[-1]:.2e};  free-running oracle: "
-          f"forward rel err {err_free:.3e}")
+    print(f"[26 layers, {cd}, input seed {seed}, weight salt {salt}] {fa.summary()}\n    same neighbour decisions: forward rel err {err:.3e}, loss {loss.item():.6f} vs "
+          f"{l_ref.item():.6f}, gradient cosine {cosine:.7f}, per-layer drift max {max(drift):.3e} (layer {drift.index(max(drift))}), first/last "
+          f"{drift[0]:.2e}/{drift[-1]:.2e};  free-running oracle: forward rel err {err_free:.3e}")
+    return {"seed": seed, "salt": salt, "forward_rel_err": err, "gradient_cosine": cosine, "loss": float(loss.item()), "loss_oracle": float(l_ref.item()),
+            "drift_max": max(drift), "forward_rel_err_free_running": err_free, "topk_rows": fa.rows, "topk_rows_identical": fa.rows - fa.mismatched,
+            "topk_rows_differ_not_near_tie": fa.unexplained, "topk_entries_equal_pct": 100.0 * fa.bits_equal / max(fa.bits, 1)}
+
+
+def _write_parity_report(cd, samples):
+    """The observed figures go to gpurun_out/r4_parity_26layers_<cd>.json (merged back from the GPU box; the copy committed under profiles/ is what
+    bench.py quotes in its `parity` field instead of a typed-in string)."""
+    import json, os, statistics
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    rep = {"test": "tests/test_gpu_model.py::test_full_depth_26_layers_against_oracle", "compute_dtype": cd, "n_layers": 26, "n_frames": 27, "batch": 2, "samples": samples,
+           "forward_rel_err_median": statistics.median(s["forward_rel_err"] for s in samples), "forward_rel_err_max": max(s["forward_rel_err"] for s in samples),
+           "gradient_cosine_median": statistics.median(s["gradient_cosine"] for s in samples), "gradient_cosine_min": min(s["gradient_cosine"] for s in samples),
+           "topk_rows_identical_pct": 100.0 * sum(s["topk_rows_identical"] for s in samples) / max(1, sum(s["topk_rows"] for s in samples))}
+    with open(os.path.join(out, f"r4_parity_26layers_{cd}.json"), "w") as f:
+        json.dump(rep, f, indent=1)
+    return rep
+
+
+FULL_DEPTH_BF16_SAMPLES = ((5, 0), (6, 1001), (7, 2002), (8, 3003), (9, 4004), (10, 5005))         # (input seed, weight salt); (5, 0) is the single sample of rounds 1-3
+
+
+@pytest.mark.parametrize("cd", ["fp32", "bf16"])
+def test_full_depth_26_layers_against_oracle(cd):
+    """The shipped depth, de-identitied weights, HIP vs oracle.  fp32 mode: one sample at the arithmetic tolerance.  bf16 mode: SIX independent (input seed,
+    weight salt) samples, all printed, judged on their median and their worst -- with O(1) layer scales this 26-layer network amplifies rounding noise
+    chaotically, so one sample cannot tell a kernel regression from luck (VERDICT r3 weak #1)."""
     if cd == "fp32":
-        assert fa.unexplained == 0, "a neighbour decision differs where the oracle's 4th and 5th similarities are NOT a near-tie"
-        assert err < 1e-3 and max(drift) < 1e-3 and cosine > 0.99999 and abs(loss.item() - l_ref.item()) < 1e-4 * max(1.0, abs(l_ref.item()))
-    else:   # bf16: activations are re-rounded to bf16 by every one of the 156 blocks.  With O(1) layer scales this 26-layer network amplifies rounding noise
-        # chaotically, so the two figures are a SAMPLE, not a property of a kernel: observed 0.105 / 0.958 with the first softmax formulation of the fused
-        # forward and 0.088 / 0.917 with the second (max over raw scores, one fma, outputs normalised instead of probabilities) -- the same arithmetic
-        # accuracy by every stable measure (stage errors 1.9e-2 vs 1.6e-2, gradient cosines of the 1-2 layer models 0.99945-0.99999 either way, same-box
-        # A/B).  DESIGN section 10 has the emulation that bounds what bf16 operands can give here (0.92-0.96).  Bars: forward observed x 2, cosine 0.88
-        assert err < 0.2 and cosine > 0.88
+        s = _full_depth_sample(cd, 5, 0)
+        _write_parity_report(cd, [s])
+        assert s["topk_rows_differ_not_near_tie"] == 0, "a neighbour decision differs where the oracle's 4th and 5th similarities are NOT a near-tie"
+        assert s["forward_rel_err"] < 1e-3 and s["drift_max"] < 1e-3 and s["gradient_cosine"] > 0.99999
+        assert abs(s["loss"] - s["loss_oracle"]) < 1e-4 * max(1.0, abs(s["loss_oracle"]))
+        return
+    samples = [_full_depth_sample(cd, seed, salt) for seed, salt in FULL_DEPTH_BF16_SAMPLES]
+    rep = _write_parity_report(cd, samples)
+    print(f"[26 layers, bf16, {len(samples)} samples] forward rel err median {rep['forward_rel_err_median']:.3e} / worst {rep['forward_rel_err_max']:.3e}; gradient cosine "
+          f"median {rep['gradient_cosine_median']:.4f} / worst {rep['gradient_cosine_min']:.4f}; top-4 rows identical to the fp32 oracle's {rep['topk_rows_identical_pct']:.2f} %")
+    # bf16: activations are re-rounded to bf16 by every one of the 156 blocks; DESIGN section 10 has the emulation that bounds what bf16 GEMM operands can give on
+    # this network (cosine 0.92-0.96 per sample).  Bars on the MEDIAN at the emulation's range, on the WORST sample at what one chaotic sample was seen to do.
+    assert rep["forward_rel_err_median"] < 0.15 and rep["forward_rel_err_max"] < 0.3
+    assert rep["gradient_cosine_median"] > 0.92 and rep["gradient_cosine_min"] > 0.85
 
 
 @pytest.mark.parametrize("T,B", [(243, 1), (100, 2), (33, 2), (5, 3), (4, 8), (64, 2), (96, 2), (32, 2), (130, 1), (200, 1), (256, 1), (50, 2)])      # 64 / 96: the three-tile fused temporal forward with an empty / a full last tile; 32: the largest one-tile group
-@pytest.mark.parametrize("cd,tol", [("fp32", 2e-3), ("bf16", 0.4)])      # bf16, a handful of clips: observed 0.04-0.30 on the worst (tiny) tensor, cosine >= 0.99977, forward 1.2e-2
+@pytest.mark.parametrize("cd,tol", [("fp32", 2e-3), ("bf16", BF16_TENSOR_TOL)])      # bf16, a handful of clips: per-tensor bar for tensors >= 256 elements, the tiny ones pooled; cosine >= 0.99977, forward 1.2e-2
 def test_arbitrary_clip_lengths(cd, tol, T, B):
     """The reference builds for any n_frames (KASportsFormer.py:291-295, README.md:59): 243 is the long configuration of this model family;
     100 is past the MFMA attention cores (<= 96), 33 past the fused attention block (<= 32), 5 and 4 are the shortest clips whose rows
@@ -568,24 +583,14 @@ def test_arbitrary_clip_lengths(cd, tol, T, B):
     assert err < (1e-3 if cd == "fp32" else 0.025), err
     if cd == "fp32":
         assert fa.unexplained == 0, fa.summary()
-    ref_grads = dict(oracle.named_parameters())
-    gmax = max(float(q.grad.abs().max()) for q in ref_grads.values() if q.grad is not None)
-    bad, dots, WORST = [], [0.0, 0.0, 0.0], [0.0]
-    for n, p in model.named_parameters():
-        r = ref_grads[n].grad
-        assert (r is None) == (p.grad is None), n
-        if r is None:
-            continue
-        g = p.grad.detach().double().cpu()
-        e = float((g - r.double()).abs().max() / max(float(r.abs().max()), (1e-3 if cd == "fp32" else 0.05) * gmax))
-        WORST[0] = max(WORST[0], e)
-        dots[0] += float((g * r.double()).sum()); dots[1] += float((g * g).sum()); dots[2] += float((r.double() ** 2).sum())
-        if not e < tol:
-            bad.append((e, n))
-    cosine = dots[0] / (dots[1] ** 0.5 * dots[2] ** 0.5)
-    print(f"[clip length T={T} B={B}, {cd}] forward err {err:.3e}, gradient cosine {cosine:.6f}, worst per-tensor error {WORST[0]:.3e}")
-    assert cosine > (0.999999 if cd == "fp32" else 0.9995), cosine
-    assert not bad, sorted(bad, reverse=True)[:8]
+    rep = compare_grads(model, oracle, cd)
+    assert not rep["none_mismatch"], rep["none_mismatch"]
+    print(f"[clip length T={T} B={B}, {cd}] forward err {err:.3e}, gradient cosine {rep['cosine']:.6f}, worst per-tensor error {rep['worst']:.3e} ({rep['worst_name']}), "
+          f"pooled cosine of the tensors below 256 elements {rep['pooled_small_cosine']:.5f}")
+    assert rep["cosine"] > (0.999999 if cd == "fp32" else 0.9995), rep["cosine"]
+    assert rep["pooled_small_cosine"] > 0.99, rep["pooled_small_cosine"]
+    bad = sorted(((v, k) for k, v in rep["errors"].items() if not v < tol), reverse=True)
+    assert not bad, bad[:8]
     model.eval()
     with torch.no_grad():
         assert torch.isfinite(model(x.cuda())).all()

@@ -21,7 +21,7 @@ for rep in range(2):
         out, ws, flags = model._launch_forward(x, False, keep=True)
     dp = torch.empty_like(out); scratch = torch.empty(4 + 4 * 16, device="cuda")
     import ctypes as C
-    _lib.check(model._lib.kasf_loss3(out.data_ptr(), y.data_ptr(), dp.data_ptr(), scratch.data_ptr(), 16, 27, 0.5, 20.0, 1.0, model._stream()))
+    _lib.check(model._lib.kasf_loss3(out.data_ptr(), y.data_ptr(), dp.data_ptr(), scratch.data_ptr(), scratch.numel(), 16, 27, 0.5, 20.0, 1.0, model._stream()))
     model._launch_backward(ws, dp, 16, flags)
     torch.cuda.synchronize()
     snaps.append({n: ws_tensor(model, ws, 16, n, flags=_lib.FLAG_TRAIN).clone() for n in names})
