@@ -98,7 +98,40 @@ def run(model, x, y, masks, record):
     return pred.detach(), torch.cat([p.grad.flatten() for p in model.parameters() if p.grad is not None]).double()
 
 
+def emulate_samples(samples, L=26):
+    """Round 4: today's bf16 mode (O + S + GS) EMULATED on the CPU oracle for each (input seed, weight salt) sample of
+    tests/test_gpu_model.py::test_full_depth_26_layers_against_oracle -- what bf16 arithmetic alone does to each sample, no HIP kernel involved.
+    Prints one JSON list (committed as tests/golden/bf16_emulation_26layers.json; the GPU test judges the HIP path against it sample by sample)."""
+    import json
+    out = []
+    for seed, salt in samples:
+        torch.manual_seed(0)
+        model = O.KASportsFormerOracle(n_layers=L, num_heads=8, n_frames=27)
+        sd = O.name_seeded_fill(model.state_dict(), salt)
+        model.load_state_dict(sd)
+        model.train()
+        add_operand_hooks(model)
+        x, y = O.synthetic_clips(2, 27, seed=seed)
+        masks = []
+        for k in FLAGS:
+            FLAGS[k] = False
+        ref, gref = run(model, x, y, masks, True)
+        sd_bf = {k: (v.bfloat16().float() if (v.dtype == torch.float32 and v.dim() == 2 and "layers_with_bone" in k and "fusion" not in k) else v) for k, v in sd.items()}
+        for k in FLAGS:
+            FLAGS[k] = True
+        model.load_state_dict(sd_bf)
+        pred, g = run(model, x, y, masks, False)
+        err = float((pred - ref).abs().max() / max(1.0, float(ref.abs().max())))
+        cos = float((g * gref).sum() / (g.norm() * gref.norm()))
+        out.append({"seed": seed, "salt": salt, "forward_rel_err": err, "gradient_cosine": cos})
+        print(f"# emulated bf16 mode, input seed {seed}, weight salt {salt}: forward err {err:.3e}, gradient cosine {cos:.4f}", file=sys.stderr, flush=True)
+    print(json.dumps({"what": "O+S+GS bf16 emulation on the CPU oracle (tests/studies/mixed_precision_study.py samples), 26 layers, B = 2, fp32 run's neighbour decisions forced",
+                      "samples": out}, indent=1))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "samples":
+        return emulate_samples([(5, 0), (6, 1001), (7, 2002), (8, 3003), (9, 4004), (10, 5005)])
     L = int(sys.argv[1]) if len(sys.argv) > 1 else 26
     torch.manual_seed(0)
     model = O.KASportsFormerOracle(n_layers=L, num_heads=8, n_frames=27)

@@ -52,6 +52,19 @@ template <int CASE> __global__ void probe(float* out, long long* cyc) {
 #define H8(A) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %5, %6, %0\n v_fma_f32 %1, %1, %7, %8\n v_fma_f32 %2, %2, %7, %8\n v_fma_f32 %3, %3, %7, %8\n v_fma_f32 %4, %4, %7, %8\n v_fma_f32 %1, %1, %7, %8\n v_fma_f32 %2, %2, %7, %8\n v_fma_f32 %3, %3, %7, %8" : "+v"(A), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(fa), "v"(fb), "v"(k), "v"(c));
             H8(acc) H8(acc1) H8(acc) H8(acc1) H8(acc) H8(acc1) H8(acc) H8(acc1)
         }
+        if (CASE >= 15 && CASE <= 18) {   // round 4: waves 0-3 MFMA only (one per SIMD); EVERY other wave of the workgroup (2 or 3 more per SIMD) plain or packed fp32,
+                                          // three times the instruction count each: how much vector issue is left beside a saturated matrix stream?
+            if ((threadIdx.x >> 8) == 0) {
+                R16(asm volatile("v_mfma_f32_16x16x32_bf16 %0, %2, %3, %0\n v_mfma_f32_16x16x32_bf16 %1, %2, %3, %1\n v_mfma_f32_16x16x32_bf16 %0, %2, %3, %0\n v_mfma_f32_16x16x32_bf16 %1, %2, %3, %1" : "+v"(acc), "+v"(acc1) : "v"(fa), "v"(fb));)
+            } else if (CASE == 15 || CASE == 17) {
+                for (int rr = 0; rr < 3; ++rr) { R16(asm volatile("v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(k), "v"(c));) }
+            } else {
+                for (int rr = 0; rr < 3; ++rr) { R16(asm volatile("v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %1, %1, %4, %5\n v_pk_fma_f32 %2, %2, %4, %5\n v_pk_fma_f32 %3, %3, %4, %5" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pk), "v"(pc));) }
+            }
+        }
+        if (CASE == 19) {   // the vector side of cases 15 / 17 alone (no MFMA wave): 3 x the instructions per wave
+            for (int rr = 0; rr < 3; ++rr) { R16(asm volatile("v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(k), "v"(c));) }
+        }
         if (CASE == 11) { R16(asm volatile("v_pk_mul_f32 %0, %0, %4\n v_pk_add_f32 %1, %1, %5\n v_pk_mul_f32 %2, %2, %4\n v_pk_add_f32 %3, %3, %5" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pk), "v"(pc));) }
     }
     const long long t1 = clock64();
@@ -99,5 +112,13 @@ int main(int argc, char** argv) {
     run<12>("waves 0-3 mfma | waves 4-7 pk_fma", 512, out, cyc);
     run<13>("waves 0-3 mfma | waves 4-7 fma", 512, out, cyc);
     BOTH(14, "1 mfma : 7 fma")
+    // round 4: vector issue beside a saturated MFMA wave.  "ns/instr/SIMD" of these rows is per instruction of ALL waves; read the wall time:
+    // MFMA wave alone 0.945 ms (row 'mfma only', 256 threads); vector waves alone: rows 'fma x3 alone'
+    run<19>("fma x3 alone, 2 waves/SIMD", 512, out, cyc);
+    run<19>("fma x3 alone, 3 waves/SIMD", 768, out, cyc);
+    run<15>("w0-3 mfma | 2 waves/SIMD fma x3", 768, out, cyc);
+    run<17>("w0-3 mfma | 3 waves/SIMD fma x3", 1024, out, cyc);
+    run<16>("w0-3 mfma | 2 waves/SIMD pk_fma x3", 768, out, cyc);
+    run<18>("w0-3 mfma | 3 waves/SIMD pk_fma x3", 1024, out, cyc);
     return 0;
 }
