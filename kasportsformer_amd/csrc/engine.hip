@@ -2,6 +2,7 @@
 // workspace plan and the forward / backward launch sequences of the KASportsFormer path
 // (reference: model/KASportsFormer.py:204-347).  Pure launch code: no allocation, no synchronisation.
 #include <atomic>
+#include <mutex>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -536,10 +537,24 @@ int kasf_model_create(const kasf_config* cfg, kasf_model** out) {
     HIPCHK(hipMemcpy(m->d_pack, m->pack.data(), m->pack.size() * sizeof(KasfPackDesc), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(m->d_tile_start, m->pack_tile_start.data(), m->pack_tile_start.size() * sizeof(int), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(m->d_pro, &m->pro, sizeof(KasfProOff), hipMemcpyHostToDevice));
-    for (int i = 0; i < 2; ++i) {
-        HIPCHK(hipStreamCreateWithFlags(&m->side[i], hipStreamNonBlocking));
-        HIPCHK(hipEventCreateWithFlags(&m->ev_join[i], hipEventDisableTiming));
+    // The two side streams are PROCESS-WIDE, one pair per device, created with the first model and never destroyed: every model of the process forks its
+    // branches onto the same pair (events order the work, so models may share them).  Round 3 gave every model a pair of its own -- and the SECOND model of
+    // a process then ran its step at 25-26 ms where the first ran at 15.8 (T = 27, B = 32; slower than with all three branches on ONE stream, 19.7), the
+    // third at 15.8 again, the fourth at 18.4: which hardware queues a new stream lands on next to the existing ones decides how well three streams
+    // overlap, and only the first pair was reliably lucky (tools/dp_probe2.py scenarios A / F / G; profiles/r4_stream_placement.jsonl).
+    static hipStream_t shared_side[64][2] = {};
+    static std::mutex shared_side_mutex;
+    {
+        std::lock_guard<std::mutex> lock(shared_side_mutex);
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev < 0 || dev >= 64) dev = 0;
+        for (int i = 0; i < 2; ++i) {
+            if (shared_side[dev][i] == nullptr) HIPCHK(hipStreamCreateWithFlags(&shared_side[dev][i], hipStreamNonBlocking));
+            m->side[i] = shared_side[dev][i];
+        }
     }
+    for (int i = 0; i < 2; ++i) HIPCHK(hipEventCreateWithFlags(&m->ev_join[i], hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
     kasf_gcn_init();
     *out = m;
@@ -563,7 +578,6 @@ void kasf_model_destroy(kasf_model* m) {
     if (m->d_pro) (void)hipFree(m->d_pro);
     if (m->d_err) (void)hipFree(m->d_err);
     for (int i = 0; i < 2; ++i) {
-        if (m->side[i]) (void)hipStreamDestroy(m->side[i]);
         if (m->ev_join[i]) (void)hipEventDestroy(m->ev_join[i]);
     }
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);

@@ -803,7 +803,9 @@ void agg_fwd_T(hipStream_t s, const void* uv, const void* xn, void* y, uint32_t*
         if (grid > 1024) grid = 1024;                    // every workgroup ends with 34 same-address fp64 atomics
         hipLaunchKernelGGL(k_gcn_agg_spatial<T>, dim3(grid), dim3(256), 0, s, (const T*)uv, (T*)y, stats, M);
     } else if (Tn == 27) agg_temporal_TL<T, 27>(s, uv, xn, y, mask, stats, B, Tn, kth);
+#ifndef KASF_AGG81_G
     else if (Tn == 81) agg_temporal_TL<T, 81>(s, uv, xn, y, mask, stats, B, Tn, kth);
+#endif
     else if (Tn == 9) agg_temporal_TL<T, 9>(s, uv, xn, y, mask, stats, B, Tn, kth);
     else {
         const int LP = (Tn + 15) / 16 * 16, MW = kasf_gcn_mask_words(Tn);

@@ -73,5 +73,17 @@ elif scen == "E":        # process group first, then DataParallel straight away 
     pg()
     a = make(32); dp = K.DataParallel(a[0], optimizer=a[1]); timeit("DataParallel B=32 (first thing after init)", *a, dp=dp)
     timeit("DataParallel B=32 again", *a, dp=dp)
+elif scen == "F":        # is it the process or the model?  model 1 timed, model 2 created, model 1 timed AGAIN, model 2 timed, model 2 on one stream
+    a = make(); timeit("plain, model 1", *a)
+    b = make()
+    timeit("plain, model 1 again (model 2 exists now)", *a)
+    timeit("plain, model 2", *b)
+    K.set_single_stream(True); timeit("model 2, three branches on ONE stream", *b); timeit("model 1, ONE stream", *a); K.set_single_stream(False)
+    timeit("plain, model 1 once more", *a)
+elif scen == "G":        # third and fourth model, each created with all earlier ones alive
+    ms = []
+    for i in range(4):
+        ms.append(make()); timeit(f"plain, model {i + 1} ({i} earlier models alive)", *ms[-1])
+    timeit("plain, model 1 at the end", *ms[0])
 if dist.is_initialized():
     dist.destroy_process_group()
