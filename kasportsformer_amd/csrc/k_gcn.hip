@@ -84,6 +84,25 @@ __global__ __launch_bounds__(256) void k_gcn_agg_spatial(const T* __restrict__ u
 // fp32 mode: the exact v_mfma_f32_16x16x4_f32 chain).  Both operands are the SAME rows in the same k order, so S is bitwise symmetric.
 // BatchNorm sums are kept in LDS across all tracks of the workgroup and leave it as ONE fp64 atomic per frame at the end.
 template <int L> constexpr int agg_lp() { return (L + 15) / 16 * 16; }
+// raw 8-element (one thread's chunk of a U row) register images: kept as loaded, widened at the point of use (a track's U rows are loaded a whole
+// track ahead; as fp32 they would hold 8 VGPRs per item instead of 4)
+template <typename T> struct Raw8;
+template <> struct Raw8<bf16> {
+    bf16x8 v;          // (typed, widened element by element like load8: a __builtin_bit_cast of the words of an f32x4 image was compiled into eight copies of word 0)
+    __device__ __forceinline__ void load(const bf16* p) { v = *reinterpret_cast<const bf16x8*>(p); }
+    __device__ __forceinline__ void get(float (&o)[8]) const {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = (float)v[k];
+    }
+};
+template <> struct Raw8<float> {
+    f32x4 a, b;
+    __device__ __forceinline__ void load(const float* p) { a = *reinterpret_cast<const f32x4*>(p); b = *reinterpret_cast<const f32x4*>(p + 4); }
+    __device__ __forceinline__ void get(float (&o)[8]) const {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { o[k] = a[k]; o[4 + k] = b[k]; }
+    }
+};
 template <typename T, int L>
 __global__ __launch_bounds__(256) void k_gcn_agg_temporal(const T* __restrict__ uv, const T* __restrict__ xn, T* __restrict__ y,
                                                           uint32_t* __restrict__ mask, double* __restrict__ stats, int Tn, int kth, int n_tracks) {
@@ -103,15 +122,16 @@ __global__ __launch_bounds__(256) void k_gcn_agg_temporal(const T* __restrict__ 
         else { float z4[4] = {0.f, 0.f, 0.f, 0.f}; store4(sX + Tile<float>::chunk_off(r, ch), z4); }
     }
     if (threadIdx.x < 2 * L) sStat[threadIdx.x] = 0.f;
-    for (int G = blockIdx.x; G < n_tracks; G += gridDim.x) {
+    // ALL global reads of a track -- the LN(x) and V chunks (raw 16-byte copies, no conversion on the way in) and the U chunks the aggregation adds at the
+    // very end -- are issued ONE TRACK AHEAD (round 4): the loads of track n + 1 go out as soon as track n's images are in LDS and land under its similarity,
+    // top-4 and aggregation phases.  (Round 2 issued them at the top of their own track: one exposed HBM round trip per track, 55 % of the wave-cycles of the
+    // T = 81 launch spent waiting.)
+    constexpr int NI = (L * CPR + 255) / 256, NI4 = (L * 16 + 255) / 256;
+    f32x4 rx[NI], rv[NI];
+    Raw8<T> ru[NI4], ru_next[NI4];
+    auto fetch = [&](int G) {
         const int b = G / KASF_J, j = G % KASF_J;
         auto tok = [&](int r) { return ((int64_t)b * Tn + r) * KASF_J + j; };
-        // ALL global reads of the track are issued here, before anything waits: the LN(x) and V chunks (raw 16-byte copies, no conversion on the way in)
-        // and the U chunks the aggregation adds at the very end.  (A load-store loop and a U load behind each item's gather made up to a dozen
-        // dependent HBM round trips per track.)
-        constexpr int NI = (L * CPR + 255) / 256, NI4 = (L * 16 + 255) / 256;
-        f32x4 rx[NI], rv[NI];
-        float ru[NI4][8];
 #pragma unroll
         for (int k = 0; k < NI; ++k) {
             const int idx = threadIdx.x + 256 * k;
@@ -124,8 +144,13 @@ __global__ __launch_bounds__(256) void k_gcn_agg_temporal(const T* __restrict__ 
 #pragma unroll
         for (int k = 0; k < NI4; ++k) {
             const int idx = threadIdx.x + 256 * k;
-            if (idx < L * 16) load8(uv + tok(idx >> 4) * 256 + (idx & 15) * 8, ru[k]);
+            if (idx < L * 16) ru_next[k].load(uv + tok(idx >> 4) * 256 + (idx & 15) * 8);
         }
+    };
+    if ((int)blockIdx.x < n_tracks) fetch(blockIdx.x);
+    for (int G = blockIdx.x; G < n_tracks; G += gridDim.x) {
+        const int b = G / KASF_J, j = G % KASF_J;
+        auto tok = [&](int r) { return ((int64_t)b * Tn + r) * KASF_J + j; };
         __syncthreads();                                // previous track fully consumed (and the zero fill / sStat init visible)
 #pragma unroll
         for (int k = 0; k < NI; ++k) {
@@ -136,6 +161,9 @@ __global__ __launch_bounds__(256) void k_gcn_agg_temporal(const T* __restrict__ 
                 *reinterpret_cast<f32x4*>(sV + r * 128 + ch * EPC) = rv[k];
             }
         }
+#pragma unroll
+        for (int k = 0; k < NI4; ++k) ru[k] = ru_next[k];
+        if (G + (int)gridDim.x < n_tracks) fetch(G + gridDim.x);
         __syncthreads();
         for (int t = w; t < NTL * NTL; t += 4) {        // 16x16 tiles of S over the 4 waves
             const int tn = t / NTL, tm = t % NTL;
@@ -152,16 +180,18 @@ __global__ __launch_bounds__(256) void k_gcn_agg_temporal(const T* __restrict__ 
             }
         }
         __syncthreads();
-        // k-th largest per row -> adjacency bits and degree (graph.py:104-112: ties kept).  FOUR lanes per row, columns interleaved (c = j mod 4): each keeps
-        // the four largest of its columns (with multiplicity), two butterfly merges leave the row's four largest in every lane of the quad, each lane then
-        // sets the mask bits of its own columns and the words are OR-ed across the quad.  (One lane per row left 81 of 256 threads scanning 81 columns
-        // twice -- a fifth of the launch at T = 81 -- and the rest idle.)
-        for (int r0 = 0; r0 < L; r0 += 64) {
-            const int r = r0 + (threadIdx.x >> 2), j = threadIdx.x & 3;
-            const bool live = r < L;
+        // k-th largest per row -> adjacency bits and degree (graph.py:104-112: ties kept).  NL lanes per row, columns interleaved (c = j mod NL): each keeps
+        // the four largest of its columns (with multiplicity), merges with the row's other lanes, then sets the mask bits of its own columns; the words are
+        // OR-ed across the row's lanes.  A wave holds RW = 64 / NL whole rows and the four waves cover all L rows in ONE pass whenever 4 RW >= L (T = 81:
+        // three lanes per row, 21 rows per wave; round 2's four lanes per row needed a second pass in which 17 of 64 row slots were live).
+        constexpr int NL = L <= 64 ? 4 : (L <= 84 ? 3 : 4), RW = 64 / NL;
+        for (int r0 = 0; r0 < L; r0 += 4 * RW) {
+            const int slot = lane / NL, j = lane - slot * NL, base = slot * NL;
+            const int r = r0 + w * RW + slot;
+            const bool live = slot < RW && r < L;
             float top[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
             if (live) {
-                for (int c = j; c < L; c += 4) {
+                for (int c = j; c < L; c += NL) {
                     float v = sS[r * (LP + 1) + c];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {          // compare-exchange as max / min (S is finite): two instructions per level
@@ -171,19 +201,38 @@ __global__ __launch_bounds__(256) void k_gcn_agg_temporal(const T* __restrict__ 
                     }
                 }
             }
+            if constexpr (NL == 4) {                         // butterfly: after each step both partners hold the merged four
 #pragma unroll
-            for (int m = 1; m <= 2; m <<= 1) {               // merge with the partner's sorted four (all lanes of the wave take part in the shuffles)
-                float o[4];
+                for (int m = 1; m <= 2; m <<= 1) {
+                    float o[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = __shfl_xor(top[e], m);
+                    for (int e = 0; e < 4; ++e) o[e] = __shfl_xor(top[e], m);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float v = o[q];
+                    for (int q = 0; q < 4; ++q) {
+                        float v = o[q];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float hi = fmaxf(top[e], v);
-                        v = fminf(top[e], v);
-                        top[e] = hi;
+                        for (int e = 0; e < 4; ++e) {
+                            const float hi = fmaxf(top[e], v);
+                            v = fminf(top[e], v);
+                            top[e] = hi;
+                        }
+                    }
+                }
+            } else {                                         // three lanes per row: every lane inserts the ORIGINAL fours of the other two, each exactly once
+                const float own[4] = {top[0], top[1], top[2], top[3]};
+#pragma unroll
+                for (int m = 1; m < NL; ++m) {
+                    int src = j + m;
+                    src = base + (src >= NL ? src - NL : src);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float v = __shfl(own[q], src);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float hi = fmaxf(top[e], v);
+                            v = fminf(top[e], v);
+                            top[e] = hi;
+                        }
                     }
                 }
             }
@@ -191,20 +240,24 @@ __global__ __launch_bounds__(256) void k_gcn_agg_temporal(const T* __restrict__ 
             uint32_t wd[MASK_W] = {0u, 0u, 0u};
             int deg = 0;
             if (live) {
-                for (int c = j; c < L; c += 4) {
+                for (int c = j; c < L; c += NL) {
                     if (sS[r * (LP + 1) + c] >= thr) { wd[c >> 5] |= 1u << (c & 31); ++deg; }
                 }
             }
+            uint32_t wo[MASK_W] = {wd[0], wd[1], wd[2]};
+            int dsum = deg;
 #pragma unroll
-            for (int m = 1; m <= 2; m <<= 1) {
+            for (int m = 1; m < NL; ++m) {
+                int src = j + m;
+                src = base + (src >= NL ? src - NL : src);
 #pragma unroll
-                for (int e = 0; e < MASK_W; ++e) wd[e] |= (uint32_t)__shfl_xor((int)wd[e], m);
-                deg += __shfl_xor(deg, m);
+                for (int e = 0; e < MASK_W; ++e) wo[e] |= (uint32_t)__shfl((int)wd[e], src);
+                dsum += __shfl(deg, src);
             }
             if (live && j == 0) {
 #pragma unroll
-                for (int e = 0; e < MASK_W; ++e) { sMask[r * MASK_W + e] = wd[e]; mask[((int64_t)G * L + r) * MASK_W + e] = wd[e]; }
-                sDinv[r] = 1.0f / sqrtf((float)deg);
+                for (int e = 0; e < MASK_W; ++e) { sMask[r * MASK_W + e] = wo[e]; mask[((int64_t)G * L + r) * MASK_W + e] = wo[e]; }
+                sDinv[r] = 1.0f / sqrtf((float)dsum);
             }
         }
         __syncthreads();
@@ -217,6 +270,8 @@ __global__ __launch_bounds__(256) void k_gcn_agg_temporal(const T* __restrict__ 
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[e] = 0.f;
             const float dr = sDinv[r];
+            // (tried in round 4: requesting the next neighbour's V chunk and degree one visit ahead -- 117 against 85 us at T = 81: the data-dependent
+            //  trip count turns the hand-pipelined form into more branches, not fewer waits)
 #pragma unroll
             for (int wi = 0; wi < (L + 31) / 32; ++wi) {
                 uint32_t bits = sMask[r * MASK_W + wi];
@@ -230,9 +285,10 @@ __global__ __launch_bounds__(256) void k_gcn_agg_temporal(const T* __restrict__ 
                     for (int e = 0; e < 8; ++e) acc[e] += wgt * v[e];
                 }
             }
-            float s1 = 0.f, s2 = 0.f;
+            float s1 = 0.f, s2 = 0.f, u[8];
+            ru[k4].get(u);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { acc[e] += ru[k4][e]; const float q = to_f(from_f<T>(acc[e])); s1 += q; s2 += q * q; }
+            for (int e = 0; e < 8; ++e) { acc[e] += u[e]; const float q = to_f(from_f<T>(acc[e])); s1 += q; s2 += q * q; }
             store8(y + tok(r) * 128 + sub * 8, acc);
             s1 = reduce16(s1);
             s2 = reduce16(s2);

@@ -111,6 +111,7 @@ if __name__ == "__main__":
     elif what == "train27fp32":          # the parity mode (exact-f32 MFMA), same workload: the mode the <= 1e-3 / 0.1 mm claims are made in
         train(27, 256, steps=5, warmup=1, cd="fp32")
     elif what == "small":                # the per-rank regime of BASELINE configs[2]: 256 clips over 8 replicas = 32 per rank (64 at 4 ranks), detector-confidence input
+        _single_rank_rccl()             # the process group first, as every multi-rank run has it (bench.py --gpus N): RCCL's streams exist before the engine's
         for B in (32, 64):
             train(27, B, steps=10, warmup=3, det_conf=True)
         for B in (32, 64):
