@@ -103,15 +103,21 @@ template <> struct Raw8<float> {
         for (int k = 0; k < 4; ++k) { o[k] = a[k]; o[4 + k] = b[k]; }
     }
 };
+// LDS: the similarity matrix and the V rows are never live together (S dies with the top-4 scan, V is first read by the aggregation), so they share one
+// region: 24.5 + 26.6 + 2 KB at T = 81 in bf16 -- THREE workgroups per CU where round 3's 78 KB allowed two (55 % of that launch's wave-cycles were waits).
+template <int L> constexpr int agg_ss_ld() { return (L | 1) + 1 + ((((L | 1) + 1) % 32 == 0) ? 2 : 0); }     // row stride of S in floats: >= L, even, not a multiple of 32
+template <typename T, int L> constexpr size_t agg_region2() {
+    return (size_t)L * agg_ss_ld<L>() * sizeof(float) > (size_t)L * 128 * sizeof(T) ? (size_t)L * agg_ss_ld<L>() * sizeof(float) : (size_t)L * 128 * sizeof(T);
+}
 template <typename T, int L>
-__global__ __launch_bounds__(256) void k_gcn_agg_temporal(const T* __restrict__ uv, const T* __restrict__ xn, T* __restrict__ y,
+__global__ __launch_bounds__(256, (sizeof(T) == 2 && L == 81) ? 3 : 1) void k_gcn_agg_temporal(const T* __restrict__ uv, const T* __restrict__ xn, T* __restrict__ y,
                                                           uint32_t* __restrict__ mask, double* __restrict__ stats, int Tn, int kth, int n_tracks) {
-    constexpr int LP = agg_lp<L>(), NTL = LP / 16, EPC = Tile<T>::EPC, CPR = Tile<T>::CPR;
+    constexpr int LP = agg_lp<L>(), NTL = LP / 16, EPC = Tile<T>::EPC, CPR = Tile<T>::CPR, SS = agg_ss_ld<L>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* sX = reinterpret_cast<T*>(smem);                 // [LP][128] swizzled tile, LN(x) rows of the track (rows >= L stay zero)
-    T* sV = sX + LP * 128;                              // [L][128]  V rows
-    float* sS = reinterpret_cast<float*>(sV + L * 128); // [L][LP+1] similarity
-    float* sDinv = sS + L * (LP + 1);                   // [L]
+    T* sV = sX + LP * 128;                              // [L][128]  V rows        } one region: S until the scan is done,
+    float* sS = reinterpret_cast<float*>(sV);           // [L][SS]   similarity    } V from then on
+    float* sDinv = reinterpret_cast<float*>(reinterpret_cast<char*>(sV) + agg_region2<T, L>());   // [L]
     float* sStat = sDinv + L;                           // [L][2]    running BatchNorm sums of this workgroup
     uint32_t* sMask = reinterpret_cast<uint32_t*>(sStat + 2 * L);   // [L][MASK_W]
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
@@ -122,13 +128,12 @@ __global__ __launch_bounds__(256) void k_gcn_agg_temporal(const T* __restrict__ 
         else { float z4[4] = {0.f, 0.f, 0.f, 0.f}; store4(sX + Tile<float>::chunk_off(r, ch), z4); }
     }
     if (threadIdx.x < 2 * L) sStat[threadIdx.x] = 0.f;
-    // ALL global reads of a track -- the LN(x) and V chunks (raw 16-byte copies, no conversion on the way in) and the U chunks the aggregation adds at the
-    // very end -- are issued ONE TRACK AHEAD (round 4): the loads of track n + 1 go out as soon as track n's images are in LDS and land under its similarity,
-    // top-4 and aggregation phases.  (Round 2 issued them at the top of their own track: one exposed HBM round trip per track, 55 % of the wave-cycles of the
-    // T = 81 launch spent waiting.)
+    // The LN(x) and V chunks of a track (raw 16-byte copies, no conversion on the way in) are requested ONE TRACK AHEAD (round 4): the loads of track n + 1
+    // go out as soon as track n's V image is in LDS and land under its aggregation and the next track's ... nothing waits for them at the top of a track.
+    // (Round 2 issued them at the top of their own track: one exposed HBM round trip per track, 55 % of the wave-cycles of the T = 81 launch spent waiting.)
     constexpr int NI = (L * CPR + 255) / 256, NI4 = (L * 16 + 255) / 256;
     f32x4 rx[NI], rv[NI];
-    Raw8<T> ru[NI4], ru_next[NI4];
+    Raw8<T> ru[NI4];
     auto fetch = [&](int G) {
         const int b = G / KASF_J, j = G % KASF_J;
         auto tok = [&](int r) { return ((int64_t)b * Tn + r) * KASF_J + j; };
@@ -141,10 +146,15 @@ __global__ __launch_bounds__(256) void k_gcn_agg_temporal(const T* __restrict__ 
                 rv[k] = *reinterpret_cast<const f32x4*>(uv + tok(r) * 256 + 128 + ch * EPC);
             }
         }
+    };
+    // the U chunks are only needed by the aggregation at the END of their own track: requested at its top (two phases of cover), not a track ahead
+    // (a second register image of them is what made the T = 81 kernel spill at three workgroups per CU)
+    auto fetch_u = [&](int G) {
+        const int b = G / KASF_J, j = G % KASF_J;
 #pragma unroll
         for (int k = 0; k < NI4; ++k) {
             const int idx = threadIdx.x + 256 * k;
-            if (idx < L * 16) ru_next[k].load(uv + tok(idx >> 4) * 256 + (idx & 15) * 8);
+            if (idx < L * 16) ru[k].load(uv + (((int64_t)b * Tn + (idx >> 4)) * KASF_J + j) * 256 + (idx & 15) * 8);
         }
     };
     if ((int)blockIdx.x < n_tracks) fetch(blockIdx.x);
@@ -158,12 +168,9 @@ __global__ __launch_bounds__(256) void k_gcn_agg_temporal(const T* __restrict__ 
             if (idx < L * CPR) {
                 const int r = idx / CPR, ch = idx % CPR;
                 *reinterpret_cast<f32x4*>(sX + Tile<T>::chunk_off(r, ch)) = rx[k];
-                *reinterpret_cast<f32x4*>(sV + r * 128 + ch * EPC) = rv[k];
             }
         }
-#pragma unroll
-        for (int k = 0; k < NI4; ++k) ru[k] = ru_next[k];
-        if (G + (int)gridDim.x < n_tracks) fetch(G + gridDim.x);
+        fetch_u(G);
         __syncthreads();
         for (int t = w; t < NTL * NTL; t += 4) {        // 16x16 tiles of S over the 4 waves
             const int tn = t / NTL, tm = t % NTL;
@@ -175,7 +182,7 @@ __global__ __launch_bounds__(256) void k_gcn_agg_temporal(const T* __restrict__ 
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int c = tn * 16 + 4 * lg + q;
-                    if (c < L) sS[r * (LP + 1) + c] = acc[0][0][q];
+                    if (c < L) sS[r * SS + c] = acc[0][0][q];
                 }
             }
         }
@@ -192,7 +199,7 @@ __global__ __launch_bounds__(256) void k_gcn_agg_temporal(const T* __restrict__ 
             float top[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
             if (live) {
                 for (int c = j; c < L; c += NL) {
-                    float v = sS[r * (LP + 1) + c];
+                    float v = sS[r * SS + c];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {          // compare-exchange as max / min (S is finite): two instructions per level
                         const float hi = fmaxf(top[e], v);
@@ -241,7 +248,7 @@ __global__ __launch_bounds__(256) void k_gcn_agg_temporal(const T* __restrict__ 
             int deg = 0;
             if (live) {
                 for (int c = j; c < L; c += NL) {
-                    if (sS[r * (LP + 1) + c] >= thr) { wd[c >> 5] |= 1u << (c & 31); ++deg; }
+                    if (sS[r * SS + c] >= thr) { wd[c >> 5] |= 1u << (c & 31); ++deg; }
                 }
             }
             uint32_t wo[MASK_W] = {wd[0], wd[1], wd[2]};
@@ -260,6 +267,13 @@ __global__ __launch_bounds__(256) void k_gcn_agg_temporal(const T* __restrict__ 
                 sDinv[r] = 1.0f / sqrtf((float)dsum);
             }
         }
+        __syncthreads();                                // the scan is done with S: its region takes the V rows now, and the NEXT track's loads go out
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            const int idx = threadIdx.x + 256 * k;
+            if (idx < L * CPR) *reinterpret_cast<f32x4*>(sV + (idx / CPR) * 128 + (idx % CPR) * EPC) = rv[k];
+        }
+        if (G + (int)gridDim.x < n_tracks) fetch(G + gridDim.x);
         __syncthreads();
 #pragma unroll
         for (int k4 = 0; k4 < NI4; ++k4) {
@@ -827,7 +841,7 @@ template <typename K> void set_smem(K k, size_t bytes) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 template <typename T, int L> constexpr size_t agg_smem() {
-    return (size_t)(agg_lp<L>() + L) * 128 * sizeof(T) + (L * (agg_lp<L>() + 1) + L + 2 * L) * sizeof(float) + L * MASK_W * sizeof(uint32_t);
+    return (size_t)agg_lp<L>() * 128 * sizeof(T) + agg_region2<T, L>() + (L + 2 * L) * sizeof(float) + L * MASK_W * sizeof(uint32_t);
 }
 template <int L> constexpr size_t bwd2_smem() { return (L * SX_LD + L) * sizeof(float) + 2 * L * MASK_W * sizeof(uint32_t); }
 
