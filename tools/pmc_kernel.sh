@@ -10,11 +10,19 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "
   timeout -k 10 200 rocprofv3 --pmc $set --kernel-trace --kernel-include-regex "$RX" -d $O/p$i -o p --output-format csv -- python3 $R/$S $T $B > $O/p$i.log 2>&1 || echo "set $i failed: $(tail -2 $O/p$i.log | head -1)"
 done
 cd $R && python - <<PY
-import collections, csv, glob
-agg = collections.defaultdict(list)
+import collections, csv, glob, re
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob("$O/p*/p_counter_collection.csv")):
     for r in csv.DictReader(open(f)):
-        agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-for k, v in agg.items():
-    print(f"{k:32s} {sum(v)/len(v):16.0f}   (n={len(v)})")
+        m = re.search(r"(k_[a-z0-9_]+)(<[^(]*>)?", r["Kernel_Name"])          # one table per kernel (template arguments kept apart)
+        agg[(m.group(1) + (m.group(2) or "")) if m else r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for kern, cs in agg.items():
+    print(f"== {kern}")
+    for k, v in cs.items():
+        print(f"{k:32s} {sum(v)/len(v):16.0f}   (n={len(v)})")
+    g = lambda n: (sum(cs[n]) / len(cs[n])) if n in cs else 0.0
+    if g("SQ_WAVE_CYCLES") and g("SQ_WAVES"):
+        wc = g("SQ_WAVE_CYCLES")
+        print(f"   per wave: {4 * wc / g('SQ_WAVES'):.0f} cycles, {g('SQ_INSTS_VALU') / g('SQ_WAVES'):.0f} VALU, {g('SQ_INSTS_LDS') / g('SQ_WAVES'):.0f} LDS, {g('SQ_INSTS_MFMA') / g('SQ_WAVES'):.0f} MFMA instructions;"
+              f"  of the wave-cycles: waiting {100 * g('SQ_WAIT_ANY') / wc:.0f} %, issue-stalled {100 * g('SQ_WAIT_INST_ANY') / wc:.0f} %, VALU active {100 * g('SQ_ACTIVE_INST_VALU') / wc:.0f} %")
 PY
