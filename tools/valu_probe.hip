@@ -8,6 +8,7 @@
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int REPS = 2000;
 
 #define R16(x) x x x x x x x x x x x x x x x x
@@ -57,6 +58,29 @@ template <int CASE> __global__ void probe(float* out, long long* cyc) {
             if ((threadIdx.x >> 8) == 0) {
                 R16(asm volatile("v_mfma_f32_16x16x32_bf16 %0, %2, %3, %0\n v_mfma_f32_16x16x32_bf16 %1, %2, %3, %1\n v_mfma_f32_16x16x32_bf16 %0, %2, %3, %0\n v_mfma_f32_16x16x32_bf16 %1, %2, %3, %1" : "+v"(acc), "+v"(acc1) : "v"(fa), "v"(fb));)
             } else if (CASE == 15 || CASE == 17) {
+                for (int rr = 0; rr < 3; ++rr) { R16(asm volatile("v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(k), "v"(c));) }
+            } else {
+                for (int rr = 0; rr < 3; ++rr) { R16(asm volatile("v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %1, %1, %4, %5\n v_pk_fma_f32 %2, %2, %4, %5\n v_pk_fma_f32 %3, %3, %4, %5" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pk), "v"(pc));) }
+            }
+        }
+        if (CASE == 24 || CASE == 25) {   // round 4: does PRIORITY buy the overlap?  MFMA wave at priority 0, vector waves at priority 3 (24) or the reverse (25)
+            if ((threadIdx.x >> 8) == 0) {
+                if (r == 0) { if (CASE == 25) __builtin_amdgcn_s_setprio(3); }
+                R16(asm volatile("v_mfma_f32_16x16x32_bf16 %0, %2, %3, %0\n v_mfma_f32_16x16x32_bf16 %1, %2, %3, %1\n v_mfma_f32_16x16x32_bf16 %0, %2, %3, %0\n v_mfma_f32_16x16x32_bf16 %1, %2, %3, %1" : "+v"(acc), "+v"(acc1) : "v"(fa), "v"(fb));)
+            } else {
+                if (r == 0) { if (CASE == 24) __builtin_amdgcn_s_setprio(3); }
+                for (int rr = 0; rr < 3; ++rr) { R16(asm volatile("v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(k), "v"(c));) }
+            }
+        }
+        if (CASE >= 20 && CASE <= 23) {   // round 4: the same with v_mfma_f32_32x32x16_bf16 (32 cycles in the pipe, vector issue held for 8 of them: 24 free against 8 of 16)
+            static_assert(true, "");
+            if ((threadIdx.x >> 8) == 0 || CASE == 20) {
+                f32x16 c0 = {0}, c1 = {0};
+                for (int q = 0; q < 1; ++q) {
+                    R16(asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, %3, %0\n v_mfma_f32_32x32x16_bf16 %1, %2, %3, %1" : "+v"(c0), "+v"(c1) : "v"(fa), "v"(fb));)
+                }
+                acc[0] += c0[0] + c1[5];
+            } else if (CASE == 21 || CASE == 23) {
                 for (int rr = 0; rr < 3; ++rr) { R16(asm volatile("v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(k), "v"(c));) }
             } else {
                 for (int rr = 0; rr < 3; ++rr) { R16(asm volatile("v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %1, %1, %4, %5\n v_pk_fma_f32 %2, %2, %4, %5\n v_pk_fma_f32 %3, %3, %4, %5" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pk), "v"(pc));) }
@@ -120,5 +144,12 @@ int main(int argc, char** argv) {
     run<17>("w0-3 mfma | 3 waves/SIMD fma x3", 1024, out, cyc);
     run<16>("w0-3 mfma | 2 waves/SIMD pk_fma x3", 768, out, cyc);
     run<18>("w0-3 mfma | 3 waves/SIMD pk_fma x3", 1024, out, cyc);
+    // 32x32x16: per loop iteration 32 MFMAs of 32 cycles = the pipe time of the 64 16x16x32 MFMAs above (same FLOPs)
+    run<20>("mfma 32x32x16 only (32 per rep)", 256, out, cyc);
+    run<21>("w0-3 mfma32 | 2 waves/SIMD fma x3", 768, out, cyc);
+    run<23>("w0-3 mfma32 | 3 waves/SIMD fma x3", 1024, out, cyc);
+    run<22>("w0-3 mfma32 | 2 waves/SIMD pk_fma x3", 768, out, cyc);
+    run<24>("w0-3 mfma prio0 | 2 waves fma x3 PRIO 3", 768, out, cyc);
+    run<25>("w0-3 mfma PRIO 3 | 2 waves fma x3 prio0", 768, out, cyc);
     return 0;
 }
