@@ -424,7 +424,24 @@ __global__ __launch_bounds__(256) void k_wgrad_ring_jobs(const WgJobs js) {
     for (int q = 1; q < 3; ++q)
         if (q < js.n && (int)blockIdx.x >= js.j[q].first) ji = q;
     const WgJob& jb = js.j[ji];
-    const int tiles_k = jb.K / 128, tiles = (jb.N / 128) * tiles_k, rel = blockIdx.x - jb.first, tile = rel % tiles, z = rel / tiles;
+    const int tiles_k = jb.K / 128, tiles = (jb.N / 128) * tiles_k, rel = blockIdx.x - jb.first;
+    // XCD-aware order (round 4; speed only, the partial-tile layout and every result bit are unchanged): workgroups are dealt round-robin to the 8 XCDs, and the
+    // `tiles` workgroups of one token split all stream the SAME X rows (LN(x): the three 128-column tiles of the qkv gradient, the two of kv / U|V).  With the
+    // tile index fastest they sat on consecutive XCDs and each fetched its own copy through the fabric (2,048 B per token moved for 1,536 B of operands);
+    // with blockIdx = first + 8 tiles grp + 8 tile + (z mod 8) they share an XCD and its L2.
+    int tile, z;
+    {
+        const int full = (js.splits / 8) * 8 * tiles;        // workgroups of the complete groups of 8 splits
+        if (rel < full) {
+            const int grp = rel / (8 * tiles), in = rel - grp * 8 * tiles;
+            z = grp * 8 + (in & 7);
+            tile = in >> 3;
+        } else {
+            const int r2 = rel - full, rs = js.splits - (js.splits / 8) * 8;
+            z = (js.splits / 8) * 8 + r2 % rs;
+            tile = r2 / rs;
+        }
+    }
     wgrad_ring_body<bf16>(jb.G, jb.ldg, jb.X, jb.ldx, nullptr, 0, jb.dbias, js.M, js.slice, jb.partial, jb.brow, jb.N, jb.K, (tile / tiles_k) * 128,
                           (tile % tiles_k) * 128, z);
 }
