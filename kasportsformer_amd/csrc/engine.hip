@@ -45,7 +45,9 @@ static bool single_stream() {
     if (v < 0) { v = getenv("KASF_SINGLE_STREAM") != nullptr ? 1 : 0; g_single_stream.store(v, std::memory_order_relaxed); }
     return v != 0;
 }
-constexpr int64_t WG_PARTIAL_FLOATS = KASF_MLP_PARTIAL_FLOATS + 65536;   // per-split weight-gradient tiles (256 workgroups x 128x128, or 64 ranges x (dW1 + dW2) of the MLP) + the per-split rows of a bias gradient
+constexpr int64_t WG_JOBS_FLOATS = 248 * 128 * 128 + 248 * 128 + 4096;   // the proj job alone: 248 splits of one 128 x 128 tile + their bias rows
+constexpr int64_t WG_BF16_BYTES = (int64_t)256 * 384 * 128 * 2;         // <= 256 bf16 partial tiles of the block's fused data + weight gradient launches (qkv: 384 rows; q + kv: 128 + 256)
+constexpr int64_t WG_PARTIAL_FLOATS = (KASF_MLP_PARTIAL_FLOATS + 65536 > WG_JOBS_FLOATS + WG_BF16_BYTES / 4 ? KASF_MLP_PARTIAL_FLOATS + 65536 : WG_JOBS_FLOATS + WG_BF16_BYTES / 4);   // per-split weight-gradient tiles (256 workgroups x 128x128, or 64 ranges x (dW1 + dW2) of the MLP) + the per-split rows of a bias gradient
 
 struct BlkWs { int64_t qkv, kv, o, xn, y, mask, x_mid, xn2, x_out, stats, bstats, coef, lse; };
 struct LayerWs { BlkWs b[6]; int64_t gate_out, alpha; };
@@ -445,8 +447,19 @@ void block_backward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void*
                                                dq + 256 * c.es, 384, c.B, c.T, o.mode, 0, c.w(w.o), w.lse >= 0 ? (const float*)c.w(w.lse) : nullptr);
         else kasf_launch_attn_bwd(c.dt, c.s, q, 384, q + 128 * c.es, q + 256 * c.es, 384, c.w(sc.d_o), dq, 384, dq + 128 * c.es, dq + 256 * c.es, 384, c.B,
                                   c.T, o.mode, heads);
-        kasf_launch_dgrad_lnbwd(c.dt, c.s, dq, 384, c.pk(o.p_mixT), nullptr, x_in, P + o.n1w, g_mid, dst, accumulate, G + o.n1w, G + o.n1b, c.M,
-                                c.w(sc.xn_a), P + o.n1b, c.sink);
+        bool fusedwg = false;
+        KasfBf16Reduce red[2];
+        int nred = 0;
+        char* wpart = (char*)(part + WG_JOBS_FLOATS);      // bf16 partial tiles behind the jobs kernel's own fp32 tiles: both live until the block's finish launch
+        // the qkv weight gradient rides in the data-gradient kernel (its dY tile and LN(x) are in LDS there): no LN(x) round trip, dqkv read once
+        if (jobs) {
+            const int np = kasf_launch_dgrad_wg(c.s, dq, 384, c.pk(o.p_mixT), x_in, P + o.n1w, P + o.n1b, g_mid, dst, accumulate, G + o.n1w, G + o.n1b, c.M, c.sink,
+                                                wpart, WG_BF16_BYTES);
+            if (np > 0) { fusedwg = true; red[nred++] = KasfBf16Reduce{wpart, G + o.mix_w, np, 384 * 128}; }
+        }
+        if (!fusedwg)
+            kasf_launch_dgrad_lnbwd(c.dt, c.s, dq, 384, c.pk(o.p_mixT), nullptr, x_in, P + o.n1w, g_mid, dst, accumulate, G + o.n1w, G + o.n1b, c.M,
+                                    c.w(sc.xn_a), P + o.n1b, c.sink);
         bool done = false;
         if (jobs) {
             const void* Gs[2] = {g_mid, dq};
@@ -454,7 +467,8 @@ void block_backward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void*
             const int Ns[2] = {128, 384};
             float* dWs[2] = {G + o.proj_w, G + o.mix_w};
             float* dbs[2] = {G + o.proj_b, nullptr};
-            done = kasf_launch_wgrad_jobs(c.s, 2, Gs, Xs, Ns, dWs, dbs, 0, P + o.proj_w, P + o.proj_b, P + o.ls1, G + o.ls1, c.M, part, WG_PARTIAL_FLOATS);
+            done = kasf_launch_wgrad_jobs(c.s, fusedwg ? 1 : 2, Gs, Xs, Ns, dWs, dbs, 0, P + o.proj_w, P + o.proj_b, P + o.ls1, G + o.ls1, c.M, part,
+                                          fusedwg ? WG_JOBS_FLOATS : WG_PARTIAL_FLOATS, nred, red);
         }
         if (!done) {
             if (jobs) {
@@ -470,10 +484,28 @@ void block_backward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void*
         if (fdo) kasf_launch_attn_bwd_fused_do(c.s, c.w(w.qkv), 128, kv, kv + 128 * c.es, 256, g_mid, c.pk(o.p_projTs), dq, 128, dkv, dkv + 128 * c.es, 256, c.B,
                                                c.T, o.mode, 0, c.w(w.o), w.lse >= 0 ? (const float*)c.w(w.lse) : nullptr);
         else kasf_launch_attn_bwd(c.dt, c.s, c.w(w.qkv), 128, kv, kv + 128 * c.es, 256, c.w(sc.d_o), dq, 128, dkv, dkv + 128 * c.es, 256, c.B, c.T, o.mode, heads);
-        kasf_launch_dgrad_lnbwd(c.dt, c.s, dq, 128, c.pk(o.p_mixT), nullptr, x_in, P + o.n1w, g_mid, dst, accumulate, G + o.n1w, G + o.n1b, c.M,
-                                c.w(sc.xn_a), P + o.n1b, c.sink);
-        kasf_launch_dgrad_lnbwd(c.dt, c.s, dkv, 256, c.pk(o.p_kvT), nullptr, x_limb, P + o.n1lw, nullptr, c.w(p.g_limb), 1, G + o.n1lw, G + o.n1lb, c.M,
-                                c.w(sc.xn_b), P + o.n1lb, c.sink);
+        bool fusedwg = false;
+        KasfBf16Reduce red[2];
+        int nred = 0;
+        char* wpart = (char*)(part + WG_JOBS_FLOATS);
+        if (jobs) {
+            const int64_t qb = (int64_t)256 * 128 * 128 * 2;
+            const int npq = kasf_launch_dgrad_wg(c.s, dq, 128, c.pk(o.p_mixT), x_in, P + o.n1w, P + o.n1b, g_mid, dst, accumulate, G + o.n1w, G + o.n1b, c.M, c.sink,
+                                                 wpart, qb);
+            const int npk = npq > 0 ? kasf_launch_dgrad_wg(c.s, dkv, 256, c.pk(o.p_kvT), x_limb, P + o.n1lw, P + o.n1lb, nullptr, c.w(p.g_limb), 1, G + o.n1lw,
+                                                           G + o.n1lb, c.M, c.sink, wpart + qb, WG_BF16_BYTES - qb) : 0;
+            if (npq > 0 && npk > 0) {
+                fusedwg = true;
+                red[nred++] = KasfBf16Reduce{wpart, G + o.mix_w, npq, 128 * 128};
+                red[nred++] = KasfBf16Reduce{wpart + qb, G + o.kv_w, npk, 256 * 128};
+            }
+        }
+        if (!fusedwg) {
+            kasf_launch_dgrad_lnbwd(c.dt, c.s, dq, 128, c.pk(o.p_mixT), nullptr, x_in, P + o.n1w, g_mid, dst, accumulate, G + o.n1w, G + o.n1b, c.M,
+                                    c.w(sc.xn_a), P + o.n1b, c.sink);
+            kasf_launch_dgrad_lnbwd(c.dt, c.s, dkv, 256, c.pk(o.p_kvT), nullptr, x_limb, P + o.n1lw, nullptr, c.w(p.g_limb), 1, G + o.n1lw, G + o.n1lb, c.M,
+                                    c.w(sc.xn_b), P + o.n1lb, c.sink);
+        }
         bool done = false;
         if (jobs) {
             const void* Gs[3] = {g_mid, dq, dkv};
@@ -481,7 +513,8 @@ void block_backward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void*
             const int Ns[3] = {128, 128, 256};
             float* dWs[3] = {G + o.proj_w, G + o.mix_w, G + o.kv_w};
             float* dbs[3] = {G + o.proj_b, nullptr, nullptr};
-            done = kasf_launch_wgrad_jobs(c.s, 3, Gs, Xs, Ns, dWs, dbs, 0, P + o.proj_w, P + o.proj_b, P + o.ls1, G + o.ls1, c.M, part, WG_PARTIAL_FLOATS);
+            done = kasf_launch_wgrad_jobs(c.s, fusedwg ? 1 : 3, Gs, Xs, Ns, dWs, dbs, 0, P + o.proj_w, P + o.proj_b, P + o.ls1, G + o.ls1, c.M, part,
+                                          fusedwg ? WG_JOBS_FLOATS : WG_PARTIAL_FLOATS, nred, red);
         }
         if (!done) {
             if (jobs) {

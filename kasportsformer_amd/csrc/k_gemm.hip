@@ -453,12 +453,57 @@ struct FinJob {
     float *db, *dls;
     const float* brow;            // [splits][N] per-split column sums of G (colsum = their fixed-order sum)
 };
+struct FinRed {                // bf16 partial tiles of a fused data + weight gradient launch (k_dgrad_r<..., WG>): out[e] += sum_z part[z][e]
+    const bf16* part;
+    float* out;
+    int nparts, elems, first;  // first workgroup; elems / 128 workgroups
+};
 struct FinJobs {
-    int n, splits;
+    int n, splits, nred;
     FinJob j[3];
+    FinRed r[2];
 };
 __global__ __launch_bounds__(256) void k_wgrad_finish_jobs(const FinJobs js) {
     __shared__ f32x4 sPart[4][64];
+    if (js.nred > 0 && (int)blockIdx.x >= js.r[0].first) {
+        // ---- reduction role (round 4): a workgroup owns 128 consecutive elements (16 lanes x 8); its 16 lane groups each add every 16th partial tile,
+        // the 16 sums meet in LDS and are added in a fixed tree: bitwise reproducible ----
+        __shared__ float sR[16][128];
+        const FinRed& rd = js.r[(js.nred > 1 && (int)blockIdx.x >= js.r[1].first) ? 1 : 0];
+        const int l = threadIdx.x & 15, zl = threadIdx.x >> 4;
+        const int64_t e = ((int64_t)((int)blockIdx.x - rd.first) * 16 + l) * 8;
+        float s0[8], s1[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { s0[k] = 0.f; s1[k] = 0.f; }
+        int z = zl;
+        for (; z + 16 < rd.nparts; z += 32) {
+            float a[8], b[8];
+            load8(rd.part + (int64_t)z * rd.elems + e, a);
+            load8(rd.part + (int64_t)(z + 16) * rd.elems + e, b);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { s0[k] += a[k]; s1[k] += b[k]; }
+        }
+        if (z < rd.nparts) {
+            float a[8];
+            load8(rd.part + (int64_t)z * rd.elems + e, a);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s0[k] += a[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sR[zl][l * 8 + k] = s0[k] + s1[k];
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            float t[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) t[q] = sR[q][threadIdx.x];
+#pragma unroll
+            for (int h = 8; h >= 1; h >>= 1)
+#pragma unroll
+                for (int q = 0; q < h; ++q) t[q] += t[q + h];
+            rd.out[((int64_t)((int)blockIdx.x - rd.first)) * 128 + threadIdx.x] += t[0];
+        }
+        return;
+    }
     int ji = 0;
 #pragma unroll
     for (int q = 1; q < 3; ++q)
@@ -734,8 +779,8 @@ void kasf_launch_pack(int dt, hipStream_t s, const float* params, void* arena, c
 // Returns false (nothing launched) when the scratch is too small.
 bool kasf_launch_wgrad_jobs(hipStream_t s, int njobs, const void* const* G, const void* const* X, const int* N, float* const* dW, float* const* dbias,
                             int fin_job, const float* fin_W, const float* fin_bias, const float* fin_ls, float* fin_dls, int64_t M, float* partial,
-                            int64_t partial_floats) {
-    if (njobs < 1 || njobs > 3 || M <= 0) return false;
+                            int64_t partial_floats, int nred, const KasfBf16Reduce* red) {
+    if (njobs < 1 || njobs > 3 || M <= 0 || nred < 0 || nred > 2) return false;
     int tiles = 0;
     for (int j = 0; j < njobs; ++j) tiles += N[j] / 128;
     constexpr int target = 248;
@@ -754,6 +799,7 @@ bool kasf_launch_wgrad_jobs(hipStream_t s, int njobs, const void* const* G, cons
     WgJobs js;
     FinJobs fj;
     js.n = fj.n = njobs; js.splits = fj.splits = splits; js.slice = slice; js.M = M;
+    fj.nred = nred;
     int first = 0, ffirst = 0;
     float* pp = partial;
     for (int j = 0; j < njobs; ++j) {
@@ -767,6 +813,10 @@ bool kasf_launch_wgrad_jobs(hipStream_t s, int njobs, const void* const* G, cons
     }
     const size_t shr = (size_t)WR_ST * 2 * WR_BM * 128 * sizeof(bf16);
     set_smem(k_wgrad_ring_jobs, shr);
+    for (int k = 0; k < nred; ++k) {                     // the bf16 partial tiles of the block's fused data + weight gradient launches ride in the same finish
+        fj.r[k] = FinRed{(const bf16*)red[k].part, red[k].out, red[k].nparts, red[k].elems, ffirst};
+        ffirst += red[k].elems / 128;
+    }
     hipLaunchKernelGGL(k_wgrad_ring_jobs, dim3(first), dim3(256), shr, s, js);
     hipLaunchKernelGGL(k_wgrad_finish_jobs, dim3(ffirst), dim3(256), 0, s, fj);
     return true;

@@ -23,11 +23,17 @@ __device__ __forceinline__ bf16x8 tok_frag(const bf16* s, int row, int ks) {
 }
 
 // Ring slot layout (tiles of [32][128] bf16, 8 KB each): dY chunk 0..KC-1 | x | resid? | add? | out(accumulate)?
-template <int KC, bool RESID, bool ADD, bool ACC, bool XN, int RING>
+// WG (round 4): the weight gradient dW[128 KC][128] = dY^T . LN(x) of the SAME linear is accumulated here as well -- the dY tile is in the ring and LN(x) is
+// formed by the LayerNorm-backward phase anyway, so the separate streaming launch (k_wgrad_ring_jobs: dY and LN(x) read once more, LN(x) written for it) goes
+// away.  Tile t - 1 is multiplied while tile t's data gradient runs (transposed LDS fragments, tokens = the MFMA's reduction axis); wave w keeps rows
+// [16 KC w, +16 KC) of dW in 8 KC accumulator registers for the whole token range and leaves ONE bf16 partial tile per workgroup (fixed-order finish).
+template <int KC, bool RESID, bool ADD, bool ACC, bool XN, int RING, bool WG = false>
 __global__ __launch_bounds__(R_THR) void k_dgrad_r(const bf16* __restrict__ dY, const bf16* __restrict__ Wt, const bf16* __restrict__ dxn_add,
                                                    const bf16* __restrict__ X, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                    const bf16* __restrict__ resid, bf16* __restrict__ out, float* __restrict__ dgamma,
-                                                   float* __restrict__ dbeta, bf16* __restrict__ xn_out, int64_t M, float* __restrict__ part) {
+                                                   float* __restrict__ dbeta, bf16* __restrict__ xn_out, int64_t M, float* __restrict__ part,
+                                                   bf16* __restrict__ wpart) {
+    static_assert(!WG || XN, "the fused weight gradient multiplies by LN(x)");
     constexpr int Kd = 128 * KC;
     constexpr int NSTREAM = KC + 1 + (RESID ? 1 : 0) + (ADD ? 1 : 0) + (ACC ? 1 : 0);     // LDS-direct loads per wave per tile
     constexpr int SLOT = NSTREAM * R_TILE;
@@ -35,6 +41,7 @@ __global__ __launch_bounds__(R_THR) void k_dgrad_r(const bf16* __restrict__ dY, 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* sRing = reinterpret_cast<bf16*>(smem);        // [RING][SLOT]
     bf16* sD = sRing + RING * SLOT;                     // [32][128] dxn of the current tile
+    bf16* sXn = sD + R_TILE;                            // WG: [2][32][128] LN(x) of tiles t - 1 / t (rows past M zero)
     float* sRed = reinterpret_cast<float*>(smem);       // [2][32][128] end-of-kernel dgamma/dbeta partials: reuses the (then dead) ring
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4, sub = lane & 15, rl = threadIdx.x >> 4;
     const int64_t ntiles_total = (M + R_BM - 1) / R_BM;
@@ -50,7 +57,28 @@ __global__ __launch_bounds__(R_THR) void k_dgrad_r(const bf16* __restrict__ dY, 
     float gm[8], bt[8], dg[8], db[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { gm[e] = gamma[sub * 8 + e]; bt[e] = XN ? beta[sub * 8 + e] : 0.f; dg[e] = 0.f; db[e] = 0.f; }
+    float* sGB = reinterpret_cast<float*>(sXn + 2 * R_TILE);     // WG: gamma | beta in LDS, re-read per tile (16 registers the KC = 3 form does not have)
+    if (WG) {
+        if (threadIdx.x < 128) { sGB[threadIdx.x] = gamma[threadIdx.x]; sGB[128 + threadIdx.x] = beta[threadIdx.x]; }
+        __syncthreads();
+    }
 
+    f32x4 accW[WG ? KC : 1][WG ? 8 : 1];
+    if (WG) zero_acc(accW);
+    auto wgrad_tile = [&](const bf16* slot_prev, const bf16* xnT) {      // dW rows [16 KC w, +16 KC) += dY(tile)^T . LN(x)(tile): one k-step of 32 tokens
+        bf16x8 ra[WG ? KC : 1];
+#pragma unroll
+        for (int a = 0; a < (WG ? KC : 0); ++a) {
+            const int R0 = 16 * KC * w + 16 * a;         // a 16-row group never crosses a 128-column chunk of dY
+            ra[a] = frag_tr(slot_prev + (R0 >> 7) * R_TILE, 8 * g, R0 & 127);
+        }
+#pragma unroll
+        for (int b = 0; b < (WG ? 8 : 0); ++b) {
+            const bf16x8 cb = frag_tr(xnT, 8 * g, 16 * b);
+#pragma unroll
+            for (int a = 0; a < (WG ? KC : 0); ++a) accW[a][b] = mfma16(ra[a], cb, accW[a][b]);
+        }
+    };
     auto nxr = [](int sl) { return sl == RING - 1 ? 0 : sl + 1; };   // ring slots roll (no 64-bit modulo in the loop)
     auto issue = [&](int64_t t, int sl) {                // exactly NSTREAM LDS-direct loads per wave per call
         const int64_t tt = t < ntiles ? t : ntiles - 1;
@@ -66,13 +94,14 @@ __global__ __launch_bounds__(R_THR) void k_dgrad_r(const bf16* __restrict__ dY, 
     };
     issue(0, 0);
     if (RING == 3) { issue(1, 1); wait_async_le<NSTREAM>(); }   // tile 0 landed, tile 1 in flight
-    int sl = 0;
-    for (int64_t t = 0; t < ntiles; ++t, sl = nxr(sl)) {
+    int sl = 0, psl = 0;
+    for (int64_t t = 0; t < ntiles; ++t, psl = sl, sl = nxr(sl)) {
         const bf16* slot = sRing + sl * SLOT;
         const int64_t row0 = (tile0 + t) * R_BM;
         if (RING == 2) wait_async();
         barrier_keep_async();                            // B1: tile t visible to every wave; everyone is past tile t-1
         if (RING == 2) issue(t + 1, nxr(sl));
+        if (WG && t >= 1) wgrad_tile(sRing + psl * SLOT, sXn + (int)((t - 1) & 1) * R_TILE);    // slot (t-1) % RING is refilled only after B2
         {   // ---- GEMM: 16 features x 32 tokens per wave ----
             f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
             bf16x8 fb[2][2];
@@ -118,6 +147,12 @@ __global__ __launch_bounds__(R_THR) void k_dgrad_r(const bf16* __restrict__ dY, 
             float xn[8];
             float s1 = 0.f, s2 = 0.f;
             const bool live = row < M;                   // rows past M are clamped copies of the last row: keep them out of the sums
+            if (WG) {
+                const f32x4 g0 = *reinterpret_cast<const f32x4*>(sGB + sub * 8), g1 = *reinterpret_cast<const f32x4*>(sGB + sub * 8 + 4);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(sGB + 128 + sub * 8), b1 = *reinterpret_cast<const f32x4*>(sGB + 128 + sub * 8 + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { gm[e] = g0[e]; gm[4 + e] = g1[e]; bt[e] = b0[e]; bt[4 + e] = b1[e]; }
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 if (XN) xn[e] = x[e] * rstd * gm[e] + bt[e];
@@ -146,14 +181,25 @@ __global__ __launch_bounds__(R_THR) void k_dgrad_r(const bf16* __restrict__ dY, 
             // tile t+1 has landed when only this wave's youngest NSTREAM requests (tile t+2) are outstanding.  Waiting BEFORE this
             // tile's stores keeps them out of that count: they get the whole next tile to drain.
             if (RING == 3) wait_async_le<NSTREAM>();
+            if (WG) {
+                if (!live) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) xn[e] = 0.f;             // clamped copies of the last row must not reach the weight gradient
+                }
+                tile_store8(sXn + (int)(t & 1) * R_TILE, rl, sub * 8, xn);
+            }
             if (live) {
                 store8(out + row * 128 + sub * 8, o);
-                if (XN) store8(xn_out + row * 128 + sub * 8, xn);
+                if (XN && !WG) store8(xn_out + row * 128 + sub * 8, xn);
             }
         }
     }
     wait_async();
     __syncthreads();
+    if (WG) {
+        wgrad_tile(sRing + psl * SLOT, sXn + (int)((ntiles - 1) & 1) * R_TILE);         // the last tile (psl: its slot after the loop's final step)
+        __syncthreads();                                 // the ring is read for the last time: it becomes sRed / the partial's staging tile below
+    }
     // ---- dgamma / dbeta: 32 row groups -> one value per channel per workgroup: row blockIdx.x of `part` (fixed-order finish, k_reduce.hip) ----
 #pragma unroll
     for (int e = 0; e < 8; ++e) { sRed[rl * 128 + sub * 8 + e] = dg[e]; sRed[R_TILE + rl * 128 + sub * 8 + e] = db[e]; }
@@ -166,17 +212,32 @@ __global__ __launch_bounds__(R_THR) void k_dgrad_r(const bf16* __restrict__ dY, 
         if (part != nullptr) part[(int64_t)blockIdx.x * 256 + threadIdx.x] = s;
         else atomicAdd((which == 0 ? dgamma : dbeta) + c, s);
     }
+    if (WG) {
+        // this workgroup's partial dW tile: accumulators -> bf16 image [128 KC][128] in the dead ring -> whole 256-byte rows out (16 bytes per lane)
+        __syncthreads();
+        bf16* sW = sRing;
+#pragma unroll
+        for (int a = 0; a < (WG ? KC : 0); ++a)
+#pragma unroll
+            for (int b = 0; b < (WG ? 8 : 0); ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sW[(16 * KC * w + 16 * a + 4 * g + r) * 128 + 16 * b + i] = (bf16)accW[a][b][r];
+        __syncthreads();
+        bf16* dst = wpart + (int64_t)blockIdx.x * (128 * KC * 128);
+        for (int c = threadIdx.x; c < 128 * KC * 16; c += R_THR) *reinterpret_cast<f32x4*>(dst + c * 8) = *reinterpret_cast<const f32x4*>(sW + c * 8);
+    }
 }
 
-template <int KC, bool RESID, bool ADD, bool ACC, bool XN>
-void launch_dgrad_r(hipStream_t s, const void* dY, const void* Wt, const void* add, const void* X, const float* gamma, const float* beta, const void* resid,
-                    void* out, float* dgamma, float* dbeta, void* xn_out, int64_t M, KasfColSink* sink) {
+template <int KC, bool RESID, bool ADD, bool ACC, bool XN, bool WG = false>
+int launch_dgrad_r(hipStream_t s, const void* dY, const void* Wt, const void* add, const void* X, const float* gamma, const float* beta, const void* resid,
+                   void* out, float* dgamma, float* dbeta, void* xn_out, int64_t M, KasfColSink* sink, void* wpart = nullptr) {
     constexpr int NSTREAM = KC + 1 + (RESID ? 1 : 0) + (ADD ? 1 : 0) + (ACC ? 1 : 0);
-    constexpr size_t fixed = (size_t)R_TILE * 2;                                        // sD (the end-of-kernel reduction reuses the ring: >= 32 KB)
+    constexpr size_t fixed = (size_t)R_TILE * 2 * (WG ? 3 : 1) + (WG ? 1024 : 0);                         // sD (+ the two LN(x) tiles of the fused weight gradient); the end-of-kernel reductions reuse the ring: >= 32 KB
     constexpr bool ring3 = 3 * NSTREAM * R_TILE * 2 + fixed <= 160 * 1024;
     constexpr int RING = ring3 ? 3 : 2;
+    static_assert(!WG || RING * NSTREAM >= 4 * KC, "the partial weight-gradient tile is staged in the ring");
     const size_t sh = (size_t)RING * NSTREAM * R_TILE * 2 + fixed;
-    auto kern = k_dgrad_r<KC, RESID, ADD, ACC, XN, RING>;
+    auto kern = k_dgrad_r<KC, RESID, ADD, ACC, XN, RING, WG>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     const int64_t tiles = (M + R_BM - 1) / R_BM;
     const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
@@ -184,16 +245,11 @@ void launch_dgrad_r(hipStream_t s, const void* dY, const void* Wt, const void* a
     const int active = (int)((tiles + per - 1) / per);                                  // workgroups that own at least one tile (the others return at once)
     float* part = sink != nullptr ? sink->take(active, 256) : nullptr;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(R_THR), sh, s, (const bf16*)dY, (const bf16*)Wt, (const bf16*)add, (const bf16*)X, gamma, beta,
-                       (const bf16*)resid, (bf16*)out, dgamma, dbeta, (bf16*)xn_out, M, part);
+                       (const bf16*)resid, (bf16*)out, dgamma, dbeta, (bf16*)xn_out, M, part, (bf16*)wpart);
     if (part != nullptr) { sink->add(part, 256, active, 128, dgamma); sink->add(part + 128, 256, active, 128, dbeta); }
+    return active;                                       // WG: this many bf16 partial tiles of [128 KC][128] were written to wpart
 }
 
-
-// ---------------------------------------------------------------------------------------------------------------
-// Forward linear.  Wave w owns output features [16 NC w, 16 NC (w+1)): NC weight tiles x 4 k-steps = 16 NC VGPRs.
-// Per 32-token tile: (LN: one 16-lane group per row normalises the raw tile into sA, one tile ahead) -> GEMM ->
-// accumulators to the swizzled output tile in LDS -> barrier -> full 16-byte-per-lane row stores.
-// ---------------------------------------------------------------------------------------------------------------
 template <int NC, bool LN, bool RES>
 __global__ __launch_bounds__(R_THR) void k_linear_r(const bf16* __restrict__ A, const bf16* __restrict__ W, const float* __restrict__ bias,
                                                     const float* __restrict__ ln_g, const float* __restrict__ ln_b, bf16* __restrict__ xn_out,
@@ -333,6 +389,19 @@ bool kasf_launch_dgrad_r(hipStream_t s, const void* dY, int Kd, const void* Wt, 
     else if (Kd == 256 && R && A && !C && !XN) launch_dgrad_r<2, true, true, false, false>(s, dY, Wt, dxn_add, X, gamma, beta, resid, out, dgamma, dbeta, xn_out, M, sink);
     else return false;
     return true;
+}
+
+// The data gradient of an LN-fused linear WITH its weight gradient (dW[Kd][128] = dY^T LN(x)) in one streaming launch.  The weight gradient leaves it as
+// `return value` bf16 partial tiles of Kd x 128 in wpart (room for 256 of them), which the block's k_wgrad_finish_jobs launch adds in a fixed order
+// (KasfBf16Reduce).  Returns 0 for combinations that are not instantiated (the caller runs the two-kernel sequence).
+int kasf_launch_dgrad_wg(hipStream_t s, const void* dY, int Kd, const void* Wt, const void* X, const float* gamma, const float* beta, const void* resid, void* out,
+                         int accumulate, float* dgamma, float* dbeta, int64_t M, KasfColSink* sink, void* wpart, int64_t wpart_bytes) {
+    if (M <= 0 || wpart == nullptr || wpart_bytes < (int64_t)256 * Kd * 128 * 2) return 0;
+    const bool R = resid != nullptr, C = accumulate != 0;
+    if (Kd == 384 && R && !C) return launch_dgrad_r<3, true, false, false, true, true>(s, dY, Wt, nullptr, X, gamma, beta, resid, out, dgamma, dbeta, nullptr, M, sink, wpart);
+    if (Kd == 128 && R && !C) return launch_dgrad_r<1, true, false, false, true, true>(s, dY, Wt, nullptr, X, gamma, beta, resid, out, dgamma, dbeta, nullptr, M, sink, wpart);
+    if (Kd == 256 && !R && C) return launch_dgrad_r<2, false, false, true, true, true>(s, dY, Wt, nullptr, X, gamma, beta, resid, out, dgamma, dbeta, nullptr, M, sink, wpart);
+    return 0;
 }
 
 // y = LN?(a) W^T + bias, a [M,128] dense, W [N,128] dense, y [M,N] dense, N in {128, 256, 384}

@@ -166,6 +166,10 @@ void kasf_launch_gather_clips(hipStream_t s, const float* xa, const float* ya, c
                               int T, float* xo, float* yo);
 
 // ---- k_gemm2.hip (bf16, persistent, register-resident weights) ----
+int kasf_launch_dgrad_wg(hipStream_t s, const void* dY, int Kd, const void* Wt, const void* X, const float* gamma, const float* beta, const void* resid, void* out,
+                         int accumulate, float* dgamma, float* dbeta, int64_t M, KasfColSink* sink, void* wpart, int64_t wpart_bytes);
+// bf16 partial tiles a fused data + weight gradient launch left: out[e] += sum over z < nparts of part[z][e], e < elems (elems a multiple of 128)
+struct KasfBf16Reduce { const void* part; float* out; int nparts; int elems; };
 bool kasf_launch_dgrad_r(hipStream_t s, const void* dY, int Kd, const void* Wt, const void* dxn_add, const void* X, const float* gamma, const void* resid,
                          void* out, int accumulate, float* dgamma, float* dbeta, int64_t M, void* xn_out, const float* beta, KasfColSink* sink = nullptr);
 bool kasf_launch_linear_r(hipStream_t s, const void* A, const void* W, const float* bias, void* C, int64_t M, int N, const float* ln_g, const float* ln_b,
@@ -181,7 +185,7 @@ bool kasf_launch_attn_block_fwd(hipStream_t s, int bone, const void* x, const vo
 // ---- k_gemm.hip: several bf16 weight gradients dW_j[N_j][128] += G_j^T X_j in one streaming launch + one finishing launch ----
 bool kasf_launch_wgrad_jobs(hipStream_t s, int njobs, const void* const* G, const void* const* X, const int* N, float* const* dW, float* const* dbias,
                             int fin_job, const float* fin_W, const float* fin_bias, const float* fin_ls, float* fin_dls, int64_t M, float* partial,
-                            int64_t partial_floats);
+                            int64_t partial_floats, int nred = 0, const KasfBf16Reduce* red = nullptr);
 bool kasf_launch_attn_bwd_fused_do(hipStream_t s, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, const void* g_mid,
                                    const void* WprojTs, void* dq, int64_t lddq, void* dk, void* dv, int64_t lddkv, int B, int Tn, int mode, int form = 0 /* 0: persistent, 1: one group per workgroup (bit-equal comparison form for the tests) */,
                                    const void* o_saved = nullptr, const float* lse = nullptr);   // o_saved [M][128] + lse [M][8] (both from the forward): groups of 33..96 positions take the key-tile-outer kernel
