@@ -424,6 +424,16 @@ void block_backward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void*
         const double count = o.mode == 0 ? (double)c.B * c.T * 128 : (double)c.B * 17 * 128;
         kasf_launch_gcn_bwd2(c.dt, c.s, c.w(sc.rbuf), c.w(w.y), (const float*)c.w(w.coef), w.mask >= 0 ? (const uint32_t*)c.w(w.mask) : nullptr, c.w(sc.duv),
                              c.B, c.T, o.mode, (const double*)c.w(w.bstats), G + o.bn_w, G + o.bn_b, count, c.bn_train ? 1 : 0);
+        // bf16: the U | V weight and bias gradients ride in the data-gradient kernel (dY tile in its ring, LN(x) formed by its LayerNorm-backward phase)
+        int np = 0;
+        if (c.dt == KASF_BF16 && c.sink != nullptr)
+            np = kasf_launch_dgrad_wg(c.s, c.w(sc.duv), 256, c.pk(o.p_mixT), x_in, P + o.n1w, P + o.n1b, g_mid, dst, accumulate, G + o.n1w, G + o.n1b, c.M, c.sink, part,
+                                      (int64_t)WG_PARTIAL_FLOATS * 4, c.w(sc.rbuf), G + o.uv_b);
+        if (np > 0) {
+            const KasfBf16Reduce red{part, G + o.mix_w, np, 256 * 128};
+            kasf_launch_bf16_reduce(c.s, 1, &red);
+            return;
+        }
         kasf_launch_dgrad_lnbwd(c.dt, c.s, c.w(sc.duv), 256, c.pk(o.p_mixT), c.w(sc.rbuf), x_in, P + o.n1w, g_mid, dst, accumulate, G + o.n1w, G + o.n1b,
                                 c.M, nullptr, nullptr, c.sink);
         kasf_launch_wgrad(c.dt, c.s, c.w(sc.duv), 256, 256, c.w(w.xn), 128, 128, nullptr, nullptr, G + o.mix_w, 128, G + o.uv_b, c.M, part, WG_PARTIAL_FLOATS);

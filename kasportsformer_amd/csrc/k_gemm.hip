@@ -774,6 +774,18 @@ void kasf_launch_pack(int dt, hipStream_t s, const float* params, void* arena, c
     else hipLaunchKernelGGL(k_pack<bf16>, dim3(total_tiles), dim3(256), 0, s, params, (bf16*)arena, desc, tile_start, ndesc);
 }
 
+void kasf_launch_bf16_reduce(hipStream_t s, int nred, const KasfBf16Reduce* red) {
+    if (nred < 1 || nred > 2) return;
+    FinJobs fj;
+    fj.n = 0; fj.splits = 0; fj.nred = nred;
+    int first = 0;
+    for (int k = 0; k < nred; ++k) {
+        fj.r[k] = FinRed{(const bf16*)red[k].part, red[k].out, red[k].nparts, red[k].elems, first};
+        first += red[k].elems / 128;
+    }
+    hipLaunchKernelGGL(k_wgrad_finish_jobs, dim3(first), dim3(256), 0, s, fj);
+}
+
 // Up to three bf16 weight gradients  dW_j[N_j][128] += G_j^T X_j  (dense operands: ldg = N_j, ldx = 128) in one streaming launch plus one
 // finishing launch.  fin_* of job j (optional): the layer-scale algebra of k_finalize_ls applied to that job (the proj weight).
 // Returns false (nothing launched) when the scratch is too small.

@@ -27,13 +27,17 @@ __device__ __forceinline__ bf16x8 tok_frag(const bf16* s, int row, int ks) {
 // formed by the LayerNorm-backward phase anyway, so the separate streaming launch (k_wgrad_ring_jobs: dY and LN(x) read once more, LN(x) written for it) goes
 // away.  Tile t - 1 is multiplied while tile t's data gradient runs (transposed LDS fragments, tokens = the MFMA's reduction axis); wave w keeps rows
 // [16 KC w, +16 KC) of dW in 8 KC accumulator registers for the whole token range and leaves ONE bf16 partial tile per workgroup (fixed-order finish).
-template <int KC, bool RESID, bool ADD, bool ACC, bool XN, int RING, bool WG = false>
+// BIAS (with WG; the GCN's U | V linear has one): the bias gradient = column sums of dY over the tokens, accumulated from the ring tile by the LayerNorm-backward
+// phase's (row, 8-column) threads and left as 128 KC more columns of the workgroup's row in `part`.
+template <int KC, bool RESID, bool ADD, bool ACC, bool XN, int RING, bool WG = false, bool BIAS = false>
 __global__ __launch_bounds__(R_THR) void k_dgrad_r(const bf16* __restrict__ dY, const bf16* __restrict__ Wt, const bf16* __restrict__ dxn_add,
                                                    const bf16* __restrict__ X, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                    const bf16* __restrict__ resid, bf16* __restrict__ out, float* __restrict__ dgamma,
                                                    float* __restrict__ dbeta, bf16* __restrict__ xn_out, int64_t M, float* __restrict__ part,
-                                                   bf16* __restrict__ wpart) {
+                                                   bf16* __restrict__ wpart, float* __restrict__ dbias) {
     static_assert(!WG || XN, "the fused weight gradient multiplies by LN(x)");
+    static_assert(!BIAS || WG, "the bias gradient rides with the fused weight gradient");
+    constexpr int PLD = 256 + (BIAS ? 128 * KC : 0);    // floats per workgroup row of `part`: dgamma | dbeta [| dbias]
     constexpr int Kd = 128 * KC;
     constexpr int NSTREAM = KC + 1 + (RESID ? 1 : 0) + (ADD ? 1 : 0) + (ACC ? 1 : 0);     // LDS-direct loads per wave per tile
     constexpr int SLOT = NSTREAM * R_TILE;
@@ -65,6 +69,11 @@ __global__ __launch_bounds__(R_THR) void k_dgrad_r(const bf16* __restrict__ dY, 
 
     f32x4 accW[WG ? KC : 1][WG ? 8 : 1];
     if (WG) zero_acc(accW);
+    float dbs[BIAS ? KC : 1][8];
+#pragma unroll
+    for (int kc = 0; kc < (BIAS ? KC : 1); ++kc)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dbs[kc][e] = 0.f;
     auto wgrad_tile = [&](const bf16* slot_prev, const bf16* xnT) {      // dW rows [16 KC w, +16 KC) += dY(tile)^T . LN(x)(tile): one k-step of 32 tokens
         bf16x8 ra[WG ? KC : 1];
 #pragma unroll
@@ -188,6 +197,15 @@ __global__ __launch_bounds__(R_THR) void k_dgrad_r(const bf16* __restrict__ dY, 
                 }
                 tile_store8(sXn + (int)(t & 1) * R_TILE, rl, sub * 8, xn);
             }
+            if (BIAS && live) {
+#pragma unroll
+                for (int kc = 0; kc < (BIAS ? KC : 0); ++kc) {
+                    float v[8];
+                    tile_load8(slot + kc * R_TILE, rl, sub * 8, v);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) dbs[kc][e] += v[e];
+                }
+            }
             if (live) {
                 store8(out + row * 128 + sub * 8, o);
                 if (XN && !WG) store8(xn_out + row * 128 + sub * 8, xn);
@@ -209,8 +227,24 @@ __global__ __launch_bounds__(R_THR) void k_dgrad_r(const bf16* __restrict__ dY, 
         float s = 0.f;
 #pragma unroll 8
         for (int k = 0; k < 32; ++k) s += sRed[which * R_TILE + k * 128 + c];
-        if (part != nullptr) part[(int64_t)blockIdx.x * 256 + threadIdx.x] = s;
+        if (part != nullptr) part[(int64_t)blockIdx.x * PLD + threadIdx.x] = s;
         else atomicAdd((which == 0 ? dgamma : dbeta) + c, s);
+    }
+    if (BIAS) {
+#pragma unroll
+        for (int kc = 0; kc < (BIAS ? KC : 0); ++kc) {
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sRed[rl * 128 + sub * 8 + e] = dbs[kc][e];
+            __syncthreads();
+            if (threadIdx.x < 128) {
+                float sb = 0.f;
+#pragma unroll 8
+                for (int k = 0; k < 32; ++k) sb += sRed[k * 128 + threadIdx.x];
+                if (part != nullptr) part[(int64_t)blockIdx.x * PLD + 256 + kc * 128 + threadIdx.x] = sb;
+                else atomicAdd(dbias + kc * 128 + threadIdx.x, sb);
+            }
+        }
     }
     if (WG) {
         // this workgroup's partial dW tile: accumulators -> bf16 image [128 KC][128] in the dead ring -> whole 256-byte rows out (16 bytes per lane)
@@ -228,25 +262,30 @@ __global__ __launch_bounds__(R_THR) void k_dgrad_r(const bf16* __restrict__ dY, 
     }
 }
 
-template <int KC, bool RESID, bool ADD, bool ACC, bool XN, bool WG = false>
+template <int KC, bool RESID, bool ADD, bool ACC, bool XN, bool WG = false, bool BIAS = false>
 int launch_dgrad_r(hipStream_t s, const void* dY, const void* Wt, const void* add, const void* X, const float* gamma, const float* beta, const void* resid,
-                   void* out, float* dgamma, float* dbeta, void* xn_out, int64_t M, KasfColSink* sink, void* wpart = nullptr) {
+                   void* out, float* dgamma, float* dbeta, void* xn_out, int64_t M, KasfColSink* sink, void* wpart = nullptr, float* dbias = nullptr) {
+    constexpr int PLD = 256 + (BIAS ? 128 * KC : 0);
     constexpr int NSTREAM = KC + 1 + (RESID ? 1 : 0) + (ADD ? 1 : 0) + (ACC ? 1 : 0);
     constexpr size_t fixed = (size_t)R_TILE * 2 * (WG ? 3 : 1) + (WG ? 1024 : 0);                         // sD (+ the two LN(x) tiles of the fused weight gradient); the end-of-kernel reductions reuse the ring: >= 32 KB
     constexpr bool ring3 = 3 * NSTREAM * R_TILE * 2 + fixed <= 160 * 1024;
     constexpr int RING = ring3 ? 3 : 2;
     static_assert(!WG || RING * NSTREAM >= 4 * KC, "the partial weight-gradient tile is staged in the ring");
     const size_t sh = (size_t)RING * NSTREAM * R_TILE * 2 + fixed;
-    auto kern = k_dgrad_r<KC, RESID, ADD, ACC, XN, RING, WG>;
+    auto kern = k_dgrad_r<KC, RESID, ADD, ACC, XN, RING, WG, BIAS>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     const int64_t tiles = (M + R_BM - 1) / R_BM;
     const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
     const int64_t per = (tiles + grid - 1) / grid;
     const int active = (int)((tiles + per - 1) / per);                                  // workgroups that own at least one tile (the others return at once)
-    float* part = sink != nullptr ? sink->take(active, 256) : nullptr;
+    float* part = sink != nullptr ? sink->take(active, PLD) : nullptr;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(R_THR), sh, s, (const bf16*)dY, (const bf16*)Wt, (const bf16*)add, (const bf16*)X, gamma, beta,
-                       (const bf16*)resid, (bf16*)out, dgamma, dbeta, (bf16*)xn_out, M, part, (bf16*)wpart);
-    if (part != nullptr) { sink->add(part, 256, active, 128, dgamma); sink->add(part + 128, 256, active, 128, dbeta); }
+                       (const bf16*)resid, (bf16*)out, dgamma, dbeta, (bf16*)xn_out, M, part, (bf16*)wpart, dbias);
+    if (part != nullptr) {
+        sink->add(part, PLD, active, 128, dgamma);
+        sink->add(part + 128, PLD, active, 128, dbeta);
+        if (BIAS) sink->add(part + 256, PLD, active, 128 * KC, dbias);
+    }
     return active;                                       // WG: this many bf16 partial tiles of [128 KC][128] were written to wpart
 }
 
@@ -395,9 +434,15 @@ bool kasf_launch_dgrad_r(hipStream_t s, const void* dY, int Kd, const void* Wt, 
 // `return value` bf16 partial tiles of Kd x 128 in wpart (room for 256 of them), which the block's k_wgrad_finish_jobs launch adds in a fixed order
 // (KasfBf16Reduce).  Returns 0 for combinations that are not instantiated (the caller runs the two-kernel sequence).
 int kasf_launch_dgrad_wg(hipStream_t s, const void* dY, int Kd, const void* Wt, const void* X, const float* gamma, const float* beta, const void* resid, void* out,
-                         int accumulate, float* dgamma, float* dbeta, int64_t M, KasfColSink* sink, void* wpart, int64_t wpart_bytes) {
+                         int accumulate, float* dgamma, float* dbeta, int64_t M, KasfColSink* sink, void* wpart, int64_t wpart_bytes, const void* dxn_add,
+                         float* dbias) {
     if (M <= 0 || wpart == nullptr || wpart_bytes < (int64_t)256 * Kd * 128 * 2) return 0;
     const bool R = resid != nullptr, C = accumulate != 0;
+    if (dxn_add != nullptr || dbias != nullptr) {        // the GCN's U | V linear: direct LN(x) gradient added in, bias gradient = column sums of dY
+        if (Kd == 256 && R && !C && dxn_add != nullptr && dbias != nullptr)
+            return launch_dgrad_r<2, true, true, false, true, true, true>(s, dY, Wt, dxn_add, X, gamma, beta, resid, out, dgamma, dbeta, nullptr, M, sink, wpart, dbias);
+        return 0;
+    }
     if (Kd == 384 && R && !C) return launch_dgrad_r<3, true, false, false, true, true>(s, dY, Wt, nullptr, X, gamma, beta, resid, out, dgamma, dbeta, nullptr, M, sink, wpart);
     if (Kd == 128 && R && !C) return launch_dgrad_r<1, true, false, false, true, true>(s, dY, Wt, nullptr, X, gamma, beta, resid, out, dgamma, dbeta, nullptr, M, sink, wpart);
     if (Kd == 256 && !R && C) return launch_dgrad_r<2, false, false, true, true, true>(s, dY, Wt, nullptr, X, gamma, beta, resid, out, dgamma, dbeta, nullptr, M, sink, wpart);

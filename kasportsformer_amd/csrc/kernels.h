@@ -166,10 +166,12 @@ void kasf_launch_gather_clips(hipStream_t s, const float* xa, const float* ya, c
                               int T, float* xo, float* yo);
 
 // ---- k_gemm2.hip (bf16, persistent, register-resident weights) ----
-int kasf_launch_dgrad_wg(hipStream_t s, const void* dY, int Kd, const void* Wt, const void* X, const float* gamma, const float* beta, const void* resid, void* out,
-                         int accumulate, float* dgamma, float* dbeta, int64_t M, KasfColSink* sink, void* wpart, int64_t wpart_bytes);
 // bf16 partial tiles a fused data + weight gradient launch left: out[e] += sum over z < nparts of part[z][e], e < elems (elems a multiple of 128)
 struct KasfBf16Reduce { const void* part; float* out; int nparts; int elems; };
+int kasf_launch_dgrad_wg(hipStream_t s, const void* dY, int Kd, const void* Wt, const void* X, const float* gamma, const float* beta, const void* resid, void* out,
+                         int accumulate, float* dgamma, float* dbeta, int64_t M, KasfColSink* sink, void* wpart, int64_t wpart_bytes, const void* dxn_add = nullptr,
+                         float* dbias = nullptr);
+void kasf_launch_bf16_reduce(hipStream_t s, int nred, const KasfBf16Reduce* red);      // the fixed-order sum of such partial tiles on its own (no streaming jobs in the block)
 bool kasf_launch_dgrad_r(hipStream_t s, const void* dY, int Kd, const void* Wt, const void* dxn_add, const void* X, const float* gamma, const void* resid,
                          void* out, int accumulate, float* dgamma, float* dbeta, int64_t M, void* xn_out, const float* beta, KasfColSink* sink = nullptr);
 bool kasf_launch_linear_r(hipStream_t s, const void* A, const void* W, const float* bias, void* C, int64_t M, int N, const float* ln_g, const float* ln_b,

@@ -24,10 +24,15 @@ ALG = {
     "k_linear_r<2, true, false>": ("LN + U|V / KV linear (N=256) + LN(x) out", 128 * s + 256 * s + 128 * s),
     "k_linear_r<1, true, false>": ("LN + Q linear (N=128)", 128 * s + 128 * s),
     "k_linear_r<1, false, true>": ("proj + layer-scale + residual", 3 * 128 * s),
-    "k_dgrad_r<3, true, false, false, true, 3>": ("dqkv.W + LN backward + residual, emits LN(x)", (384 + 4 * 128) * s),
-    "k_dgrad_r<2, true, true, false, false, 3>": ("GCN: duv.W + LN backward + residual + direct LN(x) gradient", (256 + 4 * 128) * s),
-    "k_dgrad_r<2, false, false, true, true, 3>": ("bone: dkv.W + LN backward, accumulates into g_limb, emits LN(x_limb)", (256 + 4 * 128) * s),
-    "k_dgrad_r<1, true, false, false, true, 3>": ("bone: dq.W + LN backward + residual, emits LN(x)", (128 + 4 * 128) * s),
+    # round 4: the bf16 engine runs the WG forms (weight gradient inside the data-gradient kernel: no LN(x) output, one bf16 partial dW tile per workgroup as design bytes)
+    "k_dgrad_r<3, true, false, false, true, 3, true, false>": ("dqkv.W + LN backward + residual + dW_qkv (dqkv read once)", (384 + 3 * 128) * s, 256 * 384 * 128 * 2 / M),
+    "k_dgrad_r<2, true, true, false, true, 3, true, true>": ("GCN: duv.W + LN backward + residual + direct LN(x) gradient + dW_uv, db_uv", (256 + 4 * 128) * s, 256 * 256 * 128 * 2 / M),
+    "k_dgrad_r<2, false, false, true, true, 3, true, false>": ("bone: dkv.W + LN backward, accumulates into g_limb, + dW_kv", (256 + 3 * 128) * s, 256 * 256 * 128 * 2 / M),
+    "k_dgrad_r<1, true, false, false, true, 3, true, false>": ("bone: dq.W + LN backward + residual + dW_q", (128 + 3 * 128) * s, 256 * 128 * 128 * 2 / M),
+    "k_dgrad_r<3, true, false, false, true, 3, false, false>": ("dqkv.W + LN backward + residual, emits LN(x)", (384 + 4 * 128) * s),
+    "k_dgrad_r<2, true, true, false, false, 3, false, false>": ("GCN: duv.W + LN backward + residual + direct LN(x) gradient", (256 + 4 * 128) * s),
+    "k_dgrad_r<2, false, false, true, true, 3, false, false>": ("bone: dkv.W + LN backward, accumulates into g_limb, emits LN(x_limb)", (256 + 4 * 128) * s),
+    "k_dgrad_r<1, true, false, false, true, 3, false, false>": ("bone: dq.W + LN backward + residual, emits LN(x)", (128 + 4 * 128) * s),
     # the fused MLP backward is ONE op by SURVEY §8(d): x_mid, g in, g_in out = 3 x 128 x s per token for the pair of launches; the second launch gets the
     # LayerNorm-backward share (x_mid, g in; g_in out), the first the LN(x) it streams.  Everything else both move is the design's own exchange.
     "k_lnbwd_sum4": ("sum of 4 dA partials + LN backward + residual (+ the weight-gradient partial tiles)", 3 * 128 * s, 4 * 128 * s + 2 * 64 * 65536 * 4 / M),
@@ -48,7 +53,7 @@ ALG = {
     "k_attn_bwd_long<3": ("attention backward cores + d_o, 33..96-position groups: q|k|v, g_mid in; dq|dk|dv out", (384 + 128 + 384) * s),
     "k_attn_bwd_kt<": ("attention backward cores + d_o, 33..96-position groups (key-tile-outer form): q|k|v, o, g_mid in; dq|dk|dv out", (384 + 128 + 128 + 384) * s),
     "k_attn_fwd_mfma<3>": ("attention forward core, 33..96-position groups: q|k|v in, o out", (384 + 128) * s),
-    "k_wgrad_ring_jobs": ("all weight gradients of an attention block: g_mid, o, dqkv, LN(x) streamed once", (128 + 128 + 384 + 128) * s),
+    "k_wgrad_ring_jobs": ("the proj weight gradient of an attention / bone block: g_mid, o streamed once (qkv / q / kv ride in k_dgrad_r since round 4)", (128 + 128) * s),
     "k_mlp_fwd_s": ("fused MLP fwd: x in, x_out out; LN(x) saved for the backward", 2 * 128 * s, 128 * s),
     "k_mlp_bwd_s": ("fused MLP bwd: LN(x), g in; 4 dA partials out (its x_mid / g_in traffic is booked on k_lnbwd_sum4)", 0, (2 * 128 + 4 * 128) * s),
 }
