@@ -45,6 +45,9 @@ static bool single_stream() {
     if (v < 0) { v = getenv("KASF_SINGLE_STREAM") != nullptr ? 1 : 0; g_single_stream.store(v, std::memory_order_relaxed); }
     return v != 0;
 }
+// The fused data + weight gradient launches leave one partial dW tile per WORKGROUP whatever the batch: a fixed 25-50 MB of partial traffic per block that only
+// pays for itself once the token stream is long enough (measured: T = 27, B = 256 -3 % per step; B = 32 +3 %): below this many tokens the two-kernel sequence runs.
+constexpr int64_t WG_FUSE_MIN_TOKENS = 40000;
 constexpr int64_t WG_JOBS_FLOATS = 248 * 128 * 128 + 248 * 128 + 4096;   // the proj job alone: 248 splits of one 128 x 128 tile + their bias rows
 constexpr int64_t WG_BF16_BYTES = (int64_t)256 * 384 * 128 * 2;         // <= 256 bf16 partial tiles of the block's fused data + weight gradient launches (qkv: 384 rows; q + kv: 128 + 256)
 constexpr int64_t WG_PARTIAL_FLOATS = (KASF_MLP_PARTIAL_FLOATS + 65536 > WG_JOBS_FLOATS + WG_BF16_BYTES / 4 ? KASF_MLP_PARTIAL_FLOATS + 65536 : WG_JOBS_FLOATS + WG_BF16_BYTES / 4);   // per-split weight-gradient tiles (256 workgroups x 128x128, or 64 ranges x (dW1 + dW2) of the MLP) + the per-split rows of a bias gradient
@@ -426,7 +429,7 @@ void block_backward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void*
                              c.B, c.T, o.mode, (const double*)c.w(w.bstats), G + o.bn_w, G + o.bn_b, count, c.bn_train ? 1 : 0);
         // bf16: the U | V weight and bias gradients ride in the data-gradient kernel (dY tile in its ring, LN(x) formed by its LayerNorm-backward phase)
         int np = 0;
-        if (c.dt == KASF_BF16 && c.sink != nullptr)
+        if (c.dt == KASF_BF16 && c.sink != nullptr && c.M >= WG_FUSE_MIN_TOKENS)
             np = kasf_launch_dgrad_wg(c.s, c.w(sc.duv), 256, c.pk(o.p_mixT), x_in, P + o.n1w, P + o.n1b, g_mid, dst, accumulate, G + o.n1w, G + o.n1b, c.M, c.sink, part,
                                       (int64_t)WG_PARTIAL_FLOATS * 4, c.w(sc.rbuf), G + o.uv_b);
         if (np > 0) {
@@ -462,7 +465,7 @@ void block_backward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void*
         int nred = 0;
         char* wpart = (char*)(part + WG_JOBS_FLOATS);      // bf16 partial tiles behind the jobs kernel's own fp32 tiles: both live until the block's finish launch
         // the qkv weight gradient rides in the data-gradient kernel (its dY tile and LN(x) are in LDS there): no LN(x) round trip, dqkv read once
-        if (jobs) {
+        if (jobs && c.M >= WG_FUSE_MIN_TOKENS) {
             const int np = kasf_launch_dgrad_wg(c.s, dq, 384, c.pk(o.p_mixT), x_in, P + o.n1w, P + o.n1b, g_mid, dst, accumulate, G + o.n1w, G + o.n1b, c.M, c.sink,
                                                 wpart, WG_BF16_BYTES);
             if (np > 0) { fusedwg = true; red[nred++] = KasfBf16Reduce{wpart, G + o.mix_w, np, 384 * 128}; }
@@ -498,7 +501,7 @@ void block_backward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void*
         KasfBf16Reduce red[2];
         int nred = 0;
         char* wpart = (char*)(part + WG_JOBS_FLOATS);
-        if (jobs) {
+        if (jobs && c.M >= WG_FUSE_MIN_TOKENS) {
             const int64_t qb = (int64_t)256 * 128 * 128 * 2;
             const int npq = kasf_launch_dgrad_wg(c.s, dq, 128, c.pk(o.p_mixT), x_in, P + o.n1w, P + o.n1b, g_mid, dst, accumulate, G + o.n1w, G + o.n1b, c.M, c.sink,
                                                  wpart, qb);
