@@ -96,7 +96,11 @@ __device__ __forceinline__ void lnbwd_sum4_body(const bf16* __restrict__ dApart,
 // halves of a workgroup take the even / odd splits.
 // ---------------------------------------------------------------------------------------------------------------
 // The colsum(g) terms (b2 . gsum into dls, db2 = ls . gsum) are NOT applied here: the column sums are complete only after this launch.
-__device__ __forceinline__ void mlp_wfinish_body(const float* __restrict__ p1, const float* __restrict__ p2, float* __restrict__ dW1,
+__device__ __forceinline__ f32x4 ld4(const bf16* p) {
+    const bf16x4 t = *reinterpret_cast<const bf16x4*>(p);
+    return f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
+}
+__device__ __forceinline__ void mlp_wfinish_body(const bf16* __restrict__ p1, const bf16* __restrict__ p2, float* __restrict__ dW1,
                                                  float* __restrict__ dW2, int splits, const float* __restrict__ W2, const float* __restrict__ b2,
                                                  const float* __restrict__ ls, float* __restrict__ dls, int bid) {
     __shared__ f32x4 sHalf[128];
@@ -104,28 +108,28 @@ __device__ __forceinline__ void mlp_wfinish_body(const float* __restrict__ p1, c
     const int lane = threadIdx.x & 127, half = threadIdx.x >> 7;
     const bool second = bid >= 128;
     const int blk = second ? bid - 128 : bid;
-    const float* part = second ? p2 : p1;
+    const bf16* part = second ? p2 : p1;
     const int64_t e = (int64_t)blk * 512 + lane * 4;
     f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
     int z = half;
     for (; z + 6 < splits; z += 8) {                    // four partial tiles in flight per thread; the order of the additions is the two-at-a-time loop's
-        const f32x4 u0 = *reinterpret_cast<const f32x4*>(part + (int64_t)z * 65536 + e);
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(part + (int64_t)(z + 2) * 65536 + e);
-        const f32x4 u1 = *reinterpret_cast<const f32x4*>(part + (int64_t)(z + 4) * 65536 + e);
-        const f32x4 v1 = *reinterpret_cast<const f32x4*>(part + (int64_t)(z + 6) * 65536 + e);
+        const f32x4 u0 = ld4(part + (int64_t)z * 65536 + e);
+        const f32x4 v0 = ld4(part + (int64_t)(z + 2) * 65536 + e);
+        const f32x4 u1 = ld4(part + (int64_t)(z + 4) * 65536 + e);
+        const f32x4 v1 = ld4(part + (int64_t)(z + 6) * 65536 + e);
 #pragma unroll
         for (int q = 0; q < 4; ++q) { a[q] += u0[q]; b[q] += v0[q]; }
 #pragma unroll
         for (int q = 0; q < 4; ++q) { a[q] += u1[q]; b[q] += v1[q]; }
     }
     for (; z + 2 < splits; z += 4) {
-        const f32x4 u = *reinterpret_cast<const f32x4*>(part + (int64_t)z * 65536 + e);
-        const f32x4 v = *reinterpret_cast<const f32x4*>(part + (int64_t)(z + 2) * 65536 + e);
+        const f32x4 u = ld4(part + (int64_t)z * 65536 + e);
+        const f32x4 v = ld4(part + (int64_t)(z + 2) * 65536 + e);
 #pragma unroll
         for (int q = 0; q < 4; ++q) { a[q] += u[q]; b[q] += v[q]; }
     }
     if (z < splits) {
-        const f32x4 u = *reinterpret_cast<const f32x4*>(part + (int64_t)z * 65536 + e);
+        const f32x4 u = ld4(part + (int64_t)z * 65536 + e);
 #pragma unroll
         for (int q = 0; q < 4; ++q) a[q] += u[q];
     }
@@ -161,7 +165,7 @@ __device__ __forceinline__ void mlp_wfinish_body(const float* __restrict__ p1, c
     }
 }
 struct MlpFinArgs {
-    const float *p1, *p2;
+    const bf16 *p1, *p2;       // bf16 partial tiles per token range: [ranges][512][128] and [ranges][128][512]
     float *dW1, *dW2;
     int splits;
     const float *W2, *b2, *ls;
@@ -193,8 +197,8 @@ void kasf_launch_mlp_bwd_q(hipStream_t s, const void* x, const void* xn, const v
     const int64_t tiles = (M + Q_BM - 1) / Q_BM;
     const int tpr = (int)((tiles + ranges - 1) / ranges);
     const int used = (int)((tiles + tpr - 1) / tpr);             // ranges that own at least one tile
-    float* p1 = partial;
-    float* p2 = partial + (int64_t)used * 512 * 128;
+    bf16* p1 = reinterpret_cast<bf16*>(partial);          // (the scratch is sized in floats for the round-3 fp32 tiles: half of it is used)
+    bf16* p2 = p1 + (int64_t)used * 512 * 128;
     float* db1_rows = sink != nullptr ? sink->take(used, 512) : nullptr;          // one row of db1 per token range
     kasf_launch_mlp_bwd_s(s, xn, g, W1, b1, W2ts, W1t, dApart, p1, p2, db1, db1_rows, M, tpr, used);
     if (db1_rows != nullptr) sink->add(db1_rows, 512, used, 512, db1);

@@ -292,7 +292,7 @@ __global__ __launch_bounds__(S_THR) void k_mlp_fwd_s(const bf16* __restrict__ X,
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(S_THR) void k_mlp_bwd_s(const bf16* __restrict__ XN, const bf16* __restrict__ G, const bf16* __restrict__ W1,
                                                      const float* __restrict__ b1, const bf16* __restrict__ W2ts, const bf16* __restrict__ W1t,
-                                                     bf16* __restrict__ dApart, float* __restrict__ dW1part, float* __restrict__ dW2part,
+                                                     bf16* __restrict__ dApart, bf16* __restrict__ dW1part, bf16* __restrict__ dW2part,
                                                      float* __restrict__ db1, float* __restrict__ db1_rows, int64_t M, int tiles_per_range) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* sA = reinterpret_cast<bf16*>(smem);            // [5][32][128] LN(x) ring
@@ -540,8 +540,11 @@ __global__ __launch_bounds__(S_THR) void k_mlp_bwd_s(const bf16* __restrict__ XN
             TMARK(29);
         }
         wait_async();                                    // drain the look-ahead requests before the wave retires
-        float* p1 = dW1part + (int64_t)range * 512 * 128;        // [512][128]
-        float* p2 = dW2part + (int64_t)range * 128 * 512;        // [128][512]
+        // the quarter's weight-gradient tiles leave as bf16 (round 4: 64 ranges x 0.2 % rounding noise average out two orders below the bf16 operands' own;
+        // half the partial bytes of the step's 156 MLP blocks): accumulators -> two [128][128] images in the (now dead) LDS rings -> whole rows out below
+        __builtin_amdgcn_s_barrier();                    // (with the producers, which are past their last tile: the rings are free)
+        bf16* sW1 = reinterpret_cast<bf16*>(smem);
+        bf16* sW2 = sW1 + 128 * 128;
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -549,9 +552,22 @@ __global__ __launch_bounds__(S_THR) void k_mlp_bwd_s(const bf16* __restrict__ XN
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int rr = tr0 + 16 * a + 4 * g + r, cc = tc0 + 16 * b + i;
-                    p1[(int64_t)(q * 128 + rr) * 128 + cc] = accW1[a][b][r];
-                    p2[(int64_t)rr * 512 + q * 128 + cc] = accW2[a][b][r];
+                    sW1[rr * 128 + cc] = (bf16)accW1[a][b][r];
+                    sW2[rr * 128 + cc] = (bf16)accW2[a][b][r];
                 }
+    }
+    if (w < 4) __builtin_amdgcn_s_barrier();             // pairs with the consumers' barrier above
+    __syncthreads();
+    {
+        const bf16* sW1 = reinterpret_cast<const bf16*>(smem);
+        const bf16* sW2 = sW1 + 128 * 128;
+        bf16* p1 = dW1part + (int64_t)range * 512 * 128 + (int64_t)q * 128 * 128;      // rows [128 q, +128) of [512][128]
+        bf16* p2 = dW2part + (int64_t)range * 128 * 512 + q * 128;                      // columns [128 q, +128) of [128][512]
+        for (int c = threadIdx.x; c < 128 * 16; c += S_THR) {
+            const int rr = c >> 4, ch = c & 15;
+            *reinterpret_cast<f32x4*>(p1 + rr * 128 + ch * 8) = *reinterpret_cast<const f32x4*>(sW1 + rr * 128 + ch * 8);
+            *reinterpret_cast<f32x4*>(p2 + (int64_t)rr * 512 + ch * 8) = *reinterpret_cast<const f32x4*>(sW2 + rr * 128 + ch * 8);
+        }
     }
 }
 
@@ -574,9 +590,9 @@ extern "C" void kasf_debug_read_prof(long long* dst, int reset) {
 #endif
 
 void kasf_launch_mlp_bwd_s(hipStream_t s, const void* xn, const void* g, const void* W1, const float* b1, const void* W2ts, const void* W1t, void* dApart,
-                           float* p1, float* p2, float* db1, float* db1_rows, int64_t M, int tiles_per_range, int used) {
+                           void* p1, void* p2, float* db1, float* db1_rows, int64_t M, int tiles_per_range, int used) {
     const size_t sh = (size_t)(14 * TL) * sizeof(bf16);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_bwd_s), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     hipLaunchKernelGGL(k_mlp_bwd_s, dim3(4 * used), dim3(S_THR), sh, s, (const bf16*)xn, (const bf16*)g, (const bf16*)W1, b1, (const bf16*)W2ts,
-                       (const bf16*)W1t, (bf16*)dApart, p1, p2, db1, db1_rows, M, tiles_per_range);
+                       (const bf16*)W1t, (bf16*)dApart, (bf16*)p1, (bf16*)p2, db1, db1_rows, M, tiles_per_range);
 }

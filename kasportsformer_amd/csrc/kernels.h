@@ -97,7 +97,7 @@ inline int kasf_gcn_mask_words(int n_frames) { return n_frames <= 96 ? 3 : (n_fr
 void kasf_launch_mlp_fwd_s(hipStream_t s, const void* x, const float* ln_g, const float* ln_b, const void* W1, const float* b1, const void* W2,
                            const float* b2, const float* ls2, void* out, int64_t M, void* xn_out, unsigned grid);
 void kasf_launch_mlp_bwd_s(hipStream_t s, const void* xn, const void* g, const void* W1, const float* b1, const void* W2ts, const void* W1t, void* dApart,
-                           float* p1, float* p2, float* db1, float* db1_rows, int64_t M, int tiles_per_range, int used);
+                           void* p1, void* p2, float* db1, float* db1_rows, int64_t M, int tiles_per_range, int used);     // p1 / p2: bf16 partial tiles per token range
 
 // ---- k_attn.hip ----
 // mode 0: spatial (groups = B*T frames of 17 tokens), mode 1: temporal (groups = B*17 joint tracks of T tokens)
