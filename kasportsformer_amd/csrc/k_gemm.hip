@@ -448,7 +448,7 @@ __global__ __launch_bounds__(256) void k_wgrad_ring_jobs(const WgJobs js) {
 struct FinJob {
     const float* partial;
     float* out;               // [N][K] dense, accumulated into
-    int N, K, first;          // first workgroup; N*K/256 workgroups
+    int N, K, first;          // first workgroup; N workgroups (one per output row of K = 128 columns)
     const float *W, *bias, *ls;   // W != nullptr (K == 128): out += ls[n] * G, dls[n] += <W[n], G[n]> + bias[n] * colsum[n], db[n] += ls[n] * colsum[n]
     float *db, *dls;
     const float* brow;            // [splits][N] per-split column sums of G (colsum = their fixed-order sum)
@@ -464,7 +464,6 @@ struct FinJobs {
     FinRed r[2];
 };
 __global__ __launch_bounds__(256) void k_wgrad_finish_jobs(const FinJobs js) {
-    __shared__ f32x4 sPart[4][64];
     if (js.nred > 0 && (int)blockIdx.x >= js.r[0].first) {
         // ---- reduction role (round 4): a workgroup owns 128 consecutive elements (16 lanes x 8); its 16 lane groups each add every 16th partial tile,
         // the 16 sums meet in LDS and are added in a fixed tree: bitwise reproducible ----
@@ -509,54 +508,68 @@ __global__ __launch_bounds__(256) void k_wgrad_finish_jobs(const FinJobs js) {
     for (int q = 1; q < 3; ++q)
         if (q < js.n && (int)blockIdx.x >= js.j[q].first) ji = q;
     const FinJob& jb = js.j[ji];
-    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
-    const int64_t e = ((int64_t)(blockIdx.x - jb.first) * 64 + lane) * 4, stride = (int64_t)jb.N * jb.K;
-    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
-    int z = part;
-    for (; z + 4 < js.splits; z += 8) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(jb.partial + (int64_t)z * stride + e);
-        const f32x4 b = *reinterpret_cast<const f32x4*>(jb.partial + (int64_t)(z + 4) * stride + e);
+    // ---- one output ROW (K = 128 columns) per workgroup (round 4: was 256 outputs per workgroup with four waves taking every 4th split -- the proj job alone has
+    // 248 splits and 64 such workgroups: a 62-deep dependent load chain per wave, 14 us per launch).  16 lane groups take every 16th split, 16 lanes x 8 columns
+    // each; the 16 sums meet in LDS and are added in a fixed tree; threads 128..255 add the split rows of the bias gradient meanwhile. ----
+    __shared__ float sR[16][128];
+    __shared__ float sDot[4];
+    const int l = threadIdx.x & 15, zl = threadIdx.x >> 4, n = (int)blockIdx.x - jb.first;
+    const int64_t e = (int64_t)n * 128 + l * 8, stride = (int64_t)jb.N * jb.K;
+    float s0[8], s1[8];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { s0[q] += a[q]; s1[q] += b[q]; }
+    for (int k = 0; k < 8; ++k) { s0[k] = 0.f; s1[k] = 0.f; }
+    int z = zl;
+    for (; z + 16 < js.splits; z += 32) {
+        float a[8], b[8];
+        load8(jb.partial + (int64_t)z * stride + e, a);
+        load8(jb.partial + (int64_t)(z + 16) * stride + e, b);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { s0[k] += a[k]; s1[k] += b[k]; }
     }
     if (z < js.splits) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(jb.partial + (int64_t)z * stride + e);
+        float a[8];
+        load8(jb.partial + (int64_t)z * stride + e, a);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) s0[q] += a[q];
+        for (int k = 0; k < 8; ++k) s0[k] += a[k];
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) s0[q] += s1[q];
-    sPart[part][lane] = s0;
+    for (int k = 0; k < 8; ++k) sR[zl][l * 8 + k] = s0[k] + s1[k];
+    float gs = 0.f;                                      // colsum(g)[n] = fixed-order sum of the per-split rows (threads 128..255: two waves)
+    if (jb.W != nullptr && threadIdx.x >= 128) {
+        for (int z2 = threadIdx.x - 128; z2 < js.splits; z2 += 128) gs += jb.brow[(int64_t)z2 * jb.N + n];
+        gs = reduce64(gs);
+        if ((threadIdx.x & 63) == 0) sDot[2 + ((threadIdx.x - 128) >> 6)] = gs;
+    }
     __syncthreads();
-    if (part == 0) {
-        const f32x4 a = sPart[0][lane], b = sPart[1][lane], c = sPart[2][lane], d = sPart[3][lane];
-        f32x4 gsum;
+    float dot = 0.f;
+    if (threadIdx.x < 128) {
+        float t[16];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) gsum[q] = (a[q] + b[q]) + (c[q] + d[q]);
-        f32x4* o = reinterpret_cast<f32x4*>(jb.out + e);
-        f32x4 cur = *o;
-        if (jb.W != nullptr) {                           // K == 128: lanes 0..31 hold row 2b, lanes 32..63 row 2b+1
-            const int n = (int)(e / 128);
-            const f32x4 wv = *reinterpret_cast<const f32x4*>(jb.W + e);
-            float dot = wv[0] * gsum[0] + wv[1] * gsum[1] + wv[2] * gsum[2] + wv[3] * gsum[3];
+        for (int q = 0; q < 16; ++q) t[q] = sR[q][threadIdx.x];
 #pragma unroll
-            for (int m = 16; m >= 1; m >>= 1) dot += __shfl_xor(dot, m);
-            const float l = jb.ls[n];
+        for (int h = 8; h >= 1; h >>= 1)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) cur[q] += l * gsum[q];
-            float gs = 0.f;                              // colsum(g)[n]: the 32 lanes of this row add every 32nd split, then a fixed xor tree
-            for (int z2 = lane & 31; z2 < js.splits; z2 += 32) gs += jb.brow[(int64_t)z2 * jb.N + n];
-#pragma unroll
-            for (int m = 16; m >= 1; m >>= 1) gs += __shfl_xor(gs, m);
-            if ((lane & 31) == 0) {
-                jb.dls[n] += dot + jb.bias[n] * gs;
-                jb.db[n] += gs * l;
-            }
+            for (int q = 0; q < h; ++q) t[q] += t[q + h];
+        const float gsum = t[0];
+        float* o = jb.out + (int64_t)n * 128 + threadIdx.x;
+        if (jb.W != nullptr) {                           // proj: out += ls[n] G, and the row's share of dls
+            dot = jb.W[(int64_t)n * 128 + threadIdx.x] * gsum;
+            *o += jb.ls[n] * gsum;
         } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) cur[q] += gsum[q];
+            *o += gsum;
         }
-        *o = cur;
+        if (jb.W != nullptr) {
+            dot = reduce64(dot);
+            if ((threadIdx.x & 63) == 0) sDot[threadIdx.x >> 6] = dot;
+        }
+    }
+    if (jb.W != nullptr) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float g2 = sDot[2] + sDot[3], lsn = jb.ls[n];
+            jb.dls[n] += (sDot[0] + sDot[1]) + jb.bias[n] * g2;
+            jb.db[n] += g2 * lsn;
+        }
     }
 }
 
@@ -820,7 +833,7 @@ bool kasf_launch_wgrad_jobs(hipStream_t s, int njobs, const void* const* G, cons
         const bool fin = j == fin_job;
         fj.j[j] = FinJob{pp, dW[j], N[j], 128, ffirst, fin ? fin_W : nullptr, fin_bias, fin_ls, dbias[j], fin_dls, brow};
         first += (N[j] / 128) * splits;
-        ffirst += N[j] * 128 / 256;
+        ffirst += N[j];                                   // one finishing workgroup per output row
         pp += (int64_t)splits * N[j] * 128 + (brow != nullptr ? (int64_t)splits * N[j] : 0);
     }
     const size_t shr = (size_t)WR_ST * 2 * WR_BM * 128 * sizeof(bf16);
