@@ -305,7 +305,9 @@ __global__ __launch_bounds__(256) void k_wgrad(const T* __restrict__ G, int64_t 
 constexpr int WR_BM = 64, WR_ST = 2, WR_IPT = 8;      // rows per tile, ring stages, LDS-direct loads per tile per wave
 
 // One workgroup: the 128 x 128 tile (n0, k0) of split z.  N, K = full dimensions of the weight (partial tiles are laid out [z][N][K]).
-template <typename T>
+// BF16P (the jobs launch of the bf16 engine, round 4): the split's partial tile leaves as bf16, staged through the (dead) ring and stored as whole 256-byte rows
+// -- half the partial bytes of the step's 104 attention / bone blocks, and 8 wide stores per lane where the fp32 tile took 64 scattered 4-byte ones.
+template <typename T, bool BF16P = false>
 __device__ __forceinline__ void wgrad_ring_body(const T* __restrict__ G, int64_t ldg, const T* __restrict__ X, int64_t ldx, float* __restrict__ out,
                                                 int64_t ldo, float* __restrict__ dbias, int64_t M, int64_t slice, float* __restrict__ partial, float* __restrict__ brow,
                                                 int N, int K, int n0, int k0, int z) {
@@ -366,7 +368,21 @@ __device__ __forceinline__ void wgrad_ring_body(const T* __restrict__ G, int64_t
         __syncthreads();
         consume(st, st + WR_BM * 128);
     }
-    {
+    if constexpr (BF16P) {
+        const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+        __syncthreads();                                 // every wave is done with the ring
+        bf16* sT = reinterpret_cast<bf16*>(smem);        // [128][128] image of this split's tile
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sT[(wave_n0() + nt * 16 + g * 4 + r) * 128 + wave_m0() + kt * 16 + i] = (bf16)acc[nt][kt][r];
+        __syncthreads();
+        bf16* dstb = reinterpret_cast<bf16*>(partial) + (int64_t)z * N * K + (int64_t)n0 * K + k0;
+        for (int c = threadIdx.x; c < 128 * 16; c += 256)
+            *reinterpret_cast<f32x4*>(dstb + (int64_t)(c >> 4) * K + (c & 15) * 8) = *reinterpret_cast<const f32x4*>(sT + (c >> 4) * 128 + (c & 15) * 8);
+    } else {
         const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
         float* dst = partial != nullptr ? partial + (int64_t)z * N * K : out;
         const int64_t ld = partial != nullptr ? (int64_t)K : ldo;
@@ -442,7 +458,7 @@ __global__ __launch_bounds__(256) void k_wgrad_ring_jobs(const WgJobs js) {
             tile = r2 / rs;
         }
     }
-    wgrad_ring_body<bf16>(jb.G, jb.ldg, jb.X, jb.ldx, nullptr, 0, jb.dbias, js.M, js.slice, jb.partial, jb.brow, jb.N, jb.K, (tile / tiles_k) * 128,
+    wgrad_ring_body<bf16, true>(jb.G, jb.ldg, jb.X, jb.ldx, nullptr, 0, jb.dbias, js.M, js.slice, jb.partial, jb.brow, jb.N, jb.K, (tile / tiles_k) * 128,
                           (tile % tiles_k) * 128, z);
 }
 struct FinJob {
@@ -521,14 +537,14 @@ __global__ __launch_bounds__(256) void k_wgrad_finish_jobs(const FinJobs js) {
     int z = zl;
     for (; z + 16 < js.splits; z += 32) {
         float a[8], b[8];
-        load8(jb.partial + (int64_t)z * stride + e, a);
-        load8(jb.partial + (int64_t)(z + 16) * stride + e, b);
+        load8(reinterpret_cast<const bf16*>(jb.partial) + (int64_t)z * stride + e, a);           // (the jobs launch leaves bf16 tiles)
+        load8(reinterpret_cast<const bf16*>(jb.partial) + (int64_t)(z + 16) * stride + e, b);
 #pragma unroll
         for (int k = 0; k < 8; ++k) { s0[k] += a[k]; s1[k] += b[k]; }
     }
     if (z < js.splits) {
         float a[8];
-        load8(jb.partial + (int64_t)z * stride + e, a);
+        load8(reinterpret_cast<const bf16*>(jb.partial) + (int64_t)z * stride + e, a);
 #pragma unroll
         for (int k = 0; k < 8; ++k) s0[k] += a[k];
     }
