@@ -47,7 +47,10 @@ static bool single_stream() {
 }
 // The fused data + weight gradient launches leave one partial dW tile per WORKGROUP whatever the batch: a fixed 25-50 MB of partial traffic per block that only
 // pays for itself once the token stream is long enough (measured: T = 27, B = 256 -3 % per step; B = 32 +3 %): below this many tokens the two-kernel sequence runs.
-constexpr int64_t WG_FUSE_MIN_TOKENS = 40000;
+#ifndef KASF_WG_FUSE_MIN_TOKENS
+#define KASF_WG_FUSE_MIN_TOKENS 40000
+#endif
+constexpr int64_t WG_FUSE_MIN_TOKENS = KASF_WG_FUSE_MIN_TOKENS;
 constexpr int64_t WG_JOBS_FLOATS = 248 * 128 * 128 + 248 * 128 + 4096;   // the proj job alone: 248 splits of one 128 x 128 tile + their bias rows
 constexpr int64_t WG_BF16_BYTES = (int64_t)256 * 384 * 128 * 2;         // <= 256 bf16 partial tiles of the block's fused data + weight gradient launches (qkv: 384 rows; q + kv: 128 + 256)
 constexpr int64_t WG_PARTIAL_FLOATS = (KASF_MLP_PARTIAL_FLOATS + 65536 > WG_JOBS_FLOATS + WG_BF16_BYTES / 4 ? KASF_MLP_PARTIAL_FLOATS + 65536 : WG_JOBS_FLOATS + WG_BF16_BYTES / 4);   // per-split weight-gradient tiles (256 workgroups x 128x128, or 64 ranges x (dW1 + dW2) of the MLP) + the per-split rows of a bias gradient
