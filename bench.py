@@ -102,6 +102,7 @@ def _profile(name):
 
 TRAFFIC_FILE = _profile("pmc_traffic.json")            # tools/pmc_traffic.py (two --pmc passes over tools/mlp_bench.py)
 IN_STEP_STATS = _profile("train_kernel_stats.csv")     # rocprofv3 --kernel-trace --stats of tools/train_once.py 27 256 (three streams overlap)
+ISOLATED_STATS = _profile("single_stream_kernel_stats.csv")   # the same steps with the three branches on ONE stream (tools/prof27.sh): every launch alone on the chip
 STEP_TRAFFIC_FILE = _profile("pmc_step.json")          # tools/pmc_step.sh: FETCH_SIZE / WRITE_SIZE summed over whole training steps
 TRAFFIC_PARTS = {"k_mlp_fwd_s": {"k_mlp_fwd_s": 1}, "k_mlp_bwd_s(+lnbwd_sum4_fin)": {"k_mlp_bwd_s": 1, "k_lnbwd_sum4_fin": 1}}
 
@@ -117,14 +118,15 @@ def pmc_traffic(entry, M):
     return sum(ks[k]["hbm_bytes"] * n for k, n in TRAFFIC_PARTS[entry].items())
 
 
-def in_step_duration(kernel_names):
+def in_step_duration(kernel_names, stats_file=None):
     """Average in-step launch duration (seconds) of the named kernels from the committed kernel trace of whole training steps: there three
     streams overlap, so a launch shares the chip with the other two branches -- the honest figure next to the isolated micro-benchmark."""
     import csv
-    if not os.path.exists(IN_STEP_STATS):
+    stats_file = stats_file or IN_STEP_STATS
+    if not os.path.exists(stats_file):
         return None
     total = 0.0
-    for r in csv.DictReader(open(IN_STEP_STATS)):
+    for r in csv.DictReader(open(stats_file)):
         for k in kernel_names:
             if k + "(" in r["Name"] or k + "<" in r["Name"] or ("N_1" + str(len(k)) + k) in r["Name"]:
                 total += float(r["AverageNs"]) * 1e-9
@@ -373,6 +375,12 @@ def main():
                     out["roofline"]["in_step"] = {"launch_ms": t_in * 1e3, "achieved": ks[dom]["algorithmic_flop"] / t_in / 1e12,
                                                   "frac": ks[dom]["algorithmic_flop"] / t_in / 1e12 / PEAK_BF16_TFLOPS,
                                                   "source": "committed file profiles/" + os.path.basename(IN_STEP_STATS) + " (rocprofv3 --kernel-trace --stats -- python3 tools/train_once.py 27 256)"}
+                t_iso = in_step_duration(list(TRAFFIC_PARTS[dom]), ISOLATED_STATS)
+                if t_iso:                # ... and inside whole training steps run on ONE stream: alone on the chip, between the step's memory-bound launches instead of in a hot loop of itself
+                    out["roofline"]["in_step_single_stream"] = {"launch_ms": t_iso * 1e3, "achieved": ks[dom]["algorithmic_flop"] / t_iso / 1e12,
+                                                                "frac": ks[dom]["algorithmic_flop"] / t_iso / 1e12 / PEAK_BF16_TFLOPS,
+                                                                "source": "committed file profiles/" + os.path.basename(ISOLATED_STATS) + " (KASF_SINGLE_STREAM=1 rocprofv3 --kernel-trace --stats -- python3 tools/train_once.py 27 256); "
+                                                                          "the event-timed figure above is a back-to-back loop of this chain alone, where the same two kernels take longer per launch (profiles/r4_mlp_microbench_kernel_stats.csv)"}
             if os.path.exists(STEP_TRAFFIC_FILE) and args.batch == BATCH_PER_GPU:
                 out["step_hbm_GB"] = json.load(open(STEP_TRAFFIC_FILE))["hbm_GB_per_step"]
                 out["step_hbm_GB_source"] = "committed file profiles/" + os.path.basename(STEP_TRAFFIC_FILE)
