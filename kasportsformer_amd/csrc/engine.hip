@@ -52,7 +52,7 @@ static bool single_stream() {
 #endif
 constexpr int64_t WG_FUSE_MIN_TOKENS = KASF_WG_FUSE_MIN_TOKENS;
 constexpr int64_t WG_JOBS_FLOATS = 248 * 128 * 128 + 248 * 128 + 4096;   // the proj job alone: 248 splits of one 128 x 128 tile + their bias rows
-constexpr int64_t WG_BF16_BYTES = (int64_t)256 * 384 * 128 * 2;         // <= 256 bf16 partial tiles of the block's fused data + weight gradient launches (qkv: 384 rows; q + kv: 128 + 256)
+constexpr int64_t WG_BF16_BYTES = (int64_t)256 * 384 * 128 * 2 + (int64_t)256 * 128 * 128 * 2 + 256 * 128 * 4;         // <= 256 bf16 partial tiles of the block's fused data + weight gradient launches (qkv: 384 rows; q + kv: 128 + 256)
 constexpr int64_t WG_PARTIAL_FLOATS = (KASF_MLP_PARTIAL_FLOATS + 65536 > WG_JOBS_FLOATS + WG_BF16_BYTES / 4 ? KASF_MLP_PARTIAL_FLOATS + 65536 : WG_JOBS_FLOATS + WG_BF16_BYTES / 4);   // per-split weight-gradient tiles (256 workgroups x 128x128, or 64 ranges x (dW1 + dW2) of the MLP) + the per-split rows of a bias gradient
 
 struct BlkWs { int64_t qkv, kv, o, xn, y, mask, x_mid, xn2, x_out, stats, bstats, coef, lse; };
@@ -504,16 +504,22 @@ void block_backward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void*
         KasfBf16Reduce red[2];
         int nred = 0;
         char* wpart = (char*)(part + WG_JOBS_FLOATS);
+        bool proj_fused = false;
         if (jobs && c.M >= WG_FUSE_MIN_TOKENS) {
-            const int64_t qb = (int64_t)256 * 128 * 128 * 2;
+            // q: data gradient + dW_q + the block's PROJ gradient (g_mid is its residual operand, o one more ring stream); kv: data gradient + dW_kv.  No streaming
+            // weight-gradient launch in this block at all: one finish launch adds the three sets of bf16 partial tiles.
+            const int64_t qb = (int64_t)256 * 128 * 128 * 2, kvb = (int64_t)256 * 256 * 128 * 2;
+            char* ppart = wpart + qb + kvb;                                  // <= 256 bf16 proj tiles (8.4 MB) ...
+            float* pbrow = (float*)(ppart + qb);                             // ... and their colsum(g_mid) rows
             const int npq = kasf_launch_dgrad_wg(c.s, dq, 128, c.pk(o.p_mixT), x_in, P + o.n1w, P + o.n1b, g_mid, dst, accumulate, G + o.n1w, G + o.n1b, c.M, c.sink,
-                                                 wpart, qb);
+                                                 wpart, qb, nullptr, nullptr, c.w(w.o), ppart, pbrow);
             const int npk = npq > 0 ? kasf_launch_dgrad_wg(c.s, dkv, 256, c.pk(o.p_kvT), x_limb, P + o.n1lw, P + o.n1lb, nullptr, c.w(p.g_limb), 1, G + o.n1lw,
-                                                           G + o.n1lb, c.M, c.sink, wpart + qb, WG_BF16_BYTES - qb) : 0;
+                                                           G + o.n1lb, c.M, c.sink, wpart + qb, kvb) : 0;
             if (npq > 0 && npk > 0) {
-                fusedwg = true;
+                fusedwg = proj_fused = true;
                 red[nred++] = KasfBf16Reduce{wpart, G + o.mix_w, npq, 128 * 128};
                 red[nred++] = KasfBf16Reduce{wpart + qb, G + o.kv_w, npk, 256 * 128};
+                kasf_launch_proj_finish(c.s, ppart, pbrow, npq, G + o.proj_w, P + o.proj_w, P + o.proj_b, P + o.ls1, G + o.proj_b, G + o.ls1, nred, red);
             }
         }
         if (!fusedwg) {
@@ -522,8 +528,8 @@ void block_backward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void*
             kasf_launch_dgrad_lnbwd(c.dt, c.s, dkv, 256, c.pk(o.p_kvT), nullptr, x_limb, P + o.n1lw, nullptr, c.w(p.g_limb), 1, G + o.n1lw, G + o.n1lb, c.M,
                                     c.w(sc.xn_b), P + o.n1lb, c.sink);
         }
-        bool done = false;
-        if (jobs) {
+        bool done = proj_fused;
+        if (jobs && !proj_fused) {
             const void* Gs[3] = {g_mid, dq, dkv};
             const void* Xs[3] = {c.w(w.o), c.w(sc.xn_a), c.w(sc.xn_b)};
             const int Ns[3] = {128, 128, 256};

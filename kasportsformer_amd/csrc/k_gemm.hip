@@ -803,6 +803,22 @@ void kasf_launch_pack(int dt, hipStream_t s, const float* params, void* arena, c
     else hipLaunchKernelGGL(k_pack<bf16>, dim3(total_tiles), dim3(256), 0, s, params, (bf16*)arena, desc, tile_start, ndesc);
 }
 
+// The finish launch of a block whose proj gradient came out of a fused data-gradient kernel (no streaming jobs launch): the proj job's fixed-order sum + layer-scale
+// algebra over `nparts` bf16 tiles and bias rows, and the block's other bf16 partial-tile reductions, in one launch.
+void kasf_launch_proj_finish(hipStream_t s, const void* proj_part, const float* proj_brow, int nparts, float* dW, const float* W, const float* bias, const float* ls,
+                             float* db, float* dls, int nred, const KasfBf16Reduce* red) {
+    if (nparts < 1 || nred < 0 || nred > 2) return;
+    FinJobs fj;
+    fj.n = 1; fj.splits = nparts; fj.nred = nred;
+    fj.j[0] = FinJob{(const float*)proj_part, dW, 128, 128, 0, W, bias, ls, db, dls, proj_brow};
+    int first = 128;
+    for (int k = 0; k < nred; ++k) {
+        fj.r[k] = FinRed{(const bf16*)red[k].part, red[k].out, red[k].nparts, red[k].elems, first};
+        first += red[k].elems / 128;
+    }
+    hipLaunchKernelGGL(k_wgrad_finish_jobs, dim3(first), dim3(256), 0, s, fj);
+}
+
 void kasf_launch_bf16_reduce(hipStream_t s, int nred, const KasfBf16Reduce* red) {
     if (nred < 1 || nred > 2) return;
     FinJobs fj;

@@ -29,19 +29,25 @@ __device__ __forceinline__ bf16x8 tok_frag(const bf16* s, int row, int ks) {
 // [16 KC w, +16 KC) of dW in 8 KC accumulator registers for the whole token range and leaves ONE bf16 partial tile per workgroup (fixed-order finish).
 // BIAS (with WG; the GCN's U | V linear has one): the bias gradient = column sums of dY over the tokens, accumulated from the ring tile by the LayerNorm-backward
 // phase's (row, 8-column) threads and left as 128 KC more columns of the workgroup's row in `part`.
-template <int KC, bool RESID, bool ADD, bool ACC, bool XN, int RING, bool WG = false, bool BIAS = false>
+// PROJ (with WG and RESID; the bone block's q linear): the block's OUTPUT-PROJECTION weight gradient G = g_mid^T . o rides here as well -- g_mid is this
+// kernel's residual operand, the attention output o arrives as one more ring stream -- with the column sums of g_mid (the proj bias / layer-scale terms);
+// the block then has no streaming weight-gradient launch at all, and o and g_mid are not read a second time.
+template <int KC, bool RESID, bool ADD, bool ACC, bool XN, int RING, bool WG = false, bool BIAS = false, bool PROJ = false>
 __global__ __launch_bounds__(R_THR) void k_dgrad_r(const bf16* __restrict__ dY, const bf16* __restrict__ Wt, const bf16* __restrict__ dxn_add,
                                                    const bf16* __restrict__ X, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                    const bf16* __restrict__ resid, bf16* __restrict__ out, float* __restrict__ dgamma,
                                                    float* __restrict__ dbeta, bf16* __restrict__ xn_out, int64_t M, float* __restrict__ part,
-                                                   bf16* __restrict__ wpart, float* __restrict__ dbias) {
+                                                   bf16* __restrict__ wpart, float* __restrict__ dbias, const bf16* __restrict__ Oin,
+                                                   bf16* __restrict__ ppart, float* __restrict__ pbrow) {
     static_assert(!WG || XN, "the fused weight gradient multiplies by LN(x)");
+    static_assert(!PROJ || (WG && RESID), "the proj gradient multiplies the residual operand g_mid by o");
     static_assert(!BIAS || WG, "the bias gradient rides with the fused weight gradient");
     constexpr int PLD = 256 + (BIAS ? 128 * KC : 0);    // floats per workgroup row of `part`: dgamma | dbeta [| dbias]
     constexpr int Kd = 128 * KC;
-    constexpr int NSTREAM = KC + 1 + (RESID ? 1 : 0) + (ADD ? 1 : 0) + (ACC ? 1 : 0);     // LDS-direct loads per wave per tile
+    constexpr int NSTREAM = KC + 1 + (RESID ? 1 : 0) + (ADD ? 1 : 0) + (ACC ? 1 : 0) + (PROJ ? 1 : 0);     // LDS-direct loads per wave per tile
     constexpr int SLOT = NSTREAM * R_TILE;
     constexpr int O_X = KC * R_TILE, O_RES = O_X + R_TILE, O_ADD = O_RES + (RESID ? R_TILE : 0), O_ACC = O_ADD + (ADD ? R_TILE : 0);
+    constexpr int O_O = O_ACC + (ACC ? R_TILE : 0);     // PROJ: the attention output rows
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* sRing = reinterpret_cast<bf16*>(smem);        // [RING][SLOT]
     bf16* sD = sRing + RING * SLOT;                     // [32][128] dxn of the current tile
@@ -74,6 +80,12 @@ __global__ __launch_bounds__(R_THR) void k_dgrad_r(const bf16* __restrict__ dY, 
     for (int kc = 0; kc < (BIAS ? KC : 1); ++kc)
 #pragma unroll
         for (int e = 0; e < 8; ++e) dbs[kc][e] = 0.f;
+    f32x4 accP[PROJ ? 8 : 1];                            // PROJ: rows [16 w, +16) of G = g_mid^T . o
+    float gcol[8];                                       // PROJ: column sums of g_mid (this thread's 8 columns over its rows)
+#pragma unroll
+    for (int b = 0; b < (PROJ ? 8 : 1); ++b) accP[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) gcol[e] = 0.f;
     auto wgrad_tile = [&](const bf16* slot_prev, const bf16* xnT) {      // dW rows [16 KC w, +16 KC) += dY(tile)^T . LN(x)(tile): one k-step of 32 tokens
         bf16x8 ra[WG ? KC : 1];
 #pragma unroll
@@ -86,6 +98,11 @@ __global__ __launch_bounds__(R_THR) void k_dgrad_r(const bf16* __restrict__ dY, 
             const bf16x8 cb = frag_tr(xnT, 8 * g, 16 * b);
 #pragma unroll
             for (int a = 0; a < (WG ? KC : 0); ++a) accW[a][b] = mfma16(ra[a], cb, accW[a][b]);
+        }
+        if (PROJ) {
+            const bf16x8 rp = frag_tr(slot_prev + O_RES, 8 * g, 16 * w);
+#pragma unroll
+            for (int b = 0; b < (PROJ ? 8 : 0); ++b) accP[b] = mfma16(rp, frag_tr(slot_prev + O_O, 8 * g, 16 * b), accP[b]);
         }
     };
     auto nxr = [](int sl) { return sl == RING - 1 ? 0 : sl + 1; };   // ring slots roll (no 64-bit modulo in the loop)
@@ -100,6 +117,7 @@ __global__ __launch_bounds__(R_THR) void k_dgrad_r(const bf16* __restrict__ dY, 
         if (RESID) stage_tile_async<bf16, R_BM, R_THR>(slot + O_RES, resid + row0 * 128, 128, nvalid);
         if (ADD) stage_tile_async<bf16, R_BM, R_THR>(slot + O_ADD, dxn_add + row0 * 128, 128, nvalid);
         if (ACC) stage_tile_async<bf16, R_BM, R_THR>(slot + O_ACC, out + row0 * 128, 128, nvalid);
+        if (PROJ) stage_tile_async<bf16, R_BM, R_THR>(slot + O_O, Oin + row0 * 128, 128, nvalid);
     };
     issue(0, 0);
     if (RING == 3) { issue(1, 1); wait_async_le<NSTREAM>(); }   // tile 0 landed, tile 1 in flight
@@ -180,6 +198,15 @@ __global__ __launch_bounds__(R_THR) void k_dgrad_r(const bf16* __restrict__ dY, 
                 tile_load8(slot + O_RES, rl, sub * 8, a);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] += a[e];
+                if (PROJ) {
+                    if (live) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) gcol[e] += a[e];
+                    } else {                             // a clamped copy of the last row: its o row must not reach G (this tile's slot is multiplied next iteration)
+                        const float z8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        tile_store8(const_cast<bf16*>(slot) + O_O, rl, sub * 8, z8);
+                    }
+                }
             }
             if (ACC) {
                 float a[8];
@@ -246,6 +273,18 @@ __global__ __launch_bounds__(R_THR) void k_dgrad_r(const bf16* __restrict__ dY, 
             }
         }
     }
+    if (PROJ) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sRed[rl * 128 + sub * 8 + e] = gcol[e];
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            float sb = 0.f;
+#pragma unroll 8
+            for (int k = 0; k < 32; ++k) sb += sRed[k * 128 + threadIdx.x];
+            pbrow[(int64_t)blockIdx.x * 128 + threadIdx.x] = sb;             // one row of colsum(g_mid) per workgroup: the finish launch's `brow`
+        }
+    }
     if (WG) {
         // this workgroup's partial dW tile: accumulators -> bf16 image [128 KC][128] in the dead ring -> whole 256-byte rows out (16 bytes per lane)
         __syncthreads();
@@ -257,22 +296,35 @@ __global__ __launch_bounds__(R_THR) void k_dgrad_r(const bf16* __restrict__ dY, 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) sW[(16 * KC * w + 16 * a + 4 * g + r) * 128 + 16 * b + i] = (bf16)accW[a][b][r];
         __syncthreads();
+        bf16* sWp = sW + 128 * KC * 128;                 // PROJ: the [128][128] tile of G behind it
+        if (PROJ) {
+#pragma unroll
+            for (int b = 0; b < (PROJ ? 8 : 0); ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sWp[(16 * w + 4 * g + r) * 128 + 16 * b + i] = (bf16)accP[b][r];
+        }
+        __syncthreads();
         bf16* dst = wpart + (int64_t)blockIdx.x * (128 * KC * 128);
         for (int c = threadIdx.x; c < 128 * KC * 16; c += R_THR) *reinterpret_cast<f32x4*>(dst + c * 8) = *reinterpret_cast<const f32x4*>(sW + c * 8);
+        if (PROJ) {
+            bf16* dstp = ppart + (int64_t)blockIdx.x * (128 * 128);
+            for (int c = threadIdx.x; c < 128 * 16; c += R_THR) *reinterpret_cast<f32x4*>(dstp + c * 8) = *reinterpret_cast<const f32x4*>(sWp + c * 8);
+        }
     }
 }
 
-template <int KC, bool RESID, bool ADD, bool ACC, bool XN, bool WG = false, bool BIAS = false>
+template <int KC, bool RESID, bool ADD, bool ACC, bool XN, bool WG = false, bool BIAS = false, bool PROJ = false>
 int launch_dgrad_r(hipStream_t s, const void* dY, const void* Wt, const void* add, const void* X, const float* gamma, const float* beta, const void* resid,
-                   void* out, float* dgamma, float* dbeta, void* xn_out, int64_t M, KasfColSink* sink, void* wpart = nullptr, float* dbias = nullptr) {
+                   void* out, float* dgamma, float* dbeta, void* xn_out, int64_t M, KasfColSink* sink, void* wpart = nullptr, float* dbias = nullptr,
+                   const void* o_in = nullptr, void* ppart = nullptr, float* pbrow = nullptr) {
     constexpr int PLD = 256 + (BIAS ? 128 * KC : 0);
-    constexpr int NSTREAM = KC + 1 + (RESID ? 1 : 0) + (ADD ? 1 : 0) + (ACC ? 1 : 0);
+    constexpr int NSTREAM = KC + 1 + (RESID ? 1 : 0) + (ADD ? 1 : 0) + (ACC ? 1 : 0) + (PROJ ? 1 : 0);
     constexpr size_t fixed = (size_t)R_TILE * 2 * (WG ? 3 : 1) + (WG ? 1024 : 0);                         // sD (+ the two LN(x) tiles of the fused weight gradient); the end-of-kernel reductions reuse the ring: >= 32 KB
     constexpr bool ring3 = 3 * NSTREAM * R_TILE * 2 + fixed <= 160 * 1024;
     constexpr int RING = ring3 ? 3 : 2;
-    static_assert(!WG || RING * NSTREAM >= 4 * KC, "the partial weight-gradient tile is staged in the ring");
+    static_assert(!WG || RING * NSTREAM >= 4 * (KC + (PROJ ? 1 : 0)), "the partial weight-gradient tiles are staged in the ring");
     const size_t sh = (size_t)RING * NSTREAM * R_TILE * 2 + fixed;
-    auto kern = k_dgrad_r<KC, RESID, ADD, ACC, XN, RING, WG, BIAS>;
+    auto kern = k_dgrad_r<KC, RESID, ADD, ACC, XN, RING, WG, BIAS, PROJ>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     const int64_t tiles = (M + R_BM - 1) / R_BM;
     const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
@@ -280,7 +332,7 @@ int launch_dgrad_r(hipStream_t s, const void* dY, const void* Wt, const void* ad
     const int active = (int)((tiles + per - 1) / per);                                  // workgroups that own at least one tile (the others return at once)
     float* part = sink != nullptr ? sink->take(active, PLD) : nullptr;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(R_THR), sh, s, (const bf16*)dY, (const bf16*)Wt, (const bf16*)add, (const bf16*)X, gamma, beta,
-                       (const bf16*)resid, (bf16*)out, dgamma, dbeta, (bf16*)xn_out, M, part, (bf16*)wpart, dbias);
+                       (const bf16*)resid, (bf16*)out, dgamma, dbeta, (bf16*)xn_out, M, part, (bf16*)wpart, dbias, (const bf16*)o_in, (bf16*)ppart, pbrow);
     if (part != nullptr) {
         sink->add(part, PLD, active, 128, dgamma);
         sink->add(part + 128, PLD, active, 128, dbeta);
@@ -435,9 +487,15 @@ bool kasf_launch_dgrad_r(hipStream_t s, const void* dY, int Kd, const void* Wt, 
 // (KasfBf16Reduce).  Returns 0 for combinations that are not instantiated (the caller runs the two-kernel sequence).
 int kasf_launch_dgrad_wg(hipStream_t s, const void* dY, int Kd, const void* Wt, const void* X, const float* gamma, const float* beta, const void* resid, void* out,
                          int accumulate, float* dgamma, float* dbeta, int64_t M, KasfColSink* sink, void* wpart, int64_t wpart_bytes, const void* dxn_add,
-                         float* dbias) {
+                         float* dbias, const void* proj_o, void* proj_part, float* proj_brow) {
     if (M <= 0 || wpart == nullptr || wpart_bytes < (int64_t)256 * Kd * 128 * 2) return 0;
     const bool R = resid != nullptr, C = accumulate != 0;
+    if (proj_o != nullptr) {                             // the bone block's q linear carrying the block's proj weight gradient: g_mid (= resid) ^T . o
+        if (Kd == 128 && R && !C && dxn_add == nullptr && dbias == nullptr && proj_part != nullptr && proj_brow != nullptr)
+            return launch_dgrad_r<1, true, false, false, true, true, false, true>(s, dY, Wt, nullptr, X, gamma, beta, resid, out, dgamma, dbeta, nullptr, M, sink, wpart,
+                                                                                  nullptr, proj_o, proj_part, proj_brow);
+        return 0;
+    }
     if (dxn_add != nullptr || dbias != nullptr) {        // the GCN's U | V linear: direct LN(x) gradient added in, bias gradient = column sums of dY
         if (Kd == 256 && R && !C && dxn_add != nullptr && dbias != nullptr)
             return launch_dgrad_r<2, true, true, false, true, true, true>(s, dY, Wt, dxn_add, X, gamma, beta, resid, out, dgamma, dbeta, nullptr, M, sink, wpart, dbias);

@@ -170,7 +170,11 @@ void kasf_launch_gather_clips(hipStream_t s, const float* xa, const float* ya, c
 struct KasfBf16Reduce { const void* part; float* out; int nparts; int elems; };
 int kasf_launch_dgrad_wg(hipStream_t s, const void* dY, int Kd, const void* Wt, const void* X, const float* gamma, const float* beta, const void* resid, void* out,
                          int accumulate, float* dgamma, float* dbeta, int64_t M, KasfColSink* sink, void* wpart, int64_t wpart_bytes, const void* dxn_add = nullptr,
-                         float* dbias = nullptr);
+                         float* dbias = nullptr, const void* proj_o = nullptr, void* proj_part = nullptr, float* proj_brow = nullptr);
+// proj_o (bone q linear, Kd = 128): the block's output-projection gradient G = resid^T . proj_o rides along: <= 256 bf16 tiles of 128 x 128 in proj_part and one
+// fp32 row of colsum(resid) per tile in proj_brow, in the layout kasf_launch_proj_finish adds up
+void kasf_launch_proj_finish(hipStream_t s, const void* proj_part, const float* proj_brow, int nparts, float* dW, const float* W, const float* bias, const float* ls,
+                             float* db, float* dls, int nred, const KasfBf16Reduce* red);
 void kasf_launch_bf16_reduce(hipStream_t s, int nred, const KasfBf16Reduce* red);      // the fixed-order sum of such partial tiles on its own (no streaming jobs in the block)
 bool kasf_launch_dgrad_r(hipStream_t s, const void* dY, int Kd, const void* Wt, const void* dxn_add, const void* X, const float* gamma, const void* resid,
                          void* out, int accumulate, float* dgamma, float* dbeta, int64_t M, void* xn_out, const float* beta, KasfColSink* sink = nullptr);

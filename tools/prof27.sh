@@ -10,6 +10,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/prof${T}s -o t --output
 cd $R && python - <<PY
 import csv
 rows=list(csv.DictReader(open("$O/prof${T}s/t_kernel_stats.csv")))
+rows=[r for r in rows if 'rocclr_copyBuffer' not in r['Name']]     # the constructor's per-parameter copies into the flat array (setup, not the step)
 tot=sum(float(r['TotalDurationNs']) for r in rows)/3e6
 print(f"sum of kernel time per step (single stream): {tot:.2f} ms")
 for r in sorted(rows,key=lambda r:-float(r['TotalDurationNs']))[:40]:
