@@ -306,6 +306,261 @@ __global__ __launch_bounds__(AB_THR, BONE ? KASF_RP_BONE_WAVES : 4) void k_attn_
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Spatial blocks (a group = the 17 joints of one frame) in FLAT 32-token tiles (round 4).  The one-tile form above spends a 32-row tile on 17 rows:
+// 47 % of its LayerNorm, projection, epilogue and copy-out work -- 80 % of the kernel by its phase timers, the 32 x 32 attention core is the
+// other 20 % -- is padding.  The frames of a launch are consecutive in memory (token = 17 frame + joint), so a workgroup's frame range is one dense
+// token range: it is walked in 32-token tiles regardless of frame boundaries, and only the core keeps the frame structure:
+//   * the wave-private q | k | v tiles are rolling buffers of 48 positions (tile t's 32 rows + the <= 16 rows of a frame that began in tile t - 1);
+//     after tile t's projection a wave runs the core of every frame that ends inside the tile (one or two), reading its 17 rows at a rolling offset;
+//   * head outputs and raw x (the residual's operand) are kept per tile parity; the output projection of tile t - 1 runs one iteration late, when
+//     the frame that straddles the tile border has been through the core;
+//   * keys past 16 are dead: the softmax touches 9 of the 16 score registers (as k_attn_bwd_pers<9>).
+// Same three barriers per iteration, 17 / 32 as many iterations.  LDS 79 KB (self: two workgroups per CU) / 87 KB (bone).
+// ---------------------------------------------------------------------------------------------------------------
+template <bool BONE>
+__global__ __launch_bounds__(AB_THR, BONE ? KASF_RP_BONE_WAVES : 4) void k_attn_blk_fwd_flat(const AttnBlkArgs a) {
+    constexpr int NS = BONE ? 2 : 1, J = KASF_J, HB = 48, HT = HB * 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* sX = reinterpret_cast<bf16*>(smem);           // [2][32][128] raw x, by tile parity
+    bf16* sA = sX + 2 * AB_TILE;                        // [NS][32][128] LN(x) (| LN_limb(x_limb)); sA[0] doubles as the x_mid staging tile
+    bf16* sO = sA + NS * AB_TILE;                       // [2][32][128] attention output of the 8 heads, by tile parity (row p at p & 63)
+    bf16* sHead = sO + 2 * AB_TILE;                     // [8 waves][q | k | v][48][16] wave-private rolling operand tiles
+    float* sLn = reinterpret_cast<float*>(sHead + 8 * 3 * HT);       // [6][128] gamma, beta, limb gamma, beta, proj bias, ls1
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4, sub = lane & 15, rl = threadIdx.x >> 4;
+    const int r32 = lane & 31, hh = lane >> 5;
+    const int per = (a.groups + gridDim.x - 1) / gridDim.x;
+    const int f0 = blockIdx.x * per;
+    int nf = a.groups - f0;
+    if (nf > per) nf = per;
+    if (nf <= 0) return;
+    const int nrows = J * nf, ntiles = (nrows + 31) >> 5;
+    const unsigned tok0 = (unsigned)f0 * J;
+    bf16* sQh = sHead + w * 3 * HT;
+    bf16* sKh = sQh + HT;
+    bf16* sVh = sKh + HT;
+    bf16x8 wq[3][4], wp[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        if (BONE) {
+            wq[0][ks] = *reinterpret_cast<const bf16x8*>(a.Wq + (int64_t)(16 * w + i) * 128 + 32 * ks + 8 * g);
+            wq[1][ks] = *reinterpret_cast<const bf16x8*>(a.Wkv + (int64_t)(16 * w + i) * 128 + 32 * ks + 8 * g);
+            wq[2][ks] = *reinterpret_cast<const bf16x8*>(a.Wkv + (int64_t)(128 + 16 * w + i) * 128 + 32 * ks + 8 * g);
+        } else {
+#pragma unroll
+            for (int nt = 0; nt < 3; ++nt) wq[nt][ks] = *reinterpret_cast<const bf16x8*>(a.Wq + (int64_t)(128 * nt + 16 * w + i) * 128 + 32 * ks + 8 * g);
+        }
+        wp[ks] = *reinterpret_cast<const bf16x8*>(a.Wproj + (int64_t)(16 * w + i) * 128 + 32 * ks + 8 * g);
+    }
+    if (threadIdx.x < 128) {
+        sLn[threadIdx.x] = a.ln_g[threadIdx.x];
+        sLn[128 + threadIdx.x] = a.ln_b[threadIdx.x];
+        if (BONE) { sLn[256 + threadIdx.x] = a.lnl_g[threadIdx.x]; sLn[384 + threadIdx.x] = a.lnl_b[threadIdx.x]; }
+        sLn[512 + threadIdx.x] = a.bproj[threadIdx.x];
+        sLn[640 + threadIdx.x] = a.ls1[threadIdx.x];
+    }
+    {   // the rolling tiles start finite: a frame's core reads 32 rows of them, 15 of which belong to the neighbouring frames (their scores are masked by
+        // selects, their V rows are multiplied by zero probabilities)
+        const bf16x8 zero = {};
+        for (int c = lane; c < 3 * HT / 8; c += 64) *reinterpret_cast<bf16x8*>(sQh + c * 8) = zero;
+    }
+    bf16x8 xN, lN;
+    auto fetch = [&](int t) {
+        int p = 32 * t + rl;
+        p = p < nrows ? p : nrows - 1;                   // rows past the range: clamped load, zeroed at the point of use
+        const unsigned b = (tok0 + (unsigned)p) * 128u + sub * 8;
+        xN = *reinterpret_cast<const bf16x8*>(a.X + (size_t)b);
+        if (BONE) lN = *reinterpret_cast<const bf16x8*>(a.XL + (size_t)b);
+    };
+    auto layernorm = [&](const bf16x8 raw, bf16* dst, const float* gp, const float* bp) {      // row rl from registers; gp/bp in LDS
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (float)raw[e];
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[e];
+        const float mean = reduce16(s) * (1.0f / 128.0f);
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { v[e] -= mean; q = __builtin_fmaf(v[e], v[e], q); }
+        const float rstd = rsqrtf(reduce16(q) * (1.0f / 128.0f) + KASF_LN_EPS);
+        const f32x4 g0v = *reinterpret_cast<const f32x4*>(gp + sub * 8), g1v = *reinterpret_cast<const f32x4*>(gp + sub * 8 + 4);
+        const f32x4 b0v = *reinterpret_cast<const f32x4*>(bp + sub * 8), b1v = *reinterpret_cast<const f32x4*>(bp + sub * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = __builtin_fmaf(v[e], rstd * g0v[e], b0v[e]); v[4 + e] = __builtin_fmaf(v[4 + e], rstd * g1v[e], b1v[e]); }
+        tile_store8(dst, rl, sub * 8, v);
+    };
+    auto wrap = [](int r) { return r >= HB ? r - HB : r; };
+    auto core = [&](int j, int sm, int lv) {            // frame j of the range: its rows sit at rolling offset sm = (17 j) mod 48 of the wave's tiles
+        const int r32 = lv & 31, hh = lv >> 5;           // (lv: the lane id behind an optimisation barrier -- the addresses below are recomputed per tile instead of
+                                                         //  living in registers across the loop: the self form has none to spare at two workgroups per CU)
+        const int row = wrap(sm + r32);
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sKh + row * 16 + 8 * hh);
+        const bf16x8 qf = *reinterpret_cast<const bf16x8*>(sQh + row * 16 + 8 * hh);
+        f32x16 z;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) z[e] = 0.f;
+        f32x16 st = mfma32(kf, qf, z);                   // S^T[key][query]; register e holds key pos_of(e, hh): keys 0..15 in registers 0..7, key 16 in register 8 of half 0
+        st[8] = hh == 0 ? st[8] : -INFINITY;
+        float mx = st[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mx = fmaxf(mx, st[e]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        constexpr float C2 = 0.25f * 1.4426950408889634f;     // scale . log2(e)
+        const float nm = -mx * C2;
+        float sum = 0.f;
+#pragma unroll
+        for (int e = 0; e < 9; ++e) { st[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[e], C2, nm)); sum += st[e]; }
+#pragma unroll
+        for (int e = 9; e < 16; ++e) st[e] = 0.f;
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.0f / sum;
+        auto vfrag = [&](int ks) {                       // tr_frag at the rolling offset
+            const int u = lv & 15, q = u >> 2, p = u & 3, k0 = 16 * ks + 4 * hh;
+            typedef __attribute__((address_space(3))) bf16x4 lds_v4;
+            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)(sVh + wrap(sm + k0 + q) * 16 + 4 * p));
+            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)(sVh + wrap(sm + k0 + 8 + q) * 16 + 4 * p));
+            return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        };
+        f32x16 ot = mfma32(vfrag(0), pack8(st, 0), z);
+        ot = mfma32(vfrag(1), pack8(st, 1), ot);
+        if (r32 < J) {                                   // queries past 16 belong to the next frame
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ot[e] *= inv;
+            float o0[4] = {ot[0], ot[1], ot[2], ot[3]}, o1[4] = {ot[4], ot[5], ot[6], ot[7]};
+            const int prow = (J * j + r32) & 63;
+            store4(sO + Tile<bf16>::off4(prow, 16 * w + 4 * hh), o0);
+            store4(sO + Tile<bf16>::off4(prow, 16 * w + 8 + 4 * hh), o1);
+        }
+    };
+    fetch(0);
+    __syncthreads();                                     // sLn
+    int nfr = 0, sm = 0;                                 // next frame for the core, its rolling offset
+    for (int t = 0; t <= ntiles; ++t) {
+        const int par = t & 1;
+        int lv = lane;
+        asm volatile("" : "+v"(lv));
+        if (t < ntiles) {
+            const bf16x8 zero = {};
+            const bool live = 32 * t + rl < nrows;
+            const bf16x8 xc = live ? xN : zero;
+            *reinterpret_cast<bf16x8*>(sX + par * AB_TILE + Tile<bf16>::chunk_off(rl, sub)) = xc;
+            layernorm(xc, sA, sLn, sLn + 128);
+            if (BONE) layernorm(live ? lN : zero, sA + AB_TILE, sLn + 256, sLn + 384);
+        }
+        __syncthreads();                                 // B1: raw and LN tiles complete; every wave finished the copy-out of the previous tile
+        if (t < ntiles) {
+            const int hb = (2 * t) % 3;                  // tile t's rows start at rolling row 16 hb = (32 t) mod 48; a 16-row block never straddles the wrap
+            auto blk = [&](int mt) { const int b = hb + mt; return (b >= 3 ? b - 3 : b) * 16; };
+            if (BONE) {   // ---- q_h from LN(x), then k_h, v_h from LN_limb(x_limb): two phases keep the live accumulators + operand fragments under the register cap ----
+                {
+                    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        acc[0] = mfma16(wq[0][ks], tok_frag(sA, i, ks), acc[0]);
+                        acc[1] = mfma16(wq[0][ks], tok_frag(sA, 16 + i, ks), acc[1]);
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        float v[4] = {acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3]};
+                        store4(sQh + (blk(mt) + i) * 16 + 4 * g, v);
+                    }
+                }
+                f32x4 acc[2][2];
+                zero_acc(acc);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const bf16x8 l0 = tok_frag(sA + AB_TILE, i, ks), l1 = tok_frag(sA + AB_TILE, 16 + i, ks);
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        acc[nt][0] = mfma16(wq[1 + nt][ks], l0, acc[nt][0]);
+                        acc[nt][1] = mfma16(wq[1 + nt][ks], l1, acc[nt][1]);
+                    }
+                }
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        float v[4] = {acc[nt][mt][0], acc[nt][mt][1], acc[nt][mt][2], acc[nt][mt][3]};
+                        store4(sQh + (1 + nt) * HT + (blk(mt) + i) * 16 + 4 * g, v);
+                    }
+            } else {   // ---- q_h, k_h, v_h of the tile's 32 tokens: 3 feature tiles x 2 token tiles ----
+                f32x4 acc[3][2];
+                zero_acc(acc);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const bf16x8 f0v = tok_frag(sA, i, ks), f1v = tok_frag(sA, 16 + i, ks);
+#pragma unroll
+                    for (int nt = 0; nt < 3; ++nt) {
+                        acc[nt][0] = mfma16(wq[nt][ks], f0v, acc[nt][0]);
+                        acc[nt][1] = mfma16(wq[nt][ks], f1v, acc[nt][1]);
+                    }
+                }
+#pragma unroll
+                for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        float v[4] = {acc[nt][mt][0], acc[nt][mt][1], acc[nt][mt][2], acc[nt][mt][3]};
+                        store4(sQh + nt * HT + (blk(mt) + i) * 16 + 4 * g, v);                    // wave-private rolling [pos][16]
+                    }
+            }
+            lds_fence();
+            const int r32 = lv & 31, hh = lv >> 5;
+            if (a.Qs != nullptr && 32 * t + r32 < nrows) {   // training: the backward pass reads q | k | v; lane (r32, hh) stores 16 bytes of token 32 t + r32
+                const unsigned tok = tok0 + (unsigned)(32 * t + r32);
+                const int hr = (blk(r32 >> 4) + (r32 & 15)) * 16 + 8 * hh;
+                const bf16x8 qf = *reinterpret_cast<const bf16x8*>(sQh + hr);
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sKh + hr);
+                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sVh + hr);
+                if (BONE) {
+                    *reinterpret_cast<bf16x8*>(a.Qs + (size_t)(tok * 128u + 16 * w + 8 * hh)) = qf;
+                    *reinterpret_cast<bf16x8*>(a.KVs + (size_t)(tok * 256u + 16 * w + 8 * hh)) = kf;
+                    *reinterpret_cast<bf16x8*>(a.KVs + (size_t)(tok * 256u + 128 + 16 * w + 8 * hh)) = vf;
+                } else {
+                    *reinterpret_cast<bf16x8*>(a.Qs + (size_t)(tok * 384u + 16 * w + 8 * hh)) = qf;
+                    *reinterpret_cast<bf16x8*>(a.Qs + (size_t)(tok * 384u + 128 + 16 * w + 8 * hh)) = kf;
+                    *reinterpret_cast<bf16x8*>(a.Qs + (size_t)(tok * 384u + 256 + 16 * w + 8 * hh)) = vf;
+                }
+            }
+            while (nfr < nf && J * (nfr + 1) <= 32 * (t + 1)) {      // every frame that ends inside this tile (uniform: one or two)
+                core(nfr, sm, lv);
+                ++nfr;
+                sm = wrap(sm + J);
+            }
+        }
+        __syncthreads();                                 // B2: the heads of every frame that ends in tile t are in sO: tile t - 1 is complete
+        if (t + 1 < ntiles) fetch(t + 1);                // (behind the core: its 4 (8) registers do not fit beside the core's under the 128-VGPR cap of two workgroups per CU)
+        if (t >= 1) {   // ---- output projection + layer-scale + residual of tile t - 1: 16 channels x 32 tokens per wave ----
+            const int i = lv & 15, g = lv >> 4;
+            const bf16* cO = sO + (par ^ 1) * AB_TILE;
+            const bf16* cX = sX + (par ^ 1) * AB_TILE;
+            f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                acc[0] = mfma16(wp[ks], tok_frag(cO, i, ks), acc[0]);
+                acc[1] = mfma16(wp[ks], tok_frag(cO, 16 + i, ks), acc[1]);
+            }
+            const f32x4 bpv = *reinterpret_cast<const f32x4*>(sLn + 512 + 16 * w + 4 * g), lsv = *reinterpret_cast<const f32x4*>(sLn + 640 + 16 * w + 4 * g);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                float x[4], v[4];
+                load4(cX + Tile<bf16>::off4(16 * mt + i, 16 * w + 4 * g), x);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = x[r] + lsv[r] * (acc[mt][r] + bpv[r]);
+                store4(sA + Tile<bf16>::off4(16 * mt + i, 16 * w + 4 * g), v);       // x_mid staging: LN(x_t) has no readers left; thread (rl, sub) reads the chunk back below
+            }
+        }
+        __syncthreads();                                 // B3: x_mid tile complete
+        const int rl = 4 * w + (lv >> 4), sub = lv & 15;
+        if (t >= 1 && 32 * (t - 1) + rl < nrows) {   // ---- full-row stores: x_mid always; o only when the backward pass will need it ----
+            const unsigned tok = tok0 + (unsigned)(32 * (t - 1) + rl);
+            const int co = Tile<bf16>::chunk_off(rl, sub);
+            *reinterpret_cast<f32x4*>(a.OUT + (size_t)(tok * 128u + sub * 8)) = *reinterpret_cast<const f32x4*>(sA + co);
+            if (a.Qs != nullptr) *reinterpret_cast<f32x4*>(a.Os + (size_t)(tok * 128u + sub * 8)) = *reinterpret_cast<const f32x4*>(sO + (par ^ 1) * AB_TILE + co);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // The same block for groups of 33..96 positions (temporal attention at T = 81): three 32-position tiles per group, one workgroup per CU
 // (147 KB of LDS: raw x, ONE LayerNorm tile, head outputs, 72 KB of wave-private q | k | v tiles).  What differs from the one-tile form:
 //   * the LayerNorm tile is used twice per group in the bone form (LN(x) for q, then LN_limb(x_limb) for k | v: two more barriers, negligible
@@ -596,6 +851,21 @@ bool kasf_launch_attn_block_fwd(hipStream_t s, int bone, const void* x, const vo
     }
     const int ns = bone ? 2 : 1;
     const int cap = bone ? 256 : 512;
+#ifndef KASF_NO_FLAT_SPATIAL
+    if (mode == 0) {                                    // the 17 joints of a frame: flat 32-token tiles over consecutive frames
+        const int want = (a.groups + 1) / 2;            // >= 2 frames per workgroup (a lone frame would pay a whole tile + the lagging iteration)
+        const unsigned grid = (unsigned)(want < cap ? (want < 1 ? 1 : want) : cap);
+        const size_t sh = (size_t)(2 + ns + 2) * AB_TILE * 2 + (size_t)8 * 3 * 48 * 16 * 2 + 6 * 128 * 4;
+        if (bone) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_blk_fwd_flat<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+            hipLaunchKernelGGL(k_attn_blk_fwd_flat<true>, dim3(grid), dim3(AB_THR), sh, s, a);
+        } else {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_blk_fwd_flat<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+            hipLaunchKernelGGL(k_attn_blk_fwd_flat<false>, dim3(grid), dim3(AB_THR), sh, s, a);
+        }
+        return true;
+    }
+#endif
     const unsigned grid = (unsigned)(a.groups < cap ? a.groups : cap);
     const size_t sh = (size_t)(1 + ns + 1 + 1) * AB_TILE * 2 + 8 * 3 * 512 * 2 + 6 * 128 * 4;
     if (bone) {
