@@ -434,3 +434,23 @@ __device__ __forceinline__ void load4(const float* p, float (&v)[4]) {
         hipError_t e_ = (x);                                                      \
         if (e_ != hipSuccess) return kasf_set_error(1000 + (int)e_, hipGetErrorString(e_)); \
     } while (0)
+
+// raw 8-element register images of a thread's 16-byte (bf16) / 32-byte (f32) chunk: kept as loaded, widened at the point of use (as fp32 a bf16 chunk
+// would hold 8 VGPRs instead of 4: k_gcn_agg_temporal loads a whole track ahead, k_gate_bwd keeps three branch rows across two passes)
+template <typename T> struct Raw8;
+template <> struct Raw8<bf16> {
+    bf16x8 v;          // (typed, widened element by element like load8: a __builtin_bit_cast of the words of an f32x4 image was compiled into eight copies of word 0)
+    __device__ __forceinline__ void load(const bf16* p) { v = *reinterpret_cast<const bf16x8*>(p); }
+    __device__ __forceinline__ void get(float (&o)[8]) const {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = (float)v[k];
+    }
+};
+template <> struct Raw8<float> {
+    f32x4 a, b;
+    __device__ __forceinline__ void load(const float* p) { a = *reinterpret_cast<const f32x4*>(p); b = *reinterpret_cast<const f32x4*>(p + 4); }
+    __device__ __forceinline__ void get(float (&o)[8]) const {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { o[k] = a[k]; o[4 + k] = b[k]; }
+    }
+};

@@ -719,6 +719,7 @@ int kasf_ws_entry(const kasf_model* m, int32_t batch, int32_t flags, int32_t idx
 
 int kasf_forward(const kasf_model* m, const float* params, const void* packed, float* buffers, const float* x, float* out, void* workspace,
                  int64_t workspace_bytes, int32_t batch, int32_t flags, void* stream) {
+    struct ModelPath { ModelPath() { kasf_tls_model_path = 1; } ~ModelPath() { kasf_tls_model_path = 0; } } model_path;      // grid widths of the persistent launches (kernels.h)
     if (check_model(m)) return 2;
     if (!params || !packed || !buffers || !x || !out || !workspace) return kasf_set_error(2, "null pointer argument");
     if (m->d_pro == nullptr) return kasf_set_error(4, "layout-only model cannot run");
@@ -775,6 +776,7 @@ int kasf_forward(const kasf_model* m, const float* params, const void* packed, f
 
 int kasf_backward(const kasf_model* m, const float* params, const void* packed, const float* dout, float* grads, void* workspace, int64_t workspace_bytes,
                   int32_t batch, int32_t flags, int32_t stage_begin, int32_t stage_end, void* stream) {
+    struct ModelPath { ModelPath() { kasf_tls_model_path = 1; } ~ModelPath() { kasf_tls_model_path = 0; } } model_path;      // grid widths of the persistent launches (kernels.h)
     if (check_model(m)) return 2;
     if (!params || !packed || !dout || !grads || !workspace) return kasf_set_error(2, "null pointer argument");
     const int L = m->cfg.n_layers;

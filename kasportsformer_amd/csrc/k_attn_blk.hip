@@ -850,7 +850,7 @@ bool kasf_launch_attn_block_fwd(hipStream_t s, int bone, const void* x, const vo
         return true;
     }
     const int ns = bone ? 2 : 1;
-    const int cap = bone ? 256 : 512;
+    const int cap = kasf_narrow_grid(KASF_NG_ATTN_FWD, bone ? 256 : 512, (int64_t)a.groups * L);
 #ifndef KASF_NO_FLAT_SPATIAL
     if (mode == 0) {                                    // the 17 joints of a frame: flat 32-token tiles over consecutive frames
         const int want = (a.groups + 1) / 2;            // >= 2 frames per workgroup (a lone frame would pay a whole tile + the lagging iteration)

@@ -1276,7 +1276,8 @@ bool kasf_launch_attn_bwd_fused_do(hipStream_t s, const void* q, int64_t ldq, co
     }
     if (form != 1) {                                    // form 1: the one-group-per-workgroup kernel the persistent one is compared with bit for bit (tests)
         const size_t shp = 8 * (3 * 32 * 16 * 2 + 2 * 32 * 32 * 2) + 2 * 32 * 128 * 2;
-        const dim3 grid(groups < 512 ? groups : 512);   // two workgroups per CU
+        const int pcap = kasf_narrow_grid(KASF_NG_ATTN_BWD, 512, (int64_t)groups * L);
+        const dim3 grid(groups < pcap ? groups : pcap);   // two workgroups per CU
         if (L <= 17) {
             if (!set_smem(k_attn_bwd_pers<9>, shp)) return true;
             hipLaunchKernelGGL(k_attn_bwd_pers<9>, grid, dim3(512), shp, s, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldkv, (bf16*)dq, lddq, (bf16*)dk,

@@ -84,25 +84,6 @@ __global__ __launch_bounds__(256) void k_gcn_agg_spatial(const T* __restrict__ u
 // fp32 mode: the exact v_mfma_f32_16x16x4_f32 chain).  Both operands are the SAME rows in the same k order, so S is bitwise symmetric.
 // BatchNorm sums are kept in LDS across all tracks of the workgroup and leave it as ONE fp64 atomic per frame at the end.
 template <int L> constexpr int agg_lp() { return (L + 15) / 16 * 16; }
-// raw 8-element (one thread's chunk of a U row) register images: kept as loaded, widened at the point of use (a track's U rows are loaded a whole
-// track ahead; as fp32 they would hold 8 VGPRs per item instead of 4)
-template <typename T> struct Raw8;
-template <> struct Raw8<bf16> {
-    bf16x8 v;          // (typed, widened element by element like load8: a __builtin_bit_cast of the words of an f32x4 image was compiled into eight copies of word 0)
-    __device__ __forceinline__ void load(const bf16* p) { v = *reinterpret_cast<const bf16x8*>(p); }
-    __device__ __forceinline__ void get(float (&o)[8]) const {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) o[k] = (float)v[k];
-    }
-};
-template <> struct Raw8<float> {
-    f32x4 a, b;
-    __device__ __forceinline__ void load(const float* p) { a = *reinterpret_cast<const f32x4*>(p); b = *reinterpret_cast<const f32x4*>(p + 4); }
-    __device__ __forceinline__ void get(float (&o)[8]) const {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { o[k] = a[k]; o[4 + k] = b[k]; }
-    }
-};
 // LDS: the similarity matrix and the V rows are never live together (S dies with the top-4 scan, V is first read by the aggregation), so they share one
 // region: 24.5 + 26.6 + 2 KB at T = 81 in bf16 -- THREE workgroups per CU where round 3's 78 KB allowed two (55 % of that launch's wave-cycles were waits).
 template <int L> constexpr int agg_ss_ld() { return (L | 1) + 1 + ((((L | 1) + 1) % 32 == 0) ? 2 : 0); }     // row stride of S in floats: >= L, even, not a multiple of 32

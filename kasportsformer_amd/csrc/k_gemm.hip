@@ -840,7 +840,7 @@ bool kasf_launch_wgrad_jobs(hipStream_t s, int njobs, const void* const* G, cons
     if (njobs < 1 || njobs > 3 || M <= 0 || nred < 0 || nred > 2) return false;
     int tiles = 0;
     for (int j = 0; j < njobs; ++j) tiles += N[j] / 128;
-    constexpr int target = 248;
+    const int target = kasf_narrow_grid(KASF_NG_WGRAD, 248, M);
     int splits = (target + tiles - 1) / tiles;
     const int64_t max_splits = (M + WG_BM - 1) / WG_BM;
     if (splits > max_splits) splits = (int)max_splits;

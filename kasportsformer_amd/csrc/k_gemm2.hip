@@ -327,7 +327,8 @@ int launch_dgrad_r(hipStream_t s, const void* dY, const void* Wt, const void* ad
     auto kern = k_dgrad_r<KC, RESID, ADD, ACC, XN, RING, WG, BIAS, PROJ>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     const int64_t tiles = (M + R_BM - 1) / R_BM;
-    const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
+    const int64_t gcap = kasf_narrow_grid(KASF_NG_DGRAD, 256, M);
+    const unsigned grid = (unsigned)(tiles < gcap ? tiles : gcap);
     const int64_t per = (tiles + grid - 1) / grid;
     const int active = (int)((tiles + per - 1) / per);                                  // workgroups that own at least one tile (the others return at once)
     float* part = sink != nullptr ? sink->take(active, PLD) : nullptr;
@@ -462,7 +463,8 @@ void launch_linear_r(hipStream_t s, const void* A, const void* W, const float* b
     auto kern = k_linear_r<NC, LN, RES>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     const int64_t tiles = (M + R_BM - 1) / R_BM;
-    const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
+    const int64_t gcap = kasf_narrow_grid(KASF_NG_LINEAR, 256, M);
+    const unsigned grid = (unsigned)(tiles < gcap ? tiles : gcap);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(R_THR), sh, s, (const bf16*)A, (const bf16*)W, bias, ln_g, ln_b, (bf16*)xn_out, ls, (const bf16*)resid,
                        (bf16*)C, M);
 }

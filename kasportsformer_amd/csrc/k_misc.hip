@@ -284,10 +284,13 @@ __global__ __launch_bounds__(256) void k_gate_fwd(const T* __restrict__ xa, cons
 // the grid can be large enough to hide HBM latency without contended atomics.
 constexpr int GATE_PART_LD = 1160;      // 3 x 384 weight gradients + 3 bias gradients, padded
 template <typename T>
-__global__ __launch_bounds__(256) void k_gate_bwd(const T* __restrict__ g, const T* __restrict__ g1, const T* __restrict__ g2, const T* __restrict__ xa,
-                                                  const T* __restrict__ xg, const T* __restrict__ xb, const float* __restrict__ W,
-                                                  const float* __restrict__ alpha, T* __restrict__ ga, T* __restrict__ gg, T* __restrict__ gb,
-                                                  float* __restrict__ dW, float* __restrict__ db, float* __restrict__ part, int64_t M, int adaptive) {
+__global__ __launch_bounds__(256, 3) void k_gate_bwd(const T* __restrict__ g, const T* __restrict__ g1, const T* __restrict__ g2, const T* __restrict__ xa,
+                                                     const T* __restrict__ xg, const T* __restrict__ xb, const float* __restrict__ W,
+                                                     const float* __restrict__ alpha, T* __restrict__ ga, T* __restrict__ gg, T* __restrict__ gb,
+                                                     float* __restrict__ dW, float* __restrict__ db, float* __restrict__ part, int64_t M, int adaptive) {
+    // Round 4: 128 VGPRs, four waves per SIMD (was 217 / two: 69 % of the wave-cycles were waits on the seven streams).  The 72 weight values a lane
+    // multiplies by are re-read from LDS per token instead of living in registers, the three branch rows stay in their loaded (bf16) form between the
+    // two passes, and each branch's gradient row is stored as soon as it is formed.
     __shared__ float sRed[16][384];
     __shared__ float sW[3][384];
     const int sub = threadIdx.x & 15, rl = threadIdx.x >> 4;
@@ -300,13 +303,15 @@ __global__ __launch_bounds__(256) void k_gate_bwd(const T* __restrict__ g, const
         for (int s = 0; s < 3; ++s)
 #pragma unroll
             for (int e = 0; e < 8; ++e) dw[j][s][e] = 0.f;
+    T* const outs[3] = {ga, gg, gb};
     for (int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x; item < M * 16; item += (int64_t)gridDim.x * 256) {
         const int64_t tok = item >> 4;
-        float x[3][8], gv[8];
+        Raw8<T> xr[3];
+        float gv[8];
+        xr[0].load(xa + tok * 128 + sub * 8);
+        xr[1].load(xg + tok * 128 + sub * 8);
+        xr[2].load(xb + tok * 128 + sub * 8);
         load8(g + tok * 128 + sub * 8, gv);
-        load8(xa + tok * 128 + sub * 8, x[0]);
-        load8(xg + tok * 128 + sub * 8, x[1]);
-        load8(xb + tok * 128 + sub * 8, x[2]);
         if (g1 != nullptr) {
             float t[8];
             load8(g1 + tok * 128 + sub * 8, t);
@@ -319,33 +324,43 @@ __global__ __launch_bounds__(256) void k_gate_bwd(const T* __restrict__ g, const
 #pragma unroll
             for (int e = 0; e < 8; ++e) gv[e] += t[e];
         }
-        const float a[3] = {alpha[tok * 4], alpha[tok * 4 + 1], alpha[tok * 4 + 2]};
+        const f32x4 av = *reinterpret_cast<const f32x4*>(alpha + tok * 4);
+        const float a[3] = {av[0], av[1], av[2]};
         float dl[3] = {0.f, 0.f, 0.f};
         if (adaptive) {
             float da[3] = {0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < 3; ++s) {
+                float xs[8];
+                xr[s].get(xs);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) da[s] += gv[e] * x[s][e];
+                for (int e = 0; e < 8; ++e) da[s] += gv[e] * xs[e];
                 da[s] = reduce16(da[s]);
             }
             const float dot = a[0] * da[0] + a[1] * da[1] + a[2] * da[2];
 #pragma unroll
             for (int j = 0; j < 3; ++j) { dl[j] = a[j] * (da[j] - dot); if (sub == 0) dbl[j] += dl[j]; }
         }
-        float o[3][8];
+        int wo = sub * 8;
+        asm volatile("" : "+v"(wo));                     // the weight reads below stay in the loop
 #pragma unroll
-        for (int s = 0; s < 3; ++s)
+        for (int s = 0; s < 3; ++s) {
+            float xs[8], o[8], wv[3][8];
+            xr[s].get(xs);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(&sW[j][s * 128 + wo]), w1 = *reinterpret_cast<const f32x4*>(&sW[j][s * 128 + wo + 4]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { wv[j][e] = w0[e]; wv[j][4 + e] = w1[e]; }
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const int c = s * 128 + sub * 8 + e;
-                o[s][e] = a[s] * gv[e] + dl[0] * sW[0][c] + dl[1] * sW[1][c] + dl[2] * sW[2][c];
+                o[e] = a[s] * gv[e] + dl[0] * wv[0][e] + dl[1] * wv[1][e] + dl[2] * wv[2][e];
 #pragma unroll
-                for (int j = 0; j < 3; ++j) dw[j][s][e] += dl[j] * x[s][e];
+                for (int j = 0; j < 3; ++j) dw[j][s][e] += dl[j] * xs[e];
             }
-        store8(ga + tok * 128 + sub * 8, o[0]);
-        store8(gg + tok * 128 + sub * 8, o[1]);
-        store8(gb + tok * 128 + sub * 8, o[2]);
+            store8(outs[s] + tok * 128 + sub * 8, o);
+        }
     }
     if (!adaptive) return;
     float* prow = part != nullptr ? part + (int64_t)blockIdx.x * GATE_PART_LD : nullptr;
@@ -681,7 +696,7 @@ void kasf_launch_gate_fwd(int dt, hipStream_t s, const void* xa, const void* xg,
 }
 void kasf_launch_gate_bwd(int dt, hipStream_t s, const void* g, const void* g1, const void* g2, const void* xa, const void* xg, const void* xb,
                           const float* W, const float* alpha, void* ga, void* gg, void* gb, float* dW, float* db, int64_t M, int adaptive, KasfColSink* sink) {
-    unsigned grid = ew_grid(M * 16, 1024);              // 4 workgroups per CU: enough loads in flight for an HBM stream of 7-9 tensors
+    unsigned grid = ew_grid(M * 16, 768);               // 3 workgroups per CU (168 VGPRs): enough loads in flight for an HBM stream of 7-9 tensors
     float* part = (sink != nullptr && adaptive) ? sink->take((int)grid, GATE_PART_LD) : nullptr;      // one row of dW[3][384] | db[3] per workgroup
     if (part == nullptr && grid > 256) grid = 256;      // atomics: few workgroups
     if (dt == KASF_F32) hipLaunchKernelGGL(k_gate_bwd<float>, dim3(grid), dim3(256), 0, s, (const float*)g, (const float*)g1, (const float*)g2, (const float*)xa, (const float*)xg, (const float*)xb, W, alpha, (float*)ga, (float*)gg, (float*)gb, dW, db, part, M, adaptive);

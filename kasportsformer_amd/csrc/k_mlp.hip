@@ -7,6 +7,7 @@
 // Backward recomputes Z = LN(x) W1^T + b1 (no activation stash in HBM during forward), produces
 // dZ and H = GELU(Z) for the two weight-gradient GEMMs, chains dA = dZ . W1 in registers and ends
 // with the LayerNorm backward + residual:   g_in = g + LNbwd(dA).
+#include <cstdlib>
 #include "common.h"
 #include "kernels.h"
 #include "tile_ops.h"
@@ -219,7 +220,8 @@ void kasf_launch_mlp_fwd(int dt, hipStream_t s, const void* x, const float* ln_g
     if (M <= 0) return;
     if (dt == KASF_F32) { mlp_fwd_T<float>(s, x, ln_g, ln_b, W1, b1, W2, b2, ls2, out, M); return; }
     const int64_t tiles = (M + 31) / 32;                 // bf16: persistent producer / consumer kernel (k_mlp3.hip), one workgroup per CU
-    kasf_launch_mlp_fwd_s(s, x, ln_g, ln_b, W1, b1, W2, b2, ls2, out, M, xn_out, (unsigned)(tiles < 256 ? tiles : 256));
+    const int64_t cap = kasf_narrow_grid(KASF_NG_MLP_FWD, 256, M);
+    kasf_launch_mlp_fwd_s(s, x, ln_g, ln_b, W1, b1, W2, b2, ls2, out, M, xn_out, (unsigned)(tiles < cap ? tiles : cap));
 }
 void kasf_launch_mlp_bwd(int dt, hipStream_t s, const void* x, const void* g, const float* ln_g, const float* ln_b, const void* W1, const float* b1,
                          const void* W2ts, const void* W1t, void* Hbuf, void* dZbuf, void* xn_buf, void* g_in, float* dgamma, float* dbeta,

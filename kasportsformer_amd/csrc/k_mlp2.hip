@@ -9,6 +9,7 @@
 //                      (db2 = ls2 . colsum, dls2 += b2 . colsum)
 // Every reduction across workgroups is "store a row, add the rows later in a fixed order": the gradients are bit-reproducible and no kernel
 // synchronises with another workgroup (round 2 ended this chain with fp32 atomics and a last-workgroup ticket).
+#include <cstdlib>
 #include "common.h"
 #include "kernels.h"
 #include "tile_ops.h"
@@ -193,8 +194,9 @@ int kasf_mlp_bwd_q_ranges(int64_t M) {
 void kasf_launch_mlp_bwd_q(hipStream_t s, const void* x, const void* xn, const void* g, const float* ln_g, const void* W1, const float* b1,
                            const void* W2ts, const void* W1t, void* dApart, float* partial, float* dW1, float* dW2, float* db1, float* gsum, void* g_in,
                            float* dgamma, float* dbeta, int64_t M, const float* W2, const float* b2, const float* ls2, float* dls2, KasfColSink* sink) {
-    const int ranges = kasf_mlp_bwd_q_ranges(M);
+    int ranges = kasf_mlp_bwd_q_ranges(M);
     const int64_t tiles = (M + Q_BM - 1) / Q_BM;
+    { const int nr = kasf_narrow_grid(KASF_NG_MLP_BWD, 64, M); if (ranges > nr) ranges = nr; }
     const int tpr = (int)((tiles + ranges - 1) / ranges);
     const int used = (int)((tiles + tpr - 1) / tpr);             // ranges that own at least one tile
     bf16* p1 = reinterpret_cast<bf16*>(partial);          // (the scratch is sized in floats for the round-3 fp32 tiles: half of it is used)

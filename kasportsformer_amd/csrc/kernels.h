@@ -167,6 +167,35 @@ void kasf_launch_gather_clips(hipStream_t s, const float* xa, const float* ya, c
 
 // ---- k_gemm2.hip (bf16, persistent, register-resident weights) ----
 // bf16 partial tiles a fused data + weight gradient launch left: out[e] += sum over z < nparts of part[z][e], e < elems (elems a multiple of 128)
+// ---- persistent launches narrower than the chip (round 4) ----
+// The MLP kernels keep their weights in registers: one workgroup owns a whole CU, so a launch that spans all 256 CUs runs ALONE -- the other two branch streams wait, and its
+// fill (weights into registers, a three-deep pipeline) and drain are paid with nothing beside them.  Inside the engine's forward / backward these launches therefore take HALF the
+// chip below 150,000 tokens: two branches' MLPs run side by side, one's fill under the other's steady state (tools/smallb_probe.py, T = 27 training: +3.1 % step throughput at
+// B = 256, +8 % at 128, +9 % at 32; evaluation +12 % at B = 32 ... 0 at 512; T = 81, B = 128 = 176,256 tokens: -0.4 %, hence the threshold; a third of the chip each is
+// worse: the branches are not equally long).  Below 80,000 tokens the LDS-ring data-gradient / linear kernels do the same (more tiles per workgroup
+// per fill; at B = 256 it costs 1.5 %).  The widths are a function of the token count only -- never of the stream mode -- so results stay bit-identical between the one-stream
+// and three-stream engines; the operator entry points (tests, bench.py's hot loop) launch at full width.
+// KASF_NARROW_PCTS = "fwd,bwd,dgrad,linear,attn_fwd,attn_bwd,wgrad" (percent of the full grid) and KASF_NARROW_BELOW = tokens override the table: measurement knobs.
+#include <cstdlib>
+#include <cstdint>
+enum { KASF_NG_MLP_FWD = 0, KASF_NG_MLP_BWD = 1, KASF_NG_DGRAD = 2, KASF_NG_LINEAR = 3, KASF_NG_ATTN_FWD = 4, KASF_NG_ATTN_BWD = 5, KASF_NG_WGRAD = 6 };
+inline thread_local int kasf_tls_model_path = 0;        // 1 while the engine's forward / backward is enqueueing (engine.hip)
+inline int kasf_narrow_grid(int cls, int full, int64_t tokens) {
+    static int pcts[7] = {-1, 0, 0, 0, 0, 0, 0};
+    static int64_t below[7] = {150000, 150000, 80000, 80000, 0, 0, 0};
+    if (pcts[0] < 0) {
+        const int def[7] = {50, 50, 50, 50, 100, 100, 100};
+        int tmp[7];
+        for (int k = 0; k < 7; ++k) tmp[k] = def[k];
+        if (const char* e = getenv("KASF_NARROW_PCTS")) { int k = 0; while (*e && k < 7) { tmp[k++] = atoi(e); while (*e && *e != ',') ++e; if (*e == ',') ++e; } }
+        if (const char* e = getenv("KASF_NARROW_BELOW")) for (int k = 0; k < 7; ++k) below[k] = atoll(e);
+        for (int k = 6; k >= 0; --k) pcts[k] = tmp[k];   // pcts[0] last: the table is complete when another thread sees it set
+    }
+    if (!kasf_tls_model_path || tokens >= below[cls]) return full;
+    const int g = full * pcts[cls] / 100;
+    return g < 1 ? 1 : g;
+}
+
 struct KasfBf16Reduce { const void* part; float* out; int nparts; int elems; };
 int kasf_launch_dgrad_wg(hipStream_t s, const void* dY, int Kd, const void* Wt, const void* X, const float* gamma, const float* beta, const void* resid, void* out,
                          int accumulate, float* dgamma, float* dbeta, int64_t M, KasfColSink* sink, void* wpart, int64_t wpart_bytes, const void* dxn_add = nullptr,
