@@ -1,5 +1,5 @@
-"""Small-batch experiment: MLP grids narrower than the chip so that the three branch streams' MLP launches run side by side.
-    python tools/smallb_probe.py            (spawns one process per setting: the knobs are read once per process)"""
+"""Grid widths of the persistent launches (kernels.h: kasf_narrow_grid): training throughput at several batch sizes per setting.
+    [PROBE_BATCHES=32,64,256] python tools/smallb_probe.py [pcts ...]      (one process per setting: the knobs are read once per process)"""
 import json, os, subprocess, sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 if len(sys.argv) > 1 and sys.argv[1] == "child":
@@ -23,7 +23,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         del model, opt
     print(json.dumps(out))
     sys.exit(0)
-SETTINGS = sys.argv[1:]                  # each: seven comma-separated percentages (mlp fwd, mlp bwd, dgrad, linear, attn fwd, attn bwd, wgrad jobs)
+SETTINGS = sys.argv[1:] or ["100,100,100,100,100,100,100", "50,50,100,100,100,100,100", "50,50,50,50,100,100,100", "33,33,100,100,100,100,100"]
+# each: seven comma-separated percentages of the full grid (mlp fwd, mlp bwd, dgrad, linear, attn fwd, attn bwd, wgrad jobs), applied at every batch size
+# (per-branch widths were tried too -- the last MLP of each branch, or the bone branch, at full width; a narrower graph branch: all worse than 50 % everywhere,
+#  profiles/r4_grid_width_probe.txt)
 for pcts in SETTINGS:
     env = dict(os.environ, KASF_NARROW_PCTS=pcts, KASF_NARROW_BELOW=os.environ.get("KASF_NARROW_BELOW", "1000000000"))
     r = subprocess.run([sys.executable, __file__, "child"], env=env, capture_output=True, text=True)
