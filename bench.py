@@ -103,6 +103,8 @@ def _profile(name):
 TRAFFIC_FILE = _profile("pmc_traffic.json")            # tools/pmc_traffic.py (two --pmc passes over tools/mlp_bench.py)
 IN_STEP_STATS = _profile("train_kernel_stats.csv")     # rocprofv3 --kernel-trace --stats of tools/train_once.py 27 256 (three streams overlap)
 ISOLATED_STATS = _profile("single_stream_kernel_stats.csv")   # the same steps with the three branches on ONE stream (tools/prof27.sh): every launch alone on the chip
+ISOLATED_FULL_STATS = _profile("single_stream_fullwidth_kernel_stats.csv")   # ... with every persistent launch at its full grid (KASF_NARROW_PCTS=100,...): comparable with rounds 1-3
+MLP_HALF_CHIP_BELOW = 150000                           # tokens (csrc/kernels.h: kasf_narrow_grid): below it an MLP launch of the engine takes 128 of the 256 CUs
 STEP_TRAFFIC_FILE = _profile("pmc_step.json")          # tools/pmc_step.sh: FETCH_SIZE / WRITE_SIZE summed over whole training steps
 TRAFFIC_PARTS = {"k_mlp_fwd_s": {"k_mlp_fwd_s": 1}, "k_mlp_bwd_s(+lnbwd_sum4_fin)": {"k_mlp_bwd_s": 1, "k_lnbwd_sum4_fin": 1}}
 
@@ -375,12 +377,23 @@ def main():
                     out["roofline"]["in_step"] = {"launch_ms": t_in * 1e3, "achieved": ks[dom]["algorithmic_flop"] / t_in / 1e12,
                                                   "frac": ks[dom]["algorithmic_flop"] / t_in / 1e12 / PEAK_BF16_TFLOPS,
                                                   "source": "committed file profiles/" + os.path.basename(IN_STEP_STATS) + " (rocprofv3 --kernel-trace --stats -- python3 tools/train_once.py 27 256)"}
+                half = args.batch * T * 17 < MLP_HALF_CHIP_BELOW
+                out["roofline"]["note"] = ("event-timed in a hot loop through the operator entry points: the kernels on all 256 CUs.  " +
+                                           ("Inside the engine's step each of these launches takes 128 CUs and two branches' launches run side by side "
+                                            "(csrc/kernels.h kasf_narrow_grid; profiles/r4_grid_width_probe.txt: +3 % step throughput at this batch, +8 % at 128): "
+                                            "in_step / in_step_single_stream are durations of those half-chip launches, frac is of the WHOLE chip's peak." if half else ""))
                 t_iso = in_step_duration(list(TRAFFIC_PARTS[dom]), ISOLATED_STATS)
-                if t_iso:                # ... and inside whole training steps run on ONE stream: alone on the chip, between the step's memory-bound launches instead of in a hot loop of itself
-                    out["roofline"]["in_step_single_stream"] = {"launch_ms": t_iso * 1e3, "achieved": ks[dom]["algorithmic_flop"] / t_iso / 1e12,
-                                                                "frac": ks[dom]["algorithmic_flop"] / t_iso / 1e12 / PEAK_BF16_TFLOPS,
-                                                                "source": "committed file profiles/" + os.path.basename(ISOLATED_STATS) + " (KASF_SINGLE_STREAM=1 rocprofv3 --kernel-trace --stats -- python3 tools/train_once.py 27 256); "
-                                                                          "the event-timed figure above is a back-to-back loop of this chain alone, where the same two kernels take longer per launch (profiles/r4_mlp_microbench_kernel_stats.csv)"}
+                if t_iso:                # ... and inside whole training steps run on ONE stream: nothing else in flight, between the step's memory-bound launches instead of in a hot loop of itself
+                    fr = ks[dom]["algorithmic_flop"] / t_iso / 1e12 / PEAK_BF16_TFLOPS
+                    out["roofline"]["in_step_single_stream"] = {"launch_ms": t_iso * 1e3, "achieved": ks[dom]["algorithmic_flop"] / t_iso / 1e12, "frac": fr,
+                                                                "cus": 128 if half else 256, "frac_of_its_cus": fr * (2 if half else 1),
+                                                                "source": "committed file profiles/" + os.path.basename(ISOLATED_STATS) + " (KASF_SINGLE_STREAM=1 rocprofv3 --kernel-trace --stats -- python3 tools/train_once.py 27 256): the engine's own launches, one at a time"}
+                t_full = in_step_duration(list(TRAFFIC_PARTS[dom]), ISOLATED_FULL_STATS)
+                if t_full:               # the one-stream step with full-width launches: what rounds 1-3 reported under this name
+                    out["roofline"]["in_step_single_stream_full_width"] = {"launch_ms": t_full * 1e3, "achieved": ks[dom]["algorithmic_flop"] / t_full / 1e12,
+                                                                           "frac": ks[dom]["algorithmic_flop"] / t_full / 1e12 / PEAK_BF16_TFLOPS, "cus": 256,
+                                                                           "source": "committed file profiles/" + os.path.basename(ISOLATED_FULL_STATS) + " (the same with KASF_NARROW_PCTS=100,100,100,100,100,100,100); "
+                                                                                     "the event-timed figure above is a back-to-back loop of this chain alone, where the same two kernels take longer per launch (profiles/r4_mlp_microbench_kernel_stats.csv)"}
             if os.path.exists(STEP_TRAFFIC_FILE) and args.batch == BATCH_PER_GPU:
                 out["step_hbm_GB"] = json.load(open(STEP_TRAFFIC_FILE))["hbm_GB_per_step"]
                 out["step_hbm_GB_source"] = "committed file profiles/" + os.path.basename(STEP_TRAFFIC_FILE)

@@ -27,7 +27,14 @@ export KASF_SINGLE_STREAM=1
 trace prof27s $R/tools/train_once.py 27 256; cp $O/prof27s/t_kernel_stats.csv $O/r4_single_stream_kernel_stats.csv
 trace prof81s $R/tools/train_once.py 81 128; cp $O/prof81s/t_kernel_stats.csv $O/r4_single_stream81_kernel_stats.csv
 trace prof32s $R/tools/train_once.py 27 32;  cp $O/prof32s/t_kernel_stats.csv $O/r4_single_stream_b32_kernel_stats.csv
+# the same one-stream steps with every persistent launch at its FULL grid (the engine's default gives the MLP launches half the chip below 150,000 tokens:
+# kernels.h, kasf_narrow_grid): the figure that compares with rounds 1-3, where a launch alone on the chip had all 256 CUs
+KASF_NARROW_PCTS=100,100,100,100,100,100,100 trace prof27sf $R/tools/train_once.py 27 256; cp $O/prof27sf/t_kernel_stats.csv $O/r4_single_stream_fullwidth_kernel_stats.csv
 unset KASF_SINGLE_STREAM
+say "concurrency of the three-stream step (tools/overlap.py on the trace above) and the same step with full-width launches"
+python tools/overlap.py $O/prof27/t_kernel_trace.csv > $O/r4_overlap.txt; need $O/r4_overlap.txt
+KASF_NARROW_PCTS=100,100,100,100,100,100,100 trace prof27f $R/tools/train_once.py 27 256
+{ echo; echo "## KASF_NARROW_PCTS=100,100,100,100,100,100,100 (every launch at its full grid)"; python tools/overlap.py $O/prof27f/t_kernel_trace.csv; } >> $O/r4_overlap.txt
 python tools/hbm_table.py $O/r4_single_stream_kernel_stats.csv 256 27 $O/r4_train_kernel_stats.csv > $O/r4_op_hbm.json;       need $O/r4_op_hbm.json
 python tools/hbm_table.py $O/r4_single_stream81_kernel_stats.csv 128 81 $O/r4_train81_kernel_stats.csv > $O/r4_op_hbm_t81.json; need $O/r4_op_hbm_t81.json
 say "whole-step HBM bytes"
@@ -45,14 +52,16 @@ timeout -k 10 200 python tools/op_bench.py > $O/r4_op_bench.txt 2>&1; need $O/r4
 say "other configurations"
 : > $O/r4_configs.jsonl
 for c in train27fp32 train81 train243 eval dropin small; do timeout -k 10 400 python tools/bench_configs.py $c 2>/dev/null | grep '^{' >> $O/r4_configs.jsonl; done
+KASF_NARROW_PCTS=100,100,100,100,100,100,100 timeout -k 10 200 python tools/bench_configs.py train27 2>/dev/null | grep '^{' | sed 's/"config": "train/"config": "KASF_NARROW_PCTS=100,... (full-width launches) train/' >> $O/r4_configs.jsonl
+timeout -k 10 200 python tools/bench_configs.py train27 2>/dev/null | grep '^{' >> $O/r4_configs.jsonl
 KASF_SINGLE_STREAM=1 timeout -k 10 200 python tools/bench_configs.py train27 2>/dev/null | grep '^{' | sed 's/"config": "train/"config": "KASF_SINGLE_STREAM=1 train/' >> $O/r4_configs.jsonl
 need $O/r4_configs.jsonl
 say "strong-scaling bench lines at the per-rank shapes of BASELINE configs[2] (one global batch of 256 over 8 / 4 ranks), data-parallel path, one rank"
 timeout -k 10 300 python bench.py --force-dp --global-batch 32 --det-conf --steps 20 --warmup 5 --no-cpu-baseline --no-fp32 --no-kernel-roofline > $O/r4_bench_strong_b32.json 2> $O/bench32.err; need $O/r4_bench_strong_b32.json
 timeout -k 10 300 python bench.py --force-dp --global-batch 64 --det-conf --steps 20 --warmup 5 --no-cpu-baseline --no-fp32 --no-kernel-roofline > $O/r4_bench_strong_b64.json 2> $O/bench64.err; need $O/r4_bench_strong_b64.json
 say "bench line (quotes the files above)"
-cp $O/r4_train_kernel_stats.csv $O/r4_pmc_step.json $O/r4_pmc_traffic.json $P/
+cp $O/r4_train_kernel_stats.csv $O/r4_single_stream_kernel_stats.csv $O/r4_single_stream_fullwidth_kernel_stats.csv $O/r4_pmc_step.json $O/r4_pmc_traffic.json $P/
 for f in r4_parity_26layers_fp32.json r4_parity_26layers_bf16.json; do [ -s gpurun_out/$f ] && cp gpurun_out/$f $P/ || true; done
 timeout -k 10 600 python bench.py > $O/r4_bench_b256.json 2> $O/bench.err; need $O/r4_bench_b256.json
-rm -rf $O/prof27 $O/prof81 $O/prof32 $O/prof27s $O/prof81s $O/prof32s $O/profe $O/pmc_f $O/pmc_w $O/profm $R/gpurun_out/pmcs_f $R/gpurun_out/pmcs_w
+rm -rf $O/prof27 $O/prof27f $O/prof27sf $O/prof81 $O/prof32 $O/prof27s $O/prof81s $O/prof32s $O/profe $O/pmc_f $O/pmc_w $O/profm $R/gpurun_out/pmcs_f $R/gpurun_out/pmcs_w
 say done; ls $O
