@@ -51,7 +51,8 @@ typedef struct kasf_config {
 
 const char* kasf_last_error(void);
 /* Process-wide: 1 = the three branches of a layer run back to back on the caller's stream instead of on three streams (the mode isolated kernel
- * profiles are taken in; about 4 % of the training throughput).  NOT a determinism switch: gradients are reproducible from run to run either way and
+ * profiles are taken in; it costs a quarter of the training throughput since round 4: the MLP launches of the engine take half the chip -- so that two
+ * branches' launches run side by side -- and the grids are the same in both settings, for the sake of the bits).  NOT a determinism switch: gradients are reproducible from run to run either way and
  * the two settings give the same bits (every gradient reduction is a fixed-order sum; the one exception is the BatchNorm batch statistics, whose
  * per-node sums cross workgroups as fp64 atomic adds of fp32-derived partials -- order-dependent below 1e-15 relative, which can move an fp32 mean by
  * one ulp in rare cases; tests/test_gpu_determinism.py has not seen it).  Default 0 (or 1 when KASF_SINGLE_STREAM is set in the environment).
