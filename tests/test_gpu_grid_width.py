@@ -61,3 +61,19 @@ def test_results_do_not_depend_on_the_grid_widths(tmp_path):
         print(f"gradient: cosine {cos:.9f}, relative difference {rel:.2e}")
         assert cos > 0.9999 and rel < 5e-3, (cos, rel)               # another split of the same sums into bf16 partial tiles (observed: 1 - 1.3e-7, 5.0e-4)
     # and the default table is one of these functions of the token count: a second run of it reproduces itself bit for bit (tests/test_gpu_determinism.py)
+
+
+def test_evaluation_output_does_not_depend_on_how_the_batch_is_split():
+    """Evaluation mode (BatchNorm on running statistics) treats every clip independently: a batch and its sub-batches go through different grids, tile
+    groupings and -- the spatial attention forward walks flat 32-token tiles across frame borders -- different frame-to-tile alignments, and must still give the
+    same bits.  (At full depth: 2,048 clips in one pass equal eight passes of 256 bit for bit, tools/big_batch_check.py.)"""
+    from oracle import kasf_oracle as O
+    from tests.gpu_util import make_pair
+    _, model = make_pair(3, 27, "bf16")
+    model.eval()
+    x, _ = O.synthetic_clips(50, 27, seed=17)
+    x = x.cuda()
+    with torch.no_grad():
+        whole = model(x)
+        pieces = torch.cat([model(x[a:b]) for a, b in ((0, 16), (16, 17), (17, 50))])      # 16, 1 and 33 clips
+    assert torch.equal(whole, pieces), float((whole - pieces).abs().max())
