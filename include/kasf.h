@@ -64,6 +64,10 @@ void kasf_set_deterministic(int32_t on);
 int32_t kasf_get_deterministic(void);
 int kasf_version(void);
 
+/* Streams: every model forks its attention / graph / bone branches onto ONE process-wide pair of side streams per device (created with the first model of
+ * the device, released with the process; device indices 0..63, error 2 beyond).  Events order every fork and join, so any number of models may share the
+ * pair; models of one device driven from different host threads therefore serialise on it, and a stream capture of kasf_forward has to be the only work
+ * in flight on that device while it is recorded. */
 int kasf_model_create(const kasf_config* cfg, kasf_model** out);
 /* the same handle without touching a device: answers every layout / size query below (kasf_param_*, kasf_buffer_*, kasf_workspace_bytes, kasf_stage_grad_range ...);
  * what a host-side binding uses to build its module tree before any GPU exists (kasportsformer_amd/model.py does) */
@@ -147,7 +151,9 @@ int kasf_ws_entry(const kasf_model* m, int32_t batch, int32_t flags, int32_t idx
 int kasf_op_linear(int32_t dtype, const void* a, const void* w, const float* bias, void* y, int64_t M, int32_t N, const float* ln_g, const float* ln_b,
                    void* xn_out, int32_t act, void* stream);
 /* modules/mlp.py inside a FormerModule: out = x + ls2 * (GELU(LN(x) W1^T + b1) W2^T + b2) */
-/* xn_out (optional; bf16 only): also receives LN(x), which kasf_op_mlp_bwd_fused streams instead of recomputing (what training mode does) */
+/* xn_out (optional; bf16 only): also receives LN(x), which kasf_op_mlp_bwd_fused streams instead of recomputing (what training mode does).
+ * ABI 7: with dtype = bf16, w2 [128,512] is IEEE FP16 (torch.float16), not bf16: the forward evaluates GELU in packed fp16 and keeps the hidden
+ * activation in fp16 for GEMM2 (v_mfma_f32_16x16x32_f16); x, w1 and out stay bf16.  kasf_pack_weights writes that fp16 copy into the arena itself. */
 int kasf_op_mlp_fwd(int32_t dtype, const void* x, const float* ln_g, const float* ln_b, const void* w1, const float* b1, const void* w2, const float* b2,
                     const float* ls2, void* out, int64_t M, void* xn_out, void* stream);
 int kasf_op_mlp_bwd(int32_t dtype, const void* x, const void* g, const float* ln_g, const float* ln_b, const void* w1, const float* b1,

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("KASF_LIB") or os.path.join(_HERE, "libkasf_hip.so")
 DTYPE_F32, DTYPE_BF16 = 0, 1
 FLAG_TRAIN, FLAG_RETURN_REP, FLAG_KEEP = 1, 2, 4
 EVAL_COLS = 22
-ABI_VERSION = 6          # kasf_version() of the library these prototypes describe (a stale in-tree .so is refused)
+ABI_VERSION = 7          # kasf_version() of the library these prototypes describe (a stale in-tree .so is refused)
 
 
 class KasfConfig(C.Structure):

@@ -12,6 +12,10 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef _Float16 f16;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 
 #define KASF_C 128          // dim_feat
 #define KASF_J 17           // joints
@@ -181,6 +185,50 @@ template <int N> __device__ __forceinline__ void gelu_pairs_poly(f32x2 (&x)[N]) 
     for (int k = 0; k < N; ++k) p[k] = fma2(p[k], t[k], C(3.9880567958e-01f));
 #pragma unroll
     for (int k = 0; k < N; ++k) x[k] = fma2(x[k], xc[k] * p[k], x[k] * C(0.5f));
+}
+// Round 5, the forward pass's form in bf16 mode: the same odd polynomial evaluated in PACKED FP16 (v_pk_fma_f16: two elements per lane, the issue cost of a
+// plain fp32 instruction, and -- unlike v_pk_*_f32 -- beside another wave's MFMAs instead of in the matrix pipe: tools/valu_probe.hip cases 30-40,
+// profiles/r5_valu_probe.txt), its result kept as FP16: the hidden activation reaches GEMM2 (v_mfma_f32_16x16x32_f16 against an fp16 copy of W2) with
+// 11 significant bits instead of the 8 of bf16.
+//   xh = f16(x);  u = clamp01(xh^2 / 16);  Phi(x) - 1/2 = x . Q(u)  with Q of degree 6 in u = x^2 / 16 on |x| <= 4 (minimax in the GELU error under the
+//   constraint 4 . Q(1) = 1/2);  Phi = clamp01(x . Q + 1/2)  continues it exactly beyond |x| = 4;  GELU = xh . Phi.
+// 11 instructions per pair, all packed (the fp32 form above: 14 + one v_cvt_pk_bf16_f32).  Error against the exact erf GELU over every fp16 input in
+// [-8, 8] and 4e5 normal deviates (tests/studies/f16_gelu_study.py): rms 4.7e-4 (a correctly rounded bf16 result: 1.3e-3), max 6e-3 (the fp16 spacing
+// of results in [4, 8); bf16: 1.6e-2); relative error on the negative side, where GELU is a difference of O(1) terms, up to 1.2e-2 of values below 0.17.
+// Coefficients are O(1) in u (no cancellation beyond one binade), which is what makes fp16 Horner usable: in t = x^2 they span nine decades.
+#define KASF_GH0 3.9787025043e-01f
+#define KASF_GH1 -1.0328702880e+00f
+#define KASF_GH2 2.2435028997e+00f
+#define KASF_GH3 -3.3267139471e+00f
+#define KASF_GH4 3.1302451291e+00f
+#define KASF_GH5 -1.6659993847e+00f
+#define KASF_GH6 3.7896534064e-01f
+template <int N> __device__ __forceinline__ void gelu_pairs_h(const f32x2 (&x)[N], f16x2 (&y)[N]) {
+    auto C = [](float v) { return f16x2{(f16)v, (f16)v}; };
+    auto fma2 = [](f16x2 a, f16x2 b, f16x2 c) { return __builtin_elementwise_fma(a, b, c); };
+    auto clamp01 = [&](f16x2 a) { return __builtin_elementwise_min(__builtin_elementwise_max(a, C(0.0f)), C(1.0f)); };   // folds into the producing instruction's clamp bit
+    f16x2 xh[N], u[N], q[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        xh[k] = __builtin_convertvector(x[k], f16x2);              // v_cvt_pk_f16_f32 (round to nearest even)
+        u[k] = xh[k] * xh[k];
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) u[k] = clamp01(u[k] * C(0.0625f));
+#pragma unroll
+    for (int k = 0; k < N; ++k) q[k] = fma2(u[k], C(KASF_GH6), C(KASF_GH5));
+#pragma unroll
+    for (int k = 0; k < N; ++k) q[k] = fma2(q[k], u[k], C(KASF_GH4));
+#pragma unroll
+    for (int k = 0; k < N; ++k) q[k] = fma2(q[k], u[k], C(KASF_GH3));
+#pragma unroll
+    for (int k = 0; k < N; ++k) q[k] = fma2(q[k], u[k], C(KASF_GH2));
+#pragma unroll
+    for (int k = 0; k < N; ++k) q[k] = fma2(q[k], u[k], C(KASF_GH1));
+#pragma unroll
+    for (int k = 0; k < N; ++k) q[k] = fma2(q[k], u[k], C(KASF_GH0));
+#pragma unroll
+    for (int k = 0; k < N; ++k) y[k] = xh[k] * clamp01(fma2(xh[k], q[k], C(0.5f)));
 }
 // ... and GELU with its derivative for N pairs:  GELU'(x) = Phi + x phi = 1/2 + copysign(1/2 - s, x) + x e / sqrt(2 pi)
 template <int N> __device__ __forceinline__ void gelu_grad_pairs_fast(f32x2 (&x)[N], f32x2 (&dy)[N]) {

@@ -36,7 +36,8 @@ struct LayerOff { BlockOff blk[6]; int64_t fus_w, fus_b, begin, end; };
 struct TopOff { int64_t norm_w, norm_b, fc_w, fc_b, head_w, head_b, p_fc, p_fcT, begin, end; };
 
 // The three branches of a layer run on three streams unless this is set: kasf_set_single_stream(1) (or KASF_SINGLE_STREAM=1 in the environment, read once)
-// runs them back to back on the caller's stream: same results bit for bit, the mode the isolated per-kernel profiles are taken in; -4 % throughput.
+// runs them back to back on the caller's stream: same results bit for bit, the mode the isolated per-kernel profiles are taken in; -23 % throughput since round 4
+// (3,389 against 4,428 clips/s: the half-chip MLP grids depend on the token count only, so in this mode they run one at a time on half the chip).
 // kasf_forward / kasf_backward read the flag ONCE per call into a local (a toggle from another thread between the fork and the join of a layer would
 // otherwise skip one of the two event waits).
 static std::atomic<int> g_single_stream{-1};
@@ -129,8 +130,8 @@ void build_layout(kasf_model* m) {
     Alloc A{&m->params};
     Alloc B{&m->buffers};
     int64_t arena = 0;
-    auto packd = [&](int64_t src, int rows, int cols, int64_t scale, int transpose) {
-        KasfPackDesc d{src, arena, scale, rows, cols, transpose, 0};
+    auto packd = [&](int64_t src, int rows, int cols, int64_t scale, int transpose, int fp16 = 0) {
+        KasfPackDesc d{src, arena, scale, rows, cols, transpose, fp16};
         m->pack.push_back(d);
         const int64_t at = arena;
         arena += (int64_t)rows * cols;
@@ -194,7 +195,7 @@ void build_layout(kasf_model* m) {
             o.fc2b = A.add(p + "mlp.fc2.bias", {128});
             o.p_fc1 = packd(o.fc1w, 512, 128, -1, 0);
             o.p_fc1T = packd(o.fc1w, 512, 128, -1, 1);
-            o.p_fc2 = packd(o.fc2w, 128, 512, -1, 0);
+            o.p_fc2 = packd(o.fc2w, 128, 512, -1, 0, KASF_FWD_F16);      // read by k_mlp_fwd_s only: fp16 (ignored by the fp32 arena)
             o.p_fc2Ts = packd(o.fc2w, 128, 512, o.ls2, 1);             // (ls2 . W2)^T
         }
         if (m->cfg.use_adaptive_fusion) {
@@ -505,7 +506,11 @@ void block_backward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void*
         int nred = 0;
         char* wpart = (char*)(part + WG_JOBS_FLOATS);
         bool proj_fused = false;
-        if (jobs && c.M >= WG_FUSE_MIN_TOKENS) {
+        const int64_t qb_ = (int64_t)256 * 128 * 128 * 2, kvb_ = (int64_t)256 * 256 * 128 * 2;
+        // both fused launches or neither (the q launch registers its dgamma / dbeta rows in the sink; a kv launch declining afterwards would have sent
+        // q through the two-kernel sequence a second time)
+        if (jobs && c.M >= WG_FUSE_MIN_TOKENS && kasf_dgrad_wg_supported(128, true, false, false, false, true, c.M, qb_) &&
+            kasf_dgrad_wg_supported(256, false, true, false, false, false, c.M, kvb_)) {
             // q: data gradient + dW_q + the block's PROJ gradient (g_mid is its residual operand, o one more ring stream); kv: data gradient + dW_kv.  No streaming
             // weight-gradient launch in this block at all: one finish launch adds the three sets of bf16 partial tiles.
             const int64_t qb = (int64_t)256 * 128 * 128 * 2, kvb = (int64_t)256 * 256 * 128 * 2;
@@ -513,9 +518,10 @@ void block_backward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void*
             float* pbrow = (float*)(ppart + qb);                             // ... and their colsum(g_mid) rows
             const int npq = kasf_launch_dgrad_wg(c.s, dq, 128, c.pk(o.p_mixT), x_in, P + o.n1w, P + o.n1b, g_mid, dst, accumulate, G + o.n1w, G + o.n1b, c.M, c.sink,
                                                  wpart, qb, nullptr, nullptr, c.w(w.o), ppart, pbrow);
-            const int npk = npq > 0 ? kasf_launch_dgrad_wg(c.s, dkv, 256, c.pk(o.p_kvT), x_limb, P + o.n1lw, P + o.n1lb, nullptr, c.w(p.g_limb), 1, G + o.n1lw,
-                                                           G + o.n1lb, c.M, c.sink, wpart + qb, kvb) : 0;
-            if (npq > 0 && npk > 0) {
+            const int npk = kasf_launch_dgrad_wg(c.s, dkv, 256, c.pk(o.p_kvT), x_limb, P + o.n1lw, P + o.n1lb, nullptr, c.w(p.g_limb), 1, G + o.n1lw,
+                                                 G + o.n1lb, c.M, c.sink, wpart + qb, kvb);
+            if (npq <= 0 || npk <= 0) return;            // cannot happen after the check above; if it ever does, the missing gradients fail every test instead of being double-counted
+            {
                 fusedwg = proj_fused = true;
                 red[nred++] = KasfBf16Reduce{wpart, G + o.mix_w, npq, 128 * 128};
                 red[nred++] = KasfBf16Reduce{wpart + qb, G + o.kv_w, npk, 256 * 128};
@@ -565,7 +571,7 @@ int32_t kasf_get_single_stream(void) { return single_stream() ? 1 : 0; }
 // the round-3 names: the setting never was about determinism (gradients are bit-reproducible either way)
 void kasf_set_deterministic(int32_t on) { kasf_set_single_stream(on); }
 int32_t kasf_get_deterministic(void) { return kasf_get_single_stream(); }
-int kasf_version(void) { return 6; }
+int kasf_version(void) { return 7; }
 
 int kasf_model_create(const kasf_config* cfg, kasf_model** out) {
     if (cfg == nullptr || out == nullptr) return kasf_set_error(2, "null argument");
@@ -597,13 +603,15 @@ int kasf_model_create(const kasf_config* cfg, kasf_model** out) {
     // a process then ran its step at 25-26 ms where the first ran at 15.8 (T = 27, B = 32; slower than with all three branches on ONE stream, 19.7), the
     // third at 15.8 again, the fourth at 18.4: which hardware queues a new stream lands on next to the existing ones decides how well three streams
     // overlap, and only the first pair was reliably lucky (tools/dp_probe2.py scenarios A / F / G; profiles/r4_stream_placement.jsonl).
+    // Consequences of the sharing (documented in kasf.h): models of one device driven from DIFFERENT host threads serialise on the pair (correct -- events order
+    // every fork and join -- but not concurrent), and the pair outlives every model: it is released with the process (two streams per device, by design).
     static hipStream_t shared_side[64][2] = {};
     static std::mutex shared_side_mutex;
     {
         std::lock_guard<std::mutex> lock(shared_side_mutex);
         int dev = 0;
         (void)hipGetDevice(&dev);
-        if (dev < 0 || dev >= 64) dev = 0;
+        if (dev < 0 || dev >= 64) { delete m; return kasf_set_error(2, "device index outside [0, 64): no shared side streams for it"); }
         for (int i = 0; i < 2; ++i) {
             if (shared_side[dev][i] == nullptr) HIPCHK(hipStreamCreateWithFlags(&shared_side[dev][i], hipStreamNonBlocking));
             m->side[i] = shared_side[dev][i];

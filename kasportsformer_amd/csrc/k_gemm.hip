@@ -675,10 +675,14 @@ __global__ __launch_bounds__(256) void k_pack(const float* __restrict__ params, 
     }
     __syncthreads();
     T* dst = arena + d.dst;
+    auto put = [&](int64_t at, float v) {
+        if (sizeof(T) == 2 && d.fp16) reinterpret_cast<f16*>(dst)[at] = (f16)v;      // master weights are O(0.1): no fp16 range concern; below 6e-5 they round on a 6e-8 grid
+        else dst[at] = from_f<T>(v);
+    };
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        if (d.transpose) dst[(int64_t)(c0 + ty + 8 * k) * d.rows + r0 + tx] = from_f<T>(tile[tx][ty + 8 * k]);
-        else dst[(int64_t)(r0 + ty + 8 * k) * d.cols + c0 + tx] = from_f<T>(tile[ty + 8 * k][tx]);
+        if (d.transpose) put((int64_t)(c0 + ty + 8 * k) * d.rows + r0 + tx, tile[tx][ty + 8 * k]);
+        else put((int64_t)(r0 + ty + 8 * k) * d.cols + c0 + tx, tile[ty + 8 * k][tx]);
     }
 }
 

@@ -487,11 +487,21 @@ bool kasf_launch_dgrad_r(hipStream_t s, const void* dY, int Kd, const void* Wt, 
 // The data gradient of an LN-fused linear WITH its weight gradient (dW[Kd][128] = dY^T LN(x)) in one streaming launch.  The weight gradient leaves it as
 // `return value` bf16 partial tiles of Kd x 128 in wpart (room for 256 of them), which the block's k_wgrad_finish_jobs launch adds in a fixed order
 // (KasfBf16Reduce).  Returns 0 for combinations that are not instantiated (the caller runs the two-kernel sequence).
+// Which (shape, operand) combinations kasf_launch_dgrad_wg has an instantiation for.  The engine asks BEFORE it launches the first of a block's two fused
+// kernels: a first launch that has already registered its dgamma / dbeta rows in the column sink cannot be taken back if the second one then declines.
+bool kasf_dgrad_wg_supported(int Kd, bool resid, bool accumulate, bool dxn_add, bool dbias, bool proj, int64_t M, int64_t wpart_bytes) {
+    if (M <= 0 || wpart_bytes < (int64_t)256 * Kd * 128 * 2) return false;
+    if (proj) return Kd == 128 && resid && !accumulate && !dxn_add && !dbias;
+    if (dxn_add || dbias) return Kd == 256 && resid && !accumulate && dxn_add && dbias;
+    return ((Kd == 384 || Kd == 128) && resid && !accumulate) || (Kd == 256 && !resid && accumulate);
+}
+
 int kasf_launch_dgrad_wg(hipStream_t s, const void* dY, int Kd, const void* Wt, const void* X, const float* gamma, const float* beta, const void* resid, void* out,
                          int accumulate, float* dgamma, float* dbeta, int64_t M, KasfColSink* sink, void* wpart, int64_t wpart_bytes, const void* dxn_add,
                          float* dbias, const void* proj_o, void* proj_part, float* proj_brow) {
-    if (M <= 0 || wpart == nullptr || wpart_bytes < (int64_t)256 * Kd * 128 * 2) return 0;
     const bool R = resid != nullptr, C = accumulate != 0;
+    if (wpart == nullptr || (proj_o != nullptr && (proj_part == nullptr || proj_brow == nullptr)) ||
+        !kasf_dgrad_wg_supported(Kd, R, C, dxn_add != nullptr, dbias != nullptr, proj_o != nullptr, M, wpart_bytes)) return 0;
     if (proj_o != nullptr) {                             // the bone block's q linear carrying the block's proj weight gradient: g_mid (= resid) ^T . o
         if (Kd == 128 && R && !C && dxn_add == nullptr && dbias == nullptr && proj_part != nullptr && proj_brow != nullptr)
             return launch_dgrad_r<1, true, false, false, true, true, false, true>(s, dY, Wt, nullptr, X, gamma, beta, resid, out, dgamma, dbeta, nullptr, M, sink, wpart,

@@ -42,6 +42,14 @@ namespace {
 constexpr int S_BM = 32, S_THR = 512, TL = S_BM * 128;
 
 __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+// GEMM2 of the forward pass: H and W2 are FP16 bit patterns in bf16-typed registers / tiles (same size, same layouts)
+__device__ __forceinline__ f32x4 mfma16h(bf16x8 a, bf16x8 b, f32x4 c) {
+#if KASF_FWD_F16
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+#else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+#endif
+}
 __device__ __forceinline__ bf16x8 tok_frag(const bf16* s, int row, int ks) {
     const int g = (threadIdx.x & 63) >> 4;
     return *reinterpret_cast<const bf16x8*>(s + Tile<bf16>::chunk_off(row, 4 * ks + g));
@@ -118,12 +126,22 @@ __global__ __launch_bounds__(S_THR) void k_mlp_fwd_s(const bf16* __restrict__ X,
                         y[2 * mt] = f32x2{acc[nt & 1][mt][0], acc[nt & 1][mt][1]};
                         y[2 * mt + 1] = f32x2{acc[nt & 1][mt][2], acc[nt & 1][mt][3]};
                     }
+#if KASF_FWD_F16
+                    f16x2 hh[4];
+                    gelu_pairs_h(y, hh);                 // packed fp16, H stays fp16 (same 2-byte tile layout)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        const f16x4 h4 = {hh[2 * mt][0], hh[2 * mt][1], hh[2 * mt + 1][0], hh[2 * mt + 1][1]};
+                        *reinterpret_cast<f16x4*>(hT + Tile<bf16>::off4(mt * 16 + i, 16 * nt + 4 * g)) = h4;
+                    }
+#else
                     if (KASF_FWD_GELU_POLY) gelu_pairs_poly(y); else gelu_pairs_fast(y);
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt) {
                         const float h[4] = {y[2 * mt][0], y[2 * mt][1], y[2 * mt + 1][0], y[2 * mt + 1][1]};
                         store4(hT + Tile<bf16>::off4(mt * 16 + i, 16 * nt + 4 * g), h);
                     }
+#endif
                     if (nt < 7) {
 #pragma unroll
                         for (int k = 0; k < 8; ++k) {
@@ -231,8 +249,8 @@ __global__ __launch_bounds__(S_THR) void k_mlp_fwd_s(const bf16* __restrict__ X,
                     if (ks + 2 < 16) frag(ks + 2, (ks + 2) % 3);
 #pragma unroll
                     for (int n2 = 0; n2 < 2; ++n2) {
-                        acc2[n2][0] = mfma16(w2f[n2][ks], fh[ks % 3][0], acc2[n2][0]);
-                        acc2[n2][1] = mfma16(w2f[n2][ks], fh[ks % 3][1], acc2[n2][1]);
+                        acc2[n2][0] = mfma16h(w2f[n2][ks], fh[ks % 3][0], acc2[n2][0]);
+                        acc2[n2][1] = mfma16h(w2f[n2][ks], fh[ks % 3][1], acc2[n2][1]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }

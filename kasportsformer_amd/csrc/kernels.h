@@ -7,13 +7,17 @@
 #define KASF_F32 0
 #define KASF_BF16 1
 
+#ifndef KASF_FWD_F16            // measurement switch (-DKASF_FWD_F16=0): the round-4 MLP forward, packed-fp32 GELU and a bf16 H / W2
+#define KASF_FWD_F16 1
+#endif
+
 struct KasfPackDesc {
     int64_t src;        // element offset into the fp32 parameter buffer
     int64_t dst;        // element offset into the packed arena
     int64_t scale;      // element offset of a per-row scale vector in the parameter buffer, or -1
     int rows, cols;     // source is [rows][cols] row-major
     int transpose;      // 1: destination is [cols][rows]
-    int pad_;
+    int fp16;           // 1 (bf16 arenas only): this copy is stored as IEEE fp16 (same element size): fc2.weight for the forward's fp16 GEMM2
 };
 
 // element offsets (fp32 parameter buffer) used by the prologue kernels
@@ -197,6 +201,7 @@ inline int kasf_narrow_grid(int cls, int full, int64_t tokens) {
 }
 
 struct KasfBf16Reduce { const void* part; float* out; int nparts; int elems; };
+bool kasf_dgrad_wg_supported(int Kd, bool resid, bool accumulate, bool dxn_add, bool dbias, bool proj, int64_t M, int64_t wpart_bytes);
 int kasf_launch_dgrad_wg(hipStream_t s, const void* dY, int Kd, const void* Wt, const void* X, const float* gamma, const float* beta, const void* resid, void* out,
                          int accumulate, float* dgamma, float* dbeta, int64_t M, KasfColSink* sink, void* wpart, int64_t wpart_bytes, const void* dxn_add = nullptr,
                          float* dbias = nullptr, const void* proj_o = nullptr, void* proj_part = nullptr, float* proj_brow = nullptr);

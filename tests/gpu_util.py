@@ -116,17 +116,20 @@ class forced_adjacency:
                 f"({self.mismatched} differ, {self.unexplained} of them not near-ties); entries {100.0 * self.bits_equal / max(self.bits, 1):.4f} % equal")
 
 
-def compare_grads(model, oracle, cd, floor_rel=None, small=256):
+def compare_grads(model, oracle, cd, floor_rel=None, small=256, pool_upto=64):
     """Every gradient of the HIP model against the oracle's.  Per-tensor error = max |g - r| / max(|r|max, floor_rel * gmax) (the floor: gradients that are
-    sums of cancelling terms sit at the summation-noise floor of BOTH sides).  bf16 mode: tensors of fewer than `small` elements (the 16-element limb-MLP
-    weights at the end of the longest path, biases of a few entries) carry a difference of large noisy terms -- their individual error is a sample of bf16
-    rounding noise, not a property of a kernel -- so they are judged POOLED (one cosine over all of them) and the per-tensor bar applies to the rest.
-    Returns a dict: worst (error, name) over the per-tensor set, pooled cosine of the small set, cosine over everything."""
+    sums of cancelling terms sit at the summation-noise floor of BOTH sides).  bf16 mode: tensors of at most `pool_upto` elements (the limb-MLP weights of
+    16 ... 64 elements at the end of the longest path, biases of a few entries) carry a difference of large noisy terms -- their individual error is a sample
+    of bf16 rounding noise, not a property of a kernel -- so they are judged POOLED (one cosine over all of them).  The tensors between that and `small`
+    elements -- the 128-element LayerNorm gammas / betas, biases and layer scales, each the output of a per-workgroup-row reduction of some kernel -- are
+    judged ONE BY ONE by their cosine (`mid_min_cosine`; ADVICE r4: a pooled cosine is dominated by the largest of them, a dropped or wrong small tensor
+    could pass), and the max-error bar applies to the rest.
+    Returns a dict: worst (error, name) over the per-tensor set, pooled cosine of the tiny set, worst per-tensor cosine of the middle set, cosine over everything."""
     if floor_rel is None:
         floor_rel = 1e-3 if cd == "fp32" else 0.05
     ref = dict(oracle.named_parameters())
     gmax = max(float(q.grad.abs().max()) for q in ref.values() if q.grad is not None)
-    errs, pooled, dots, none_mismatch = {}, [0.0, 0.0, 0.0], [0.0, 0.0, 0.0], []
+    errs, pooled, dots, none_mismatch, mid = {}, [0.0, 0.0, 0.0], [0.0, 0.0, 0.0], [], {}
     for n, p in model.named_parameters():
         r = ref[n].grad
         if (r is None) != (p.grad is None):
@@ -141,9 +144,13 @@ def compare_grads(model, oracle, cd, floor_rel=None, small=256):
         if cd == "bf16" and r.numel() < small:
             for k in range(3):
                 pooled[k] += d[k]
+            if r.numel() > pool_upto:
+                mid[n] = d[0] / max(1e-300, d[1] ** 0.5 * d[2] ** 0.5) if d[2] > 0 else (1.0 if d[1] == 0 else 0.0)
             continue
         errs[n] = float((g - r).abs().max() / max(float(r.abs().max()), floor_rel * gmax))
     worst = max(errs, key=errs.get)
+    mid_name = min(mid, key=mid.get) if mid else None
     return {"errors": errs, "worst": errs[worst], "worst_name": worst, "gmax": gmax, "none_mismatch": none_mismatch,
             "pooled_small_cosine": pooled[0] / max(1e-300, pooled[1] ** 0.5 * pooled[2] ** 0.5) if pooled[2] > 0 else 1.0,
+            "mid_cosines": mid, "mid_min_cosine": mid[mid_name] if mid else 1.0, "mid_min_name": mid_name,
             "cosine": dots[0] / max(1e-300, dots[1] ** 0.5 * dots[2] ** 0.5)}

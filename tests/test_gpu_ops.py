@@ -96,7 +96,8 @@ def test_mlp_forward(lib, cd, M):
     from kasportsformer_amd import _lib
     p = _mlp_params()
     x = _rand(M, 128, seed=5)
-    xd, w1, w2 = _dev(x, cd), _dev(p["W1"], cd), _dev(p["W2"], cd)
+    xd, w1 = _dev(x, cd), _dev(p["W1"], cd)
+    w2 = p["W2"].to("cuda", torch.float16) if cd == "bf16" else _dev(p["W2"], cd)      # bf16 mode: GEMM2 runs on FP16 operands (kasf.h, ABI 7)
     out = torch.empty_like(xd)
     xn = torch.empty_like(xd) if cd == "bf16" else None          # training mode also stores LN(x) for the fused backward
     _lib.check(lib.kasf_op_mlp_fwd(DT[cd][0], ptr(xd), ptr(_f32(p["g"])), ptr(_f32(p["b"])), ptr(w1), ptr(_f32(p["b1"])), ptr(w2),
@@ -164,7 +165,7 @@ def test_mlp_backward_fused_bf16(lib, M):                          # 117504: the
     z = lambda *s: torch.zeros(*s, device="cuda")
     dW1, dW2, db1, gsum, dg, db = z(512, 128), z(128, 512), z(512), z(128), z(128), z(128)
     out, xn = torch.empty_like(xd), torch.empty_like(xd)           # the forward pass leaves LN(x) behind for the backward kernel
-    _lib.check(lib.kasf_op_mlp_fwd(1, ptr(xd), ptr(_f32(p["g"])), ptr(_f32(p["b"])), ptr(w1), ptr(_f32(p["b1"])), ptr(_dev(p["W2"], cd)), ptr(_f32(p["b2"])),
+    _lib.check(lib.kasf_op_mlp_fwd(1, ptr(xd), ptr(_f32(p["g"])), ptr(_f32(p["b"])), ptr(w1), ptr(_f32(p["b1"])), ptr(p["W2"].to("cuda", torch.float16)), ptr(_f32(p["b2"])),
                                    ptr(_f32(p["ls"])), ptr(out), M, ptr(xn), stream()))
     g_final = gd
     for rep in range(3):           # a different upstream gradient every time: anything stale from the previous launch would be off by a factor

@@ -9,7 +9,7 @@ buf = (C.c_longlong * 32)()
 M = 256 * 27 * 17
 dev, bf = "cuda", torch.bfloat16
 x = torch.randn(M, 128, device=dev).to(bf); out = torch.empty_like(x); xn = torch.empty_like(x)
-w1 = (torch.randn(512, 128, device=dev) * 0.05).to(bf); w2 = (torch.randn(128, 512, device=dev) * 0.05).to(bf)
+w1 = (torch.randn(512, 128, device=dev) * 0.05).to(bf); w2 = (torch.randn(128, 512, device=dev) * 0.05).to(torch.float16)   # ABI 7: fp16 copy of fc2.weight
 b1 = torch.zeros(512, device=dev); b2 = torch.zeros(128, device=dev); ls = torch.ones(128, device=dev); gam = torch.ones(128, device=dev); bet = torch.zeros(128, device=dev)
 p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
 st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)

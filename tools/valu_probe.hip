@@ -89,6 +89,41 @@ template <int CASE> __global__ void probe(float* out, long long* cyc) {
         if (CASE == 19) {   // the vector side of cases 15 / 17 alone (no MFMA wave): 3 x the instructions per wave
             for (int rr = 0; rr < 3; ++rr) { R16(asm volatile("v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(k), "v"(c));) }
         }
+        // round 5: packed fp16 (v_pk_*_f16): two elements per lane -- at the plain-fp32 issue cost?  beside another wave's MFMAs?
+        if (CASE == 30) { R16(asm volatile("v_pk_fma_f16 %0, %0, %4, %5\n v_pk_fma_f16 %1, %1, %4, %5\n v_pk_fma_f16 %2, %2, %4, %5\n v_pk_fma_f16 %3, %3, %4, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(k), "v"(c));) }
+        if (CASE == 31) { R16(asm volatile("v_pk_mul_f16 %0, %0, %4\n v_pk_min_f16 %1, %1, %5\n v_pk_max_f16 %2, %2, %4\n v_pk_add_f16 %3, %3, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(k), "v"(c));) }
+        if (CASE == 32) { R16(asm volatile("v_cvt_pk_f16_f32 %0, %1, %2\n v_cvt_pk_f16_f32 %3, %1, %2\n v_cvt_pk_f16_f32 %0, %1, %2\n v_cvt_pk_f16_f32 %3, %1, %2" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));) }
+        if (CASE == 33 || CASE == 36 || CASE == 37) {   // waves 0-3 MFMA only; the other waves (1, 2 or 3 per SIMD) v_pk_fma_f16 (x3 the instructions in 36 / 37)
+            if ((threadIdx.x >> 8) == 0) {
+                R16(asm volatile("v_mfma_f32_16x16x32_bf16 %0, %2, %3, %0\n v_mfma_f32_16x16x32_bf16 %1, %2, %3, %1\n v_mfma_f32_16x16x32_bf16 %0, %2, %3, %0\n v_mfma_f32_16x16x32_bf16 %1, %2, %3, %1" : "+v"(acc), "+v"(acc1) : "v"(fa), "v"(fb));)
+            } else {
+                for (int rr = 0; rr < (CASE == 33 ? 1 : 3); ++rr) { R16(asm volatile("v_pk_fma_f16 %0, %0, %4, %5\n v_pk_fma_f16 %1, %1, %4, %5\n v_pk_fma_f16 %2, %2, %4, %5\n v_pk_fma_f16 %3, %3, %4, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(k), "v"(c));) }
+            }
+        }
+        if (CASE == 34) {   // f16 MFMA only
+            R16(asm volatile("v_mfma_f32_16x16x32_f16 %0, %2, %3, %0\n v_mfma_f32_16x16x32_f16 %1, %2, %3, %1\n v_mfma_f32_16x16x32_f16 %0, %2, %3, %0\n v_mfma_f32_16x16x32_f16 %1, %2, %3, %1" : "+v"(acc), "+v"(acc1) : "v"(fa), "v"(fb));)
+        }
+        if (CASE == 35) {  // one MFMA (2 accumulators in rotation) to seven v_pk_fma_f16 in the SAME wave
+#define P8(A) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %5, %6, %0\n v_pk_fma_f16 %1, %1, %7, %8\n v_pk_fma_f16 %2, %2, %7, %8\n v_pk_fma_f16 %3, %3, %7, %8\n v_pk_fma_f16 %4, %4, %7, %8\n v_pk_fma_f16 %1, %1, %7, %8\n v_pk_fma_f16 %2, %2, %7, %8\n v_pk_fma_f16 %3, %3, %7, %8" : "+v"(A), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(fa), "v"(fb), "v"(k), "v"(c));
+            P8(acc) P8(acc1) P8(acc) P8(acc1) P8(acc) P8(acc1) P8(acc) P8(acc1)
+        }
+        if (CASE == 38) {   // the vector side of 36 / 37 alone
+            for (int rr = 0; rr < 3; ++rr) { R16(asm volatile("v_pk_fma_f16 %0, %0, %4, %5\n v_pk_fma_f16 %1, %1, %4, %5\n v_pk_fma_f16 %2, %2, %4, %5\n v_pk_fma_f16 %3, %3, %4, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(k), "v"(c));) }
+        }
+        if (CASE == 39) {   // the MLP forward's shape: one wave per SIMD MFMA-heavy (waves 0-3), one wave per SIMD issuing 1 MFMA : 9 v_pk_fma_f16 (waves 4-7)
+            if ((threadIdx.x >> 8) == 0) {
+                R16(asm volatile("v_mfma_f32_16x16x32_bf16 %0, %2, %3, %0\n v_mfma_f32_16x16x32_bf16 %1, %2, %3, %1\n v_mfma_f32_16x16x32_bf16 %0, %2, %3, %0\n v_mfma_f32_16x16x32_bf16 %1, %2, %3, %1" : "+v"(acc), "+v"(acc1) : "v"(fa), "v"(fb));)
+            } else {
+                P8(acc) P8(acc1) P8(acc) P8(acc1) P8(acc) P8(acc1) P8(acc) P8(acc1)
+            }
+        }
+        if (CASE == 40) {   // ... and the same with packed fp32 (what k_mlp_fwd_s issues today)
+            if ((threadIdx.x >> 8) == 0) {
+                R16(asm volatile("v_mfma_f32_16x16x32_bf16 %0, %2, %3, %0\n v_mfma_f32_16x16x32_bf16 %1, %2, %3, %1\n v_mfma_f32_16x16x32_bf16 %0, %2, %3, %0\n v_mfma_f32_16x16x32_bf16 %1, %2, %3, %1" : "+v"(acc), "+v"(acc1) : "v"(fa), "v"(fb));)
+            } else {
+                G8 G8 G8 G8 G8 G8 G8 G8
+            }
+        }
         if (CASE == 11) { R16(asm volatile("v_pk_mul_f32 %0, %0, %4\n v_pk_add_f32 %1, %1, %5\n v_pk_mul_f32 %2, %2, %4\n v_pk_add_f32 %3, %3, %5" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pk), "v"(pc));) }
     }
     const long long t1 = clock64();
@@ -151,5 +186,17 @@ int main(int argc, char** argv) {
     run<22>("w0-3 mfma32 | 2 waves/SIMD pk_fma x3", 768, out, cyc);
     run<24>("w0-3 mfma prio0 | 2 waves fma x3 PRIO 3", 768, out, cyc);
     run<25>("w0-3 mfma PRIO 3 | 2 waves fma x3 prio0", 768, out, cyc);
+    // round 5: packed fp16
+    BOTH(30, "v_pk_fma_f16 x4 chains")
+    BOTH(31, "v_pk_mul/min/max/add_f16")
+    BOTH(32, "v_cvt_pk_f16_f32")
+    BOTH(34, "mfma 16x16x32 f16 only")
+    BOTH(35, "1 mfma : 7 pk_fma_f16 (same wave)")
+    run<33>("waves 0-3 mfma | waves 4-7 pk_fma_f16", 512, out, cyc);
+    run<38>("pk_fma_f16 x3 alone, 2 waves/SIMD", 512, out, cyc);
+    run<36>("w0-3 mfma | 2 waves/SIMD pk_fma_f16 x3", 768, out, cyc);
+    run<37>("w0-3 mfma | 3 waves/SIMD pk_fma_f16 x3", 1024, out, cyc);
+    run<39>("w0-3 mfma | w4-7 1 mfma : 7 pk_fma_f16", 512, out, cyc);
+    run<40>("w0-3 mfma | w4-7 1 mfma : 7 pk_fma_f32", 512, out, cyc);
     return 0;
 }
