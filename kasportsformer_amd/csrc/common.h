@@ -230,7 +230,55 @@ template <int N> __device__ __forceinline__ void gelu_pairs_h(const f32x2 (&x)[N
 #pragma unroll
     for (int k = 0; k < N; ++k) y[k] = xh[k] * clamp01(fma2(xh[k], q[k], C(0.5f)));
 }
-// ... and GELU with its derivative for N pairs:  GELU'(x) = Phi + x phi = 1/2 + copysign(1/2 - s, x) + x e / sqrt(2 pi)
+// The backward pass's form (round 5): Phi(z) AND GELU'(z) = Phi + z pdf(z) of N pairs in packed fp16, both as 1/2 + zc . poly(v) with zc = clamp(z, -4, 4) and
+// v = zc^2 / 8 - 1 in [-1, 1]:  Phi - 1/2 = zc Q(v) (degree 6),  GELU' - 1/2 = zc R(v), R = Q + pdf (degree 7; its u = x^2/16 form has coefficients up to 45 and
+// loses three digits in fp16 Horner, so both polynomials live in the shifted variable).  No exponential (the fp32 form: two quarter-rate v_exp_f32 per pair).
+// The caller multiplies in fp32 (v_fma_mix_f32: fp32 z / dH times the fp16 factor), so H and dZ carry no fp16 range limit: gradients do underflow fp16.
+// tests/studies/f16_gelu_study.py: GELU' rms error 3.3e-4 (max 1.4e-3; a correctly rounded bf16 GELU': 1.35e-3), H after its bf16 rounding 1.36e-3 (1.33e-3).
+#define KASF_GQ0 1.7597076120e-01f
+#define KASF_GQ1 -8.4424545240e-02f
+#define KASF_GQ2 5.5395112154e-02f
+#define KASF_GQ3 -3.5476099890e-02f
+#define KASF_GQ4 2.4147918417e-02f
+#define KASF_GQ5 -1.6534480087e-02f
+#define KASF_GQ6 5.9213334475e-03f
+#define KASF_GR0 1.8316959647e-01f
+#define KASF_GR1 -1.1385186317e-01f
+#define KASF_GR2 1.1756731017e-01f
+#define KASF_GR3 -1.1265037252e-01f
+#define KASF_GR4 8.2926297726e-02f
+#define KASF_GR5 -7.5993324699e-02f
+#define KASF_GR6 7.7233806846e-02f
+#define KASF_GR7 -3.3267620593e-02f
+template <int N> __device__ __forceinline__ void gelu_grad_pairs_h(const f32x2 (&z)[N], f16x2 (&phi)[N], f16x2 (&dg)[N]) {
+    auto C = [](float v) { return f16x2{(f16)v, (f16)v}; };
+    auto fma2 = [](f16x2 a, f16x2 b, f16x2 c) { return __builtin_elementwise_fma(a, b, c); };
+    f16x2 zc[N], v[N], q[N], r[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        zc[k] = __builtin_convertvector(z[k], f16x2);
+        zc[k] = __builtin_elementwise_min(__builtin_elementwise_max(zc[k], C(-4.0f)), C(4.0f));
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = fma2(zc[k] * zc[k], C(0.125f), C(-1.0f));
+#pragma unroll
+    for (int k = 0; k < N; ++k) { q[k] = fma2(v[k], C(KASF_GQ6), C(KASF_GQ5)); r[k] = fma2(v[k], C(KASF_GR7), C(KASF_GR6)); }
+#pragma unroll
+    for (int k = 0; k < N; ++k) { q[k] = fma2(q[k], v[k], C(KASF_GQ4)); r[k] = fma2(r[k], v[k], C(KASF_GR5)); }
+#pragma unroll
+    for (int k = 0; k < N; ++k) { q[k] = fma2(q[k], v[k], C(KASF_GQ3)); r[k] = fma2(r[k], v[k], C(KASF_GR4)); }
+#pragma unroll
+    for (int k = 0; k < N; ++k) { q[k] = fma2(q[k], v[k], C(KASF_GQ2)); r[k] = fma2(r[k], v[k], C(KASF_GR3)); }
+#pragma unroll
+    for (int k = 0; k < N; ++k) { q[k] = fma2(q[k], v[k], C(KASF_GQ1)); r[k] = fma2(r[k], v[k], C(KASF_GR2)); }
+#pragma unroll
+    for (int k = 0; k < N; ++k) { q[k] = fma2(q[k], v[k], C(KASF_GQ0)); r[k] = fma2(r[k], v[k], C(KASF_GR1)); }
+#pragma unroll
+    for (int k = 0; k < N; ++k) r[k] = fma2(r[k], v[k], C(KASF_GR0));
+#pragma unroll
+    for (int k = 0; k < N; ++k) { phi[k] = fma2(zc[k], q[k], C(0.5f)); dg[k] = fma2(zc[k], r[k], C(0.5f)); }
+}
+// ... and GELU with its derivative for N pairs (fp32 form: rounds 1-4, KASF_BWD_F16=0):  GELU'(x) = Phi + x phi = 1/2 + copysign(1/2 - s, x) + x e / sqrt(2 pi)
 template <int N> __device__ __forceinline__ void gelu_grad_pairs_fast(f32x2 (&x)[N], f32x2 (&dy)[N]) {
     auto C = [](float v) { return f32x2{v, v}; };
     auto fma2 = [](f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); };
@@ -459,6 +507,10 @@ __device__ __forceinline__ void stage_tile_async(T* sT, const T* src, int64_t ld
 }
 __device__ __forceinline__ void wait_async() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // wait until at most N of this wave's vector-memory operations (LDS-direct loads included, in issue order) are outstanding
+// A register USE of a value loaded by an ordinary (compiler-tracked) load.  Placed after a prologue's wait_async(), in front of a loop that keeps LDS-direct
+// requests in flight: hipcc's own s_waitcnt for the first use of a pre-loop load otherwise lands INSIDE the loop -- as vmcnt(1) / vmcnt(0) per iteration, because
+// it cannot see the inline-asm requests issued since -- and drains the look-ahead every tile (round 5: 155 -> 188 us on k_mlp_bwd_s; DESIGN section 4, compiler traps).
+template <typename V> __device__ __forceinline__ void touch_loaded(const V& v) { asm volatile("" ::"v"(v)); }
 template <int N> __device__ __forceinline__ void wait_async_le() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 // workgroup barrier WITHOUT the vmcnt(0)/lgkmcnt(0) drain __syncthreads() adds while LDS-direct loads are in flight
 __device__ __forceinline__ void barrier_keep_async() {

@@ -128,7 +128,12 @@ __global__ __launch_bounds__(S_THR) void k_mlp_fwd_s(const bf16* __restrict__ X,
                     }
 #if KASF_FWD_F16
                     f16x2 hh[4];
+#ifdef KASF_KO_FGELU
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) hh[k] = __builtin_convertvector(y[k], f16x2);
+#else
                     gelu_pairs_h(y, hh);                 // packed fp16, H stays fp16 (same 2-byte tile layout)
+#endif
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt) {
                         const f16x4 h4 = {hh[2 * mt][0], hh[2 * mt][1], hh[2 * mt + 1][0], hh[2 * mt + 1][1]};
@@ -332,6 +337,40 @@ __global__ __launch_bounds__(S_THR) void k_mlp_bwd_s(const bf16* __restrict__ XN
     if (w < 4) {
         // ------------------------------------------------ producer: hidden units [32w, 32w + 32) of the quarter ------------------------------------------------
         const int h0 = 32 * w;
+        // The LDS-direct look-ahead loads are the PRODUCERS' job since round 5: wave w brings rows [8w, 8w + 8) of g and LN(x) of tile t + 3.  Segment timers of the
+        // round-4 form (consumers loading) after the producers' GELU went to packed fp16: producer busy 3.6 k cycles per tile, consumer 5.4 k -- 0.9 k of it issuing
+        // these four loads and 0.7 k waiting for them -- and the producers 2.5 k at the barrier.  The producers have no other vector-memory traffic, so their
+        // counted wait sees loads only; the consumers' queue holds their dA-partial stores only and is never waited on.
+        // Everything that does not change from tile to tile is computed once: the two wave-uniform bases of this range (SGPR pairs), the per-lane byte offset
+        // inside a tile and the LDS offset of the lane group; per tile a 32-bit tile offset is added (a range is far below 4 GB).
+        const int nt32 = (int)ntiles;
+        const int64_t rows_here = M - tile0 * S_BM;
+        const int rows_in_range = (int)(rows_here < (int64_t)nt32 * S_BM ? rows_here : (int64_t)nt32 * S_BM);
+        const void* ugb = uniform_ptr(G + tile0 * S_BM * 128);
+        const void* uab = uniform_ptr(XN + tile0 * S_BM * 128);
+        const unsigned ldsG = __builtin_amdgcn_readfirstlane(lds_addr(sG)), ldsA = __builtin_amdgcn_readfirstlane(lds_addr(sA));
+        auto issue = [&](int t, int slot) {
+            const int tt = t < nt32 ? t : 0;             // past the range: harmless re-read that keeps the per-issue load count constant
+            int nvalid = rows_in_range - tt * S_BM;
+            nvalid = t < nt32 ? (nvalid < S_BM ? nvalid : S_BM) : 1;
+            const unsigned tile_off = (unsigned)tt * (S_BM * 256u), slot_off = (unsigned)slot * (TL * 2u);
+            const void* ug = (const char*)ugb + tile_off;             // two scalar adds each
+            const void* ua = (const char*)uab + tile_off;
+            int ln = lane;
+            asm volatile("" : "+v"(ln));                 // re-derive the lane's row / chunk here (six vector instructions) instead of holding four more registers across the loop
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int row = (2 * w + k) * 4 + (ln >> 4);
+                const int srow = row < nvalid ? row : nvalid - 1;
+                const unsigned off = (unsigned)srow * 256u + (unsigned)(((ln & 15) ^ (row & 15)) * 16);
+                const unsigned lo = slot_off + (unsigned)(2 * w + k) * 1024u;
+                glds16_s(ug, off, ldsG + lo);
+                glds16_s(ua, off, ldsA + lo);
+            }
+        };
+        issue(0, 0);                                     // the first tiles are in flight while the weights arrive from L2
+        issue(1, 1);
+        issue(2, 2);
         bf16x8 w1f[2][4], w2f[2][4];
         f32x4 bias4[2], db1acc[2];
 #pragma unroll
@@ -344,10 +383,20 @@ __global__ __launch_bounds__(S_THR) void k_mlp_bwd_s(const bf16* __restrict__ XN
             bias4[nt] = *reinterpret_cast<const f32x4*>(b1 + q * 128 + h0 + 16 * nt + 4 * g);
             db1acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        barrier_keep_async();                            // tile 0 has landed
+        wait_async();                                    // tiles 0..2 and the weights.  NOT a counted wait: hipcc is free to sink the (const, restrict) weight
+                                                         // loads below this point, and a count that assumes them would then let tile 0 through unfinished
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {                 // ... and a use of every one of them HERE, so that hipcc's own wait for them is not placed inside the loop
+            touch_loaded(bias4[nt]);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) { touch_loaded(w1f[nt][ks]); touch_loaded(w2f[nt][ks]); }
+        }
+        barrier_keep_async();                            // every producer's rows of tile 0 have landed
         TSTART();
-        int sp = 0;                                      // ring slot of tile t (t mod 5, rolling)
-        for (int64_t t = 0; t <= ntiles; ++t, sp = sp == 4 ? 0 : sp + 1) {
+        int sp = 0, si = 3;                              // ring slots of tile t and of tile t+3 (mod 5, rolling)
+        for (int64_t t = 0; t <= ntiles; ++t, sp = sp == 4 ? 0 : sp + 1, si = si == 4 ? 0 : si + 1) {
+            issue((int)t + 3, si);                       // into the slot of tile t-2 (free since the barrier that ended iteration t-1): three tiles of HBM latency cover
+            TMARK(19);
             if (t < ntiles) {
                 const bf16* cA = sA + sp * TL;
                 const bf16* cG = sG + sp * TL;
@@ -376,6 +425,44 @@ __global__ __launch_bounds__(S_THR) void k_mlp_bwd_s(const bf16* __restrict__ XN
                         }
                 };
                 const bool ragged = nvalid != S_BM;      // rows past M (only the last tile of the last range has any) must not leak GELU(b1) into anything
+#if KASF_BWD_F16
+                auto act = [&](int nt) {                 // Phi and GELU' in packed fp16, the products in fp32 (v_fma_mix_f32), H / dZ rounded to bf16 once
+                    f32x2 z[4];
+                    f16x2 ph[4], dgh[4];
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int hp = 0; hp < 2; ++hp)
+                            z[2 * mt + hp] = f32x2{accZ[nt][mt][2 * hp], accZ[nt][mt][2 * hp + 1]};
+#ifdef KASF_KO_GELU
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { ph[k] = __builtin_convertvector(z[k], f16x2); dgh[k] = ph[k]; }
+#else
+                    gelu_grad_pairs_h(z, ph, dgh);
+#endif
+                    if (ragged) {                        // rows past M: H = dZ = 0 (wave-uniform branch; only the last tile of the last range is ragged)
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt) {
+                            const f16 lv = (mt * 16 + i < nvalid) ? (f16)1.0f : (f16)0.0f;
+#pragma unroll
+                            for (int hp = 0; hp < 2; ++hp) { ph[2 * mt + hp] *= f16x2{lv, lv}; dgh[2 * mt + hp] *= f16x2{lv, lv}; }
+                        }
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        float h[4], dz[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const f16 p1 = ph[2 * mt + (r >> 1)][r & 1], d1 = dgh[2 * mt + (r >> 1)][r & 1];
+                            h[r] = __builtin_fmaf((float)p1, accZ[nt][mt][r], 0.0f);
+                            dz[r] = __builtin_fmaf((float)d1, accH[nt][mt][r], 0.0f);
+                            db1acc[nt][r] = __builtin_fmaf((float)d1, accH[nt][mt][r], db1acc[nt][r]);
+                        }
+                        store4(cH + Tile<bf16>::off4(mt * 16 + i, h0 + 16 * nt + 4 * g), h);
+                        store4(cD + Tile<bf16>::off4(mt * 16 + i, h0 + 16 * nt + 4 * g), dz);
+                    }
+                };
+#else
                 auto act = [&](int nt) {
                     f32x2 z[4], dg[4];
 #pragma unroll
@@ -398,6 +485,7 @@ __global__ __launch_bounds__(S_THR) void k_mlp_bwd_s(const bf16* __restrict__ XN
                         store4(cD + Tile<bf16>::off4(mt * 16 + i, h0 + 16 * nt + 4 * g), dz);
                     }
                 };
+#endif
                 gemm(0);
                 __builtin_amdgcn_sched_barrier(0);
                 TMARK(16);
@@ -412,9 +500,11 @@ __global__ __launch_bounds__(S_THR) void k_mlp_bwd_s(const bf16* __restrict__ XN
                 act(1);
                 TMARK(17);
             }
+            wait_async_le<8>();                          // tile t+1 has landed: only the requests of tiles t+3 and t+2 (4 loads each, this wave's only vector-memory traffic) may be in flight
             barrier_keep_async();
             TMARK(18);
         }
+        wait_async();                                    // drain the look-ahead requests before the wave goes on to its epilogue
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -439,50 +529,14 @@ __global__ __launch_bounds__(S_THR) void k_mlp_bwd_s(const bf16* __restrict__ XN
         f32x4 accW1[4][4], accW2[4][4];
         zero_acc(accW1);
         zero_acc(accW2);
-        // four LDS-direct loads per consumer wave: rows [8c, 8c + 8) of g and LN(x) of tile t.  Everything that does not change from tile to tile is
-        // computed once: the two wave-uniform bases of this range (SGPR pairs), the per-lane byte offset inside a tile and the LDS offset of the lane
-        // group; per tile a 32-bit tile offset is added (a range is far below 4 GB).  (The first form rebuilt 64-bit addresses, row counts and selects
-        // from t every time: ~45 scalar instructions in a dependent chain per tile on the wave that bounds the kernel.)
-        const int nt32 = (int)ntiles;
-        const int64_t rows_here = M - tile0 * S_BM;
-        const int rows_in_range = (int)(rows_here < (int64_t)nt32 * S_BM ? rows_here : (int64_t)nt32 * S_BM);
-        const void* ugb = uniform_ptr(G + tile0 * S_BM * 128);
-        const void* uab = uniform_ptr(XN + tile0 * S_BM * 128);
-        const unsigned ldsG = __builtin_amdgcn_readfirstlane(lds_addr(sG)), ldsA = __builtin_amdgcn_readfirstlane(lds_addr(sA));
-        auto issue = [&](int t, int slot) {
-            const int tt = t < nt32 ? t : 0;             // past the range: harmless re-read that keeps the per-issue load count constant
-            int nvalid = rows_in_range - tt * S_BM;
-            nvalid = t < nt32 ? (nvalid < S_BM ? nvalid : S_BM) : 1;
-            const unsigned tile_off = (unsigned)tt * (S_BM * 256u), slot_off = (unsigned)slot * (TL * 2u);
-            const void* ug = (const char*)ugb + tile_off;             // two scalar adds each
-            const void* ua = (const char*)uab + tile_off;
-            int ln = lane;
-            asm volatile("" : "+v"(ln));                 // re-derive the lane's row / chunk here (six vector instructions) instead of holding four more
-                                                         // registers across the loop: the kernel sits at the 256-VGPR cap and would spill a prologue iteration
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int row = (2 * c + k) * 4 + (ln >> 4);
-                const int srow = row < nvalid ? row : nvalid - 1;
-                const unsigned off = (unsigned)srow * 256u + (unsigned)(((ln & 15) ^ (row & 15)) * 16);
-                const unsigned lo = slot_off + (unsigned)(2 * c + k) * 1024u;
-                glds16_s(ug, off, ldsG + lo);
-                glds16_s(ua, off, ldsA + lo);
-            }
-        };
-        issue(0, 0);                                     // the first tiles are in flight while the weights arrive from L2
-        issue(1, 1);
-        issue(2, 2);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) wtf[nt][ks] = *reinterpret_cast<const bf16x8*>(W1t + (int64_t)(ch0 + 16 * nt + i) * 512 + q * 128 + 32 * ks + 8 * g);
-        wait_async();                                    // tiles 0..2 and the weights.  NOT a counted wait: hipcc is free to sink the (const, restrict) weight
-                                                         // loads below this point, and a count that assumes them would then let tile 0 through unfinished
-        barrier_keep_async();
+        barrier_keep_async();                            // (the producers' rows of tile 0 have landed)
         TSTART();
-        int si = 3, sc = 4;                              // ring slots of tile t+3 (issued) and tile t-1 (consumed), rolling mod 5
-        for (int64_t t = 0; t <= ntiles; ++t, si = si == 4 ? 0 : si + 1, sc = sc == 4 ? 0 : sc + 1) {
-            issue((int)t + 3, si);                            // into the slot of tile t-2: three tiles of HBM latency cover
+        int sc = 4;                                      // ring slot of tile t-1 (consumed), rolling mod 5
+        for (int64_t t = 0; t <= ntiles; ++t, sc = sc == 4 ? 0 : sc + 1) {
             TMARK(24);
             f32x4 accA[2][2];
             if (t >= 1) {
@@ -490,8 +544,9 @@ __global__ __launch_bounds__(S_THR) void k_mlp_bwd_s(const bf16* __restrict__ XN
                 const bf16* cG = sG + sc * TL;
                 const bf16* cH = sH + (int)((t - 1) & 1) * TL;
                 const bf16* cD = sD + (int)((t - 1) & 1) * TL;
+                zero_acc(accA);
+#ifndef KASF_KO_DA
                 {   // ---- dA_q partial: 32 channels x 32 tokens over the 128 hidden units of the quarter ----
-                    zero_acc(accA);
                     bf16x8 fd[2][2];
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt) fd[0][mt] = tok_frag(cD, mt * 16 + i, 0);
@@ -509,7 +564,9 @@ __global__ __launch_bounds__(S_THR) void k_mlp_bwd_s(const bf16* __restrict__ XN
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
+#endif
                 TMARK(25);
+#ifndef KASF_KO_WGRAD
                 {   // ---- weight gradients: reduction over the 32 tokens of the tile (one k-step) ----
                     bf16x8 ra[4], cb[4];
 #pragma unroll
@@ -532,14 +589,14 @@ __global__ __launch_bounds__(S_THR) void k_mlp_bwd_s(const bf16* __restrict__ XN
 #pragma unroll
                         for (int b = 0; b < 4; ++b) accW2[a][b] = mfma16(ra[a], cb[b], accW2[a][b]);             // dW2[c][hq] += g^T H
                 }
+#endif
             }
             TMARK(26);
-            // tile t+1 must have landed.  In issue order this wave has, youngest first: loads(t+3) 4, stores(t-2) 4, loads(t+2) 4, stores(t-3) 4, loads(t+1) ...
-            // (every full tile stores exactly 4 times per wave; only the last tile of the last range can store less, and no wait follows it).  The first
-            // iterations have fewer stores in the sequence, so they wait for all but the two youngest load groups instead.
-            if (t >= 3) wait_async_le<16>(); else wait_async_le<8>();
-            TMARK(27);
+#ifdef KASF_KO_DASTORE
+            if (t >= 1 && accA[0][0][0] == 123.456f) {
+#else
             if (t >= 1) {
+#endif
                 const int64_t row0 = (tile0 + t - 1) * S_BM;
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
@@ -557,7 +614,6 @@ __global__ __launch_bounds__(S_THR) void k_mlp_bwd_s(const bf16* __restrict__ XN
             barrier_keep_async();
             TMARK(29);
         }
-        wait_async();                                    // drain the look-ahead requests before the wave retires
         // the quarter's weight-gradient tiles leave as bf16 (round 4: 64 ranges x 0.2 % rounding noise average out two orders below the bf16 operands' own;
         // half the partial bytes of the step's 156 MLP blocks): accumulators -> two [128][128] images in the (now dead) LDS rings -> whole rows out below
         __builtin_amdgcn_s_barrier();                    // (with the producers, which are past their last tile: the rings are free)

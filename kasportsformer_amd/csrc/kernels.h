@@ -11,6 +11,10 @@
 #define KASF_FWD_F16 1
 #endif
 
+#ifndef KASF_BWD_F16            // measurement switch (-DKASF_BWD_F16=0): the round-4 MLP backward producers (fp32 GELU / GELU' with one exponential)
+#define KASF_BWD_F16 1
+#endif
+
 struct KasfPackDesc {
     int64_t src;        // element offset into the fp32 parameter buffer
     int64_t dst;        // element offset into the packed arena

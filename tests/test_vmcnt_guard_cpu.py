@@ -9,7 +9,7 @@ This test compiles every source that contains a counted wait to gfx950 assembly 
 (they are recognisable: emitted between ``;;#ASMSTART`` / ``;;#ASMEND``), around the loop's back edge if it sits in a loop, classifying the
 vector-memory instructions it meets:
   * default rule: the N youngest are all LDS-direct loads (the look-ahead requests the wait is meant to leave in flight);
-  * kernels that interleave stores with the look-ahead (the fused MLP backward) declare their exact youngest-first pattern below;
+  * kernels whose youngest operations may include something else (the fused MLP backward's first iterations) declare their exact youngest-first patterns below;
   * no kernel with counted waits may spill inside a loop (scratch_* between a loop header and its back edge).
 """
 import concurrent.futures as cf
@@ -32,11 +32,10 @@ BRANCH = re.compile(r"^\s+s_cbranch_\w+\s+(\.LBB\d+_\d+)|^\s+s_branch\s+(\.LBB\d
 # youngest-first patterns that are NOT "all LDS-direct loads": (kernel-name regex, N) -> accepted lists of kinds
 G4, S4 = ["glds"] * 4, ["store"] * 4
 DECLARED = {
-    # k_mlp_bwd_s consumer, two-kernel chain, steady state: loads(t+3) 4, stores(t-2) 4, loads(t+2) 4, stores(t-3) 4  (k_mlp3.hip, comment at the wait)
-    (r"k_mlp_bwd_sE", 16): [G4 + S4 + G4 + S4],
-    # its first three iterations (hipcc peels them): fewer stores exist yet; the prologue's weight loads (plain loads) may have been sunk below the
-    # prologue's uncounted wait -- "all but the two youngest load groups" holds in each of these forms
-    (r"k_mlp_bwd_sE", 8): [G4 + G4, G4 + ["load"] * 4, G4 + S4],
+    # k_mlp_bwd_s PRODUCER waves (round 5: they issue the look-ahead loads; the consumers' queue holds stores only and is never waited on): the requests of
+    # tiles t+3 and t+2 stay in flight.  First iterations (hipcc peels them): the prologue's weight loads (plain loads) may have been sunk below the prologue's
+    # uncounted wait -- "all but the two youngest load groups" holds in that form too
+    (r"k_mlp_bwd_sE", 8): [G4 + G4, G4 + ["load"] * 4],
 }
 PATTERN_EXEMPT = ()
 SPILL_OUTSIDE_LOOP_OK = ()

@@ -124,6 +124,15 @@ template <int CASE> __global__ void probe(float* out, long long* cyc) {
                 G8 G8 G8 G8 G8 G8 G8 G8
             }
         }
+        if (CASE == 41) { R16(asm volatile("v_fma_mix_f32 %0, %4, %0, %5 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %1, %4, %1, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %2, %4, %2, %5 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %3, %4, %3, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(k), "v"(c));) }
+        if (CASE == 42) {   // waves 0-3 MFMA only; waves 4-7 v_fma_mix_f32
+            if ((threadIdx.x >> 8) == 0) {
+                R16(asm volatile("v_mfma_f32_16x16x32_bf16 %0, %2, %3, %0\n v_mfma_f32_16x16x32_bf16 %1, %2, %3, %1\n v_mfma_f32_16x16x32_bf16 %0, %2, %3, %0\n v_mfma_f32_16x16x32_bf16 %1, %2, %3, %1" : "+v"(acc), "+v"(acc1) : "v"(fa), "v"(fb));)
+            } else {
+                R16(asm volatile("v_fma_mix_f32 %0, %4, %0, %5 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %1, %4, %1, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %2, %4, %2, %5 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %3, %4, %3, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(k), "v"(c));)
+            }
+        }
+        if (CASE == 43) { R16(asm volatile("v_cvt_f32_f16 %0, %4\n v_cvt_f32_f16_sdwa %1, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n v_cvt_f32_f16 %2, %5\n v_cvt_f32_f16_sdwa %3, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(k), "v"(c));) }
         if (CASE == 11) { R16(asm volatile("v_pk_mul_f32 %0, %0, %4\n v_pk_add_f32 %1, %1, %5\n v_pk_mul_f32 %2, %2, %4\n v_pk_add_f32 %3, %3, %5" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pk), "v"(pc));) }
     }
     const long long t1 = clock64();
@@ -198,5 +207,8 @@ int main(int argc, char** argv) {
     run<37>("w0-3 mfma | 3 waves/SIMD pk_fma_f16 x3", 1024, out, cyc);
     run<39>("w0-3 mfma | w4-7 1 mfma : 7 pk_fma_f16", 512, out, cyc);
     run<40>("w0-3 mfma | w4-7 1 mfma : 7 pk_fma_f32", 512, out, cyc);
+    BOTH(41, "v_fma_mix_f32 (f16 x f32 + f32)")
+    run<42>("waves 0-3 mfma | waves 4-7 fma_mix", 512, out, cyc);
+    BOTH(43, "v_cvt_f32_f16 (plain / sdwa hi)")
     return 0;
 }
