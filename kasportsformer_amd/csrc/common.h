@@ -510,7 +510,11 @@ __device__ __forceinline__ void wait_async() { asm volatile("s_waitcnt vmcnt(0)"
 // A register USE of a value loaded by an ordinary (compiler-tracked) load.  Placed after a prologue's wait_async(), in front of a loop that keeps LDS-direct
 // requests in flight: hipcc's own s_waitcnt for the first use of a pre-loop load otherwise lands INSIDE the loop -- as vmcnt(1) / vmcnt(0) per iteration, because
 // it cannot see the inline-asm requests issued since -- and drains the look-ahead every tile (round 5: 155 -> 188 us on k_mlp_bwd_s; DESIGN section 4, compiler traps).
+#ifdef KASF_NO_TOUCH_LOADED          // negative control of tests/test_vmcnt_guard_cpu.py only
+template <typename V> __device__ __forceinline__ void touch_loaded(const V&) {}
+#else
 template <typename V> __device__ __forceinline__ void touch_loaded(const V& v) { asm volatile("" ::"v"(v)); }
+#endif
 template <int N> __device__ __forceinline__ void wait_async_le() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 // workgroup barrier WITHOUT the vmcnt(0)/lgkmcnt(0) drain __syncthreads() adds while LDS-direct loads are in flight
 __device__ __forceinline__ void barrier_keep_async() {

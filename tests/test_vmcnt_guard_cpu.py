@@ -169,3 +169,58 @@ def test_no_spills_inside_loops_of_kernels_with_counted_waits(asm_files):
                     if inside or not any(re.search(rx, name) for rx in SPILL_OUTSIDE_LOOP_OK):
                         problems.append(f"{src}:{name}: spill at line {i} ({'inside' if inside else 'outside'} a loop): {ln.strip()}")
     assert not problems, "\n".join(problems[:20])
+
+
+def _compiler_drains(asm_files):
+    """Round 5 (k_mlp_bwd_s, 155 -> 188 us): hipcc places its OWN `s_waitcnt vmcnt(k)` in front of the first use of a value loaded before a loop -- inside the
+    loop when nothing uses the value earlier, and with a small k, because it does not see the inline-asm LDS-direct requests issued since.  Every iteration then
+    drains the look-ahead.  In a loop that holds a hand-counted wait vmcnt(N), a compiler-generated wait with k < N is that defect (the cure: a register use of
+    every pre-loop load right after the prologue's wait -- touch_loaded() in csrc/common.h)."""
+    problems = []
+    for src, path in asm_files.items():
+        for name, body in kernels_of(path):
+            hand = counted_waits(body)
+            if not hand:
+                continue
+            hand_at = {i for i, _ in hand}
+            all_loops = [(h, e) for h, e in loops_of(body) if "Loop Header" in body[h] or "in Loop:" in body[h]]      # real loops only (hipcc marks their headers); a backward branch into
+                                                                                             # a shared block is not one
+            innermost = set()                    # every real loop around a hand-counted wait (hipcc lays a loop out as several label-to-branch cycles: the
+            for at, n in hand:                   # latch blocks in front of the header, a short cycle for the iterations that skip the body)
+                if n > 0:
+                    innermost.update((h, e) for h, e in all_loops if h <= at <= e)
+            for h, e in sorted(innermost):
+                mine = [n for i, n in hand if h <= i <= e and n > 0]
+                if not mine or not any("global_load_lds" in body[i] for i in range(h, e + 1)):
+                    continue
+                in_asm = False
+                for i in range(h, e + 1):
+                    ln = body[i]
+                    if "#ASMSTART" in ln:
+                        in_asm = True
+                    elif "#ASMEND" in ln:
+                        in_asm = False
+                    elif not in_asm and i not in hand_at:
+                        m = re.match(r"^\s+s_waitcnt\b.*vmcnt\((\d+)\)", ln)
+                        if m and int(m.group(1)) < min(mine):
+                            problems.append(f"{src}:{name}: compiler-generated '{ln.strip()}' at line {i} inside the loop whose counted wait is vmcnt({min(mine)})")
+    return problems
+
+
+def test_no_compiler_wait_drains_the_look_ahead_inside_a_loop(asm_files):
+    problems = _compiler_drains(asm_files)
+    assert not problems, "\n".join(problems[:20])
+
+
+def test_the_drain_guard_sees_the_defect_it_was_written_for():
+    """Negative control: k_mlp3.hip with touch_loaded() compiled out must show hipcc's in-loop vmcnt(1) / vmcnt(0) in k_mlp_bwd_s again."""
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    out = os.path.join(CSRC, "build", "asm", "k_mlp3_no_touch.s")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-DKASF_NO_TOUCH_LOADED", "-I" + os.path.join(ROOT, "include"),
+           "-I" + CSRC, "--cuda-device-only", "-S", "-o", out, os.path.join(CSRC, "k_mlp3.hip")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    problems = _compiler_drains({"k_mlp3.hip": out})
+    assert any("k_mlp_bwd_s" in p for p in problems), "the guard no longer recognises the in-loop drain"
