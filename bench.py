@@ -104,13 +104,31 @@ PROFILES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
 
 
 def _profile(name):
-    """Newest committed round of a profile file (profiles/r4_<name>, else r3_ / r2_<name>): counters cannot be read from inside the process, so the bench
-    line QUOTES the committed summaries of separate rocprofv3 runs of the same launches (tools/refresh_profiles_r3.sh) and says so (`*_source`)."""
-    for rnd in ("r4", "r3", "r2"):
+    """Newest committed round of a profile file (profiles/r5_<name>, else r4_ / r3_ / r2_<name>): counters cannot be read from inside the process, so the bench
+    line QUOTES the committed summaries of separate rocprofv3 runs of the same launches (tools/refresh_profiles_r5.sh) and says so (`*_source`)."""
+    for rnd in ("r5", "r4", "r3", "r2"):
         f = os.path.join(PROFILES, f"{rnd}_{name}")
         if os.path.exists(f):
             return f
-    return os.path.join(PROFILES, f"r4_{name}")
+    return os.path.join(PROFILES, f"r5_{name}")
+
+
+STALE = []           # quoted profile files whose stamp is not this tree's (tools/stamp.py): reported as "profile_stale" and NOT quoted
+
+
+def fresh(path):
+    """True if `path` was measured on the sources this library is built from (its stamp's source_sha256 = sha256 over csrc/ + include/kasf.h of this tree).
+    A kernel edited after the last refresh, or a pre-round-5 file without a stamp, is stale: the bench line then omits the figure instead of shipping last
+    round's traffic / in-step numbers beside this round's kernels."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import stamp
+    finally:
+        sys.path.pop(0)
+    ok = os.path.exists(path) and stamp.is_fresh(path, ROOT)
+    if not ok and os.path.exists(path) and os.path.basename(path) not in STALE:
+        STALE.append(os.path.basename(path))
+    return ok
 
 
 TRAFFIC_FILE = _profile("pmc_traffic.json")            # tools/pmc_traffic.py (two --pmc passes over tools/mlp_bench.py)
@@ -125,7 +143,7 @@ TRAFFIC_PARTS = {"k_mlp_fwd_s": {"k_mlp_fwd_s": 1}, "k_mlp_bwd_s(+lnbwd_sum4_fin
 def pmc_traffic(entry, M):
     """HBM bytes per launch of a micro-benchmark entry, from the committed rocprofv3 --pmc summary (tools/pmc_traffic.py; the
     counters cannot be read from inside the process).  Only valid for the token count the summary was collected at."""
-    if entry not in TRAFFIC_PARTS or M != BATCH_PER_GPU * T * 17 or not os.path.exists(TRAFFIC_FILE):
+    if entry not in TRAFFIC_PARTS or M != BATCH_PER_GPU * T * 17 or not fresh(TRAFFIC_FILE):
         return None
     ks = json.load(open(TRAFFIC_FILE))["kernels"]
     if any(k not in ks for k in TRAFFIC_PARTS[entry]):
@@ -138,7 +156,7 @@ def in_step_duration(kernel_names, stats_file=None):
     streams overlap, so a launch shares the chip with the other two branches -- the honest figure next to the isolated micro-benchmark."""
     import csv
     stats_file = stats_file or IN_STEP_STATS
-    if not os.path.exists(stats_file):
+    if not fresh(stats_file):
         return None
     total = 0.0
     for r in csv.DictReader(open(stats_file)):
@@ -227,21 +245,25 @@ def workload_name(args, world, strong):
 
 def parity_summary():
     """What the parity tests OBSERVED on the shipped kernels, read from the files tests/test_gpu_model.py::test_full_depth_26_layers_against_oracle writes
-    (gpurun_out/r4_parity_26layers_<mode>.json, committed as profiles/...): nothing in this string is typed in."""
+    (gpurun_out/r5_parity_26layers_<mode>.json, committed as profiles/...): nothing in this string is typed in."""
     out = {}
     for cd in ("fp32", "bf16"):
         f = _profile(f"parity_26layers_{cd}.json")
-        if not os.path.exists(f):
+        if not fresh(f):
             out[cd] = None
             continue
         r = json.load(open(f))
         out[cd] = {"samples": len(r["samples"]), "forward_rel_err_median": r["forward_rel_err_median"], "forward_rel_err_max": r["forward_rel_err_max"],
                    "gradient_cosine_median": r["gradient_cosine_median"], "gradient_cosine_min": r["gradient_cosine_min"],
                    "topk_rows_identical_pct": r["topk_rows_identical_pct"], "source": "committed file profiles/" + os.path.basename(f)}
+        if "forward_rel_err_free_running_max" in r:      # the oracle taking its OWN top-4 decisions instead of following the HIP path's: the flipped near-ties are O(1) changes of a token
+            out[cd]["forward_rel_err_free_running"] = r["forward_rel_err_free_running_max"]
+            out[cd]["topk_rows_differ"] = r["topk_rows_differ"]
+            out[cd]["topk_rows_differ_not_near_tie"] = r["topk_rows_differ_not_near_tie"]
     out["what"] = ("26-layer HIP model vs the CPU oracle following the same top-4 neighbour decisions, B = 2, de-identitied weights "
                    "(tests/test_gpu_model.py::test_full_depth_26_layers_against_oracle; bf16 = this line's mode: (input seed, weight salt) samples)")
     f = _profile("train_fidelity.json")
-    if os.path.exists(f):
+    if os.path.exists(f):                    # (a 1,000-step training run, not a per-build measurement: quoted by name whatever its stamp)
         out["training_fidelity_source"] = "committed file profiles/" + os.path.basename(f) + " (tools/train_fidelity.py: 1,000 steps at full depth, bf16 vs fp32 mode)"
     return out
 
@@ -265,6 +287,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-kernel-roofline", action="store_true")
     ap.add_argument("--no-fp32", action="store_true", help="skip the fp32 parity-mode throughput leg")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the legs for BASELINE configs[2] (per-rank shape), [3] and [4] that follow the headline at N = 1")
+    ap.add_argument("--grad-dtype", choices=("fp32", "bf16"), default="fp32", help="wire format of the gradient all-reduce (bf16: 58.7 MB per step instead of 117.4)")
     ap.add_argument("--force-dp", action="store_true", help="testing: take the data-parallel code path (stage-sliced backward, RCCL all-reduce) with one rank")
     ap.add_argument("--launch-only", action="store_true", help="testing: the ranks rendezvous, all-reduce one number and leave (gloo without GPUs); no model")
     return ap.parse_args(argv)
@@ -437,7 +460,7 @@ def main():
     opt = K.FusedAdamW(model, lr=5e-4, weight_decay=0.01)
     dp = None
     if (world > 1 or args.force_dp) and not args.eval_only:
-        dp = K.DataParallel(model, overlap=os.environ.get("KASF_DP_OVERLAP", "1") != "0", optimizer=opt)     # sets opt.grad_scale = 1 / world
+        dp = K.DataParallel(model, overlap=os.environ.get("KASF_DP_OVERLAP", "1") != "0", optimizer=opt, grad_dtype=args.grad_dtype)     # sets opt.grad_scale = 1 / world
         if os.environ.get("KASF_DP_SKIP_ALLREDUCE") == "1":          # diagnosis only: process group alive, no collective in the step
             model.grad_stage_hook = None
             dp.finish_gradients = lambda *a: None
@@ -541,7 +564,8 @@ def main():
             "config": {"workload": workload_name(args, world, strong), "n_layers": LAYERS,
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world, "n_frames": Tn, "tokens_per_step_per_gpu": args.batch * Tn * 17,
                        "input": "detector confidence ~U(0,1), 1920x1080" if args.det_conf else "ground-truth 2-D (confidence 1), 1312x1216",
-                       "parallelism": f"dp{world}" if world > 1 else "single", "init": "reference default init, seed 114514"},
+                       "parallelism": f"dp{world}" if world > 1 else "single", "init": "reference default init, seed 114514",
+                       **({"gradient_allreduce": "bf16 on the wire, fp32 master gradient"} if (dp is not None and args.grad_dtype == "bf16") else {})},
             "per_rank_clips_per_sec": per_rank,
             "final_loss": loss_val,
             "eval": {"clips_per_sec": args.batch * world / dt_eval, "clips_per_sec_flip_tta": args.batch * world / dt_tta,
@@ -583,7 +607,7 @@ def main():
                                                                            "frac": ks[dom]["algorithmic_flop"] / t_full / 1e12 / PEAK_BF16_TFLOPS, "cus": 256,
                                                                            "source": "committed file profiles/" + os.path.basename(ISOLATED_FULL_STATS) + " (the same with KASF_NARROW_PCTS=100,100,100,100,100,100,100); "
                                                                                      "the event-timed figure above is a back-to-back loop of this chain alone, where the same two kernels take longer per launch"}
-            if os.path.exists(STEP_TRAFFIC_FILE) and headline:
+            if headline and fresh(STEP_TRAFFIC_FILE):
                 out["step_hbm_GB"] = json.load(open(STEP_TRAFFIC_FILE))["hbm_GB_per_step"]
                 out["step_hbm_GB_source"] = "committed file profiles/" + os.path.basename(STEP_TRAFFIC_FILE)
             out["kernels"] = {k: {"ms": v["seconds"] * 1e3, "tflops": v["achieved_tflops"]} for k, v in ks.items()}
@@ -597,6 +621,9 @@ def main():
                 log("fp32 parity-mode leg done")
             if not args.no_cpu_baseline and not args.eval_only and Tn == T:
                 out["cpu_baseline"] = cpu_baseline()
+        out["profile_stale"] = bool(STALE)       # a quoted committed file was measured on other sources than this library's: its figures are omitted above
+        if STALE:
+            out["profile_stale_files"] = sorted(STALE)
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if world > 1 or args.force_dp:

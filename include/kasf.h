@@ -53,13 +53,19 @@ const char* kasf_last_error(void);
 /* Process-wide: 1 = the three branches of a layer run back to back on the caller's stream instead of on three streams (the mode isolated kernel
  * profiles are taken in; it costs a quarter of the training throughput since round 4: the MLP launches of the engine take half the chip -- so that two
  * branches' launches run side by side -- and the grids are the same in both settings, for the sake of the bits).  NOT a determinism switch: gradients are reproducible from run to run either way and
- * the two settings give the same bits (every gradient reduction is a fixed-order sum; the one exception is the BatchNorm batch statistics, whose
- * per-node sums cross workgroups as fp64 atomic adds of fp32-derived partials -- order-dependent below 1e-15 relative, which can move an fp32 mean by
- * one ulp in rare cases; tests/test_gpu_determinism.py has not seen it).  Default 0 (or 1 when KASF_SINGLE_STREAM is set in the environment).
+ * the two settings give the same bits (every gradient reduction is a fixed-order sum; the BatchNorm batch statistics, which cross workgroups through
+ * atomics, are accumulated EXACTLY -- 52-bit pieces of a fixed-point number, 64-bit integer atomic adds, csrc/k_gcn.hip -- so their totals do not depend on
+ * arrival order either: since ABI 7 there is no exception left).  Default 0 (or 1 when KASF_SINGLE_STREAM is set in the environment).
  * kasf_forward / kasf_backward read the setting once per call.  kasf_set_deterministic / kasf_get_deterministic are the round-3 names of the same
  * two functions, kept as aliases. */
 void kasf_set_single_stream(int32_t on);
 int32_t kasf_get_single_stream(void);
+/* Process-wide: from how many tokens per launch (M = batch x frames x 17) the bf16 backward forms the mixers' weight gradients INSIDE the data-gradient kernels
+ * (one bf16 partial tile per workgroup, fixed-order reduce) instead of in a separate streaming launch.  Default 40,000 (below it the partial tiles cost more
+ * than the second pass over dY they save); tokens < 0 restores the default.  Both forms are bit-reproducible; they differ from each other at bf16 rounding
+ * level (tests/test_gpu_determinism.py compares them on one shape). */
+void kasf_set_fused_wgrad_min_tokens(int64_t tokens);
+int64_t kasf_get_fused_wgrad_min_tokens(void);
 void kasf_set_deterministic(int32_t on);
 int32_t kasf_get_deterministic(void);
 int kasf_version(void);

@@ -35,6 +35,8 @@ SIGNATURES = {
     "kasf_last_error": (C.c_char_p, []),
     "kasf_version": (_i32, []),
     "kasf_set_single_stream": (None, [_i32]),
+    "kasf_set_fused_wgrad_min_tokens": (None, [_i64]),
+    "kasf_get_fused_wgrad_min_tokens": (_i64, []),
     "kasf_get_single_stream": (_i32, []),
     "kasf_set_deterministic": (None, [_i32]),
     "kasf_get_deterministic": (_i32, []),

@@ -51,7 +51,8 @@ static bool single_stream() {
 #ifndef KASF_WG_FUSE_MIN_TOKENS
 #define KASF_WG_FUSE_MIN_TOKENS 40000
 #endif
-constexpr int64_t WG_FUSE_MIN_TOKENS = KASF_WG_FUSE_MIN_TOKENS;
+static std::atomic<int64_t> g_wg_fuse_min_tokens{KASF_WG_FUSE_MIN_TOKENS};      // kasf_set_fused_wgrad_min_tokens(): tests compare the fused with the two-kernel sequence on one shape
+#define WG_FUSE_MIN_TOKENS (g_wg_fuse_min_tokens.load(std::memory_order_relaxed))
 constexpr int64_t WG_JOBS_FLOATS = 248 * 128 * 128 + 248 * 128 + 4096;   // the proj job alone: 248 splits of one 128 x 128 tile + their bias rows
 constexpr int64_t WG_BF16_BYTES = (int64_t)256 * 384 * 128 * 2 + (int64_t)256 * 128 * 128 * 2 + 256 * 128 * 4;         // <= 256 bf16 partial tiles of the block's fused data + weight gradient launches (qkv: 384 rows; q + kv: 128 + 256)
 constexpr int64_t WG_PARTIAL_FLOATS = (KASF_MLP_PARTIAL_FLOATS + 65536 > WG_JOBS_FLOATS + WG_BF16_BYTES / 4 ? KASF_MLP_PARTIAL_FLOATS + 65536 : WG_JOBS_FLOATS + WG_BF16_BYTES / 4);   // per-split weight-gradient tiles (256 workgroups x 128x128, or 64 ranges x (dW1 + dW2) of the MLP) + the per-split rows of a bias gradient
@@ -278,11 +279,11 @@ void build_plan(const kasf_model* m, int B, bool train, bool names, Plan& p) {
     p.layers.resize(nl);
     p.stats_begin = cur;
     for (int l = 0; l < nl; ++l)
-        for (int b = 2; b < 4; ++b) p.layers[l].b[b].stats = take((int64_t)KASF_STAT_LD * KASF_STAT_SLOTS, 2, "bn_stats", l, b);
+        for (int b = 2; b < 4; ++b) p.layers[l].b[b].stats = take((int64_t)KASF_STAT_LD * KASF_STAT_SLOTS * KASF_STAT_WORDS, 2, "bn_stats", l, b);
     p.stats_bytes = cur - p.stats_begin;
     p.bstats_begin = cur;
     for (int l = 0; l < nl; ++l)
-        for (int b = 2; b < 4; ++b) p.layers[l].b[b].bstats = take((int64_t)KASF_STAT_LD * KASF_STAT_SLOTS, 2, "bn_bwd_stats", l, b);
+        for (int b = 2; b < 4; ++b) p.layers[l].b[b].bstats = take((int64_t)KASF_STAT_LD * KASF_STAT_SLOTS * KASF_STAT_WORDS, 2, "bn_bwd_stats", l, b);
     p.bstats_bytes = cur - p.bstats_begin;
     p.x3 = take(M * 3, 1, "x_input");
     p.bone3 = take(M * 3, 1, "bone3");
@@ -569,6 +570,8 @@ const char* kasf_last_error(void) { return g_err.c_str(); }
 void kasf_set_single_stream(int32_t on) { g_single_stream.store(on ? 1 : 0, std::memory_order_relaxed); }
 int32_t kasf_get_single_stream(void) { return single_stream() ? 1 : 0; }
 // the round-3 names: the setting never was about determinism (gradients are bit-reproducible either way)
+void kasf_set_fused_wgrad_min_tokens(int64_t tokens) { g_wg_fuse_min_tokens.store(tokens < 0 ? (int64_t)KASF_WG_FUSE_MIN_TOKENS : tokens, std::memory_order_relaxed); }
+int64_t kasf_get_fused_wgrad_min_tokens(void) { return g_wg_fuse_min_tokens.load(std::memory_order_relaxed); }
 void kasf_set_deterministic(int32_t on) { kasf_set_single_stream(on); }
 int32_t kasf_get_deterministic(void) { return kasf_get_single_stream(); }
 int kasf_version(void) { return 7; }

@@ -20,17 +20,52 @@ constexpr int COEF_LD = 8;      // per node: scale, shift, mean, rstd, c1, c2, -
 constexpr int MASK_W = 3;       // 32-bit words per adjacency row of the T <= 96 instantiations (any T: kasf_gcn_mask_words)
 constexpr int SX_LD = 132;      // padded fp32 row of the temporal tiles
 
-// Batch statistics are accumulated in KASF_STAT_SLOTS copies ([slot][96 nodes][2] doubles, slot = workgroup index mod slots): a thousand
-// workgroups each ending in fp64 atomics on the same 34..162 addresses serialise at the memory side (44 us for the spatial aggregate with one
-// copy, 24 us without the atomics); readers add the copies up.
+// Batch statistics cross workgroups through an EXACT accumulator (round 5): every per-workgroup partial sum is split into 52-bit pieces of a fixed-point
+// number and added with 64-bit INTEGER atomics -- integer addition is associative, so the total does not depend on the order in which workgroups arrive
+// (the fp64 atomic adds of rounds 1-4 were order-dependent below 1e-15 relative: the one stated exception to bit-reproducible gradients, include/kasf.h).
+// One statistic = KASF_STAT_WORDS int64 words: word k (k < 4) counts units of 2^(KASF_STAT_E0 + 52 k), i.e. bits 2^-110 .. 2^98 (partials are fp32 sums: their 24-bit
+// mantissas straddle at most two words; what lies below 2^-110 is dropped, toward -inf); 12 spare bits per word hold the carries of up to 2^11 additions
+// (grids are capped at 1,024 workgroups, 256 per slot); word 4 is a poison flag (a non-finite or >= 2^97 partial: readers return NaN, as the fp64 sum did).
+// KASF_STAT_SLOTS copies ([slot][2 x 256 nodes][words], slot = workgroup index mod slots) because a thousand workgroups each ending in atomics on the same
+// 34..162 addresses serialise at the memory side (44 us for the spatial aggregate with one copy, 24 us without the atomics); readers add the copies up.
+constexpr int KASF_STAT_E0 = -110;
 __device__ __forceinline__ double stat_sum(const double* stats, int idx) {
-    double v = 0.0;
+    const long long* w = reinterpret_cast<const long long*>(stats);
+    long long acc[KASF_STAT_WORDS];
 #pragma unroll
-    for (int sl = 0; sl < KASF_STAT_SLOTS; ++sl) v += stats[sl * KASF_STAT_LD + idx];
+    for (int k = 0; k < KASF_STAT_WORDS; ++k) acc[k] = 0;
+#pragma unroll
+    for (int sl = 0; sl < KASF_STAT_SLOTS; ++sl)
+#pragma unroll
+        for (int k = 0; k < KASF_STAT_WORDS; ++k) acc[k] += w[((int64_t)sl * KASF_STAT_LD + idx) * KASF_STAT_WORDS + k];
+    if (acc[KASF_STAT_WORDS - 1] != 0) return __builtin_nan("");
+    double v = 0.0;                              // most significant word first; every term is an exactly scaled integer, the three additions round deterministically
+#pragma unroll
+    for (int k = KASF_STAT_WORDS - 2; k >= 0; --k) v += ldexp((double)acc[k], KASF_STAT_E0 + 52 * k);
     return v;
 }
-__device__ __forceinline__ void stat_add(double* slot, double v) { atomicAdd(slot, v); }
-__device__ __forceinline__ double* stat_slot(double* stats) { return stats + (blockIdx.x % KASF_STAT_SLOTS) * KASF_STAT_LD; }
+__device__ __forceinline__ void stat_add(double* slot, int idx, double v) {
+    unsigned long long* w = reinterpret_cast<unsigned long long*>(slot) + (int64_t)idx * KASF_STAT_WORDS;
+    if (v == 0.0) return;
+    if (!(fabs(v) < 0x1p97)) { atomicOr(w + KASF_STAT_WORDS - 1, 1ull); return; }      // NaN, inf, or beyond the accumulator's range
+    int e;
+    const double m = frexp(v, &e);               // v = m 2^e, 1/2 <= |m| < 1
+    unsigned long long a = (unsigned long long)ldexp(fabs(m), 53);                     // 53-bit integer mantissa: |v| = a 2^(e - 53)
+    int p = e - 53 - KASF_STAT_E0;               // position of a's lowest bit above the accumulator's lowest
+    const bool neg = v < 0.0;
+    if (p < 0) {                                 // bits below 2^E0: dropped toward -inf (floor of the signed value)
+        const int sh = -p;
+        if (sh >= 54) { a = neg ? 1 : 0; }
+        else { const unsigned long long lost = a & ((1ull << sh) - 1); a >>= sh; if (neg && lost) a += 1; }
+        p = 0;
+        if (a == 0) return;
+    }
+    const int k = p / 52, r = p % 52;
+    const unsigned long long lo = (a & ((1ull << (52 - r)) - 1)) << r, hi = a >> (52 - r);      // lo < 2^52 in word k, hi < 2^(r+2) in word k + 1 (k + 1 <= 3 below 2^97)
+    if (lo) atomicAdd(w + k, neg ? (0ull - lo) : lo);
+    if (hi) atomicAdd(w + k + 1, neg ? (0ull - hi) : hi);
+}
+__device__ __forceinline__ double* stat_slot(double* stats) { return stats + (int64_t)(blockIdx.x % KASF_STAT_SLOTS) * KASF_STAT_LD * KASF_STAT_WORDS; }
 
 // 32-bit token arithmetic (the engine bounds M * 16 below 2^31): a 64-bit divide by 17 is ~40 instructions per lane, paid by all 16 lanes of a token
 __device__ __forceinline__ int node_of(int tok, int T, int mode) { return mode == 0 ? tok % KASF_J : (tok / KASF_J) % T; }
@@ -75,7 +110,7 @@ __global__ __launch_bounds__(256) void k_gcn_agg_spatial(const T* __restrict__ u
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) t += sStat[k][threadIdx.x];
-        stat_add(stat_slot(stats) + threadIdx.x, (double)t);
+        stat_add(stat_slot(stats), threadIdx.x, (double)t);
     }
 }
 
@@ -291,7 +326,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && L == 81) ? 3 : 1) void k_gc
         }
     }
     __syncthreads();
-    if (threadIdx.x < 2 * L) stat_add(stat_slot(stats) + threadIdx.x, (double)sStat[threadIdx.x]);
+    if (threadIdx.x < 2 * L) stat_add(stat_slot(stats), threadIdx.x, (double)sStat[threadIdx.x]);
 }
 
 // ------------------------------------------------------------------ BatchNorm1d(num_nodes) + ReLU + layer-scale + residual
@@ -428,7 +463,7 @@ __global__ __launch_bounds__(256) void k_gcn_bwd1(const T* __restrict__ g, const
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) t += sStat[k * 2 * nodes + idx];
-        stat_add(stat_slot(bstats) + idx, (double)t);
+        stat_add(stat_slot(bstats), idx, (double)t);
     }
 }
 
@@ -721,7 +756,7 @@ __global__ __launch_bounds__(256) void k_gcn_agg_temporal_g(const T* __restrict_
         }
     }
     __syncthreads();
-    for (int idx = threadIdx.x; idx < 2 * L; idx += 256) stat_add(stat_slot(stats) + idx, (double)sStat[idx]);
+    for (int idx = threadIdx.x; idx < 2 * L; idx += 256) stat_add(stat_slot(stats), idx, (double)sStat[idx]);
 }
 
 template <typename T>

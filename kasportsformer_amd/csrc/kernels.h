@@ -94,8 +94,10 @@ void kasf_launch_mlp_bwd_q(hipStream_t s, const void* x, const void* xn, const v
                            const void* W2ts, const void* W1t, void* dApart, float* partial, float* dW1, float* dW2, float* db1, float* gsum, void* g_in,
                            float* dgamma, float* dbeta, int64_t M, const float* W2 = nullptr, const float* b2 = nullptr, const float* ls2 = nullptr,
                            float* dls2 = nullptr, KasfColSink* sink = nullptr);
-// BatchNorm batch-statistics buffers: KASF_STAT_SLOTS copies of [KASF_MAX_NODES][2] doubles (k_gcn.hip: producers pick a copy by workgroup index)
+// BatchNorm batch-statistics buffers: KASF_STAT_SLOTS copies of [KASF_MAX_NODES][2] statistics of KASF_STAT_WORDS 64-bit words each (k_gcn.hip: an exact
+// fixed-point accumulator fed by integer atomics; producers pick a copy by workgroup index)
 #define KASF_STAT_SLOTS 4
+#define KASF_STAT_WORDS 5
 #define KASF_MAX_NODES 256                 // BatchNorm1d channels = joints (17) or frames: n_frames <= 256
 #define KASF_STAT_LD (2 * KASF_MAX_NODES)
 // 32-bit words per row of the stored temporal adjacency (bit c of word c >> 5 = "frame c is a neighbour")

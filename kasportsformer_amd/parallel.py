@@ -20,9 +20,18 @@ import torch.distributed as dist
 
 
 class DataParallel:
-    def __init__(self, model, process_group=None, overlap=True, stages_per_bucket=7, optimizer=None):
+    def __init__(self, model, process_group=None, overlap=True, stages_per_bucket=7, optimizer=None, grad_dtype="fp32"):
         """``stages_per_bucket`` backward stages (layers) share one all-reduce: 4 buckets of ~30 MB instead of 27 of 4.5 MB keep the
-        per-bucket host and launch overhead off the step (xGMI ring all-reduce of 117 MB is ~1 ms; the point of the buckets is overlap)."""
+        per-bucket host and launch overhead off the step (xGMI ring all-reduce of 117 MB is ~1 ms; the point of the buckets is overlap).
+
+        ``grad_dtype="bf16"`` (optional): every bucket is cast to bf16, all-reduced (58.7 MB per step instead of 117.4 MB on the wire) and
+        widened back into the flat fp32 gradient; master weights, moments and the optimizer step stay fp32.  The sum over ranks is then formed in bf16 by the
+        collective (every addition rounds to 8 significant bits): at the per-rank batch of configs[2] (32 clips, a 14 ms step) it halves what the all-reduce has
+        to hide; the default stays fp32."""
+        if grad_dtype not in ("fp32", "bf16"):
+            raise ValueError(f"grad_dtype {grad_dtype!r}: 'fp32' or 'bf16'")
+        self.grad_dtype = grad_dtype
+        self._wire = {}                  # (bucket address, elements) -> persistent bf16 staging buffer
         if not dist.is_initialized():
             raise RuntimeError("init torch.distributed first (backend 'nccl' = RCCL on ROCm; 'gloo' for CPU rehearsal)")
         if model._flat.is_cuda and os.environ.get("GPU_MAX_HW_QUEUES") is None:
@@ -66,8 +75,20 @@ class DataParallel:
             dist.broadcast(t, src=0, group=self.group)
         m.mark_weights_dirty()
 
+    def _reduce(self, grad_slice, async_op):
+        """One bucket: returns (work, staging buffer or None).  bf16: cast on the current stream (the bucket's gradients are final there), reduce the copy."""
+        if self.grad_dtype == "fp32":
+            return dist.all_reduce(grad_slice, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op), None
+        key = (grad_slice.data_ptr(), grad_slice.numel())
+        buf = self._wire.get(key)
+        if buf is None:
+            buf = self._wire[key] = torch.empty(grad_slice.numel(), dtype=torch.bfloat16, device=grad_slice.device)
+        buf.copy_(grad_slice)
+        return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op), buf
+
     def _on_stage(self, stage, grad_slice):
-        self._pending.append(dist.all_reduce(grad_slice, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        work, buf = self._reduce(grad_slice, True)
+        self._pending.append((work, buf, grad_slice))
 
     def finish_gradients(self, optimizer=None):
         """Call after loss.backward(): waits for the bucketed all-reduces (or runs one when overlap is off).  Pass (or attach) the optimizer so
@@ -81,11 +102,15 @@ class DataParallel:
             raise RuntimeError("DataParallel.finish_gradients: no optimizer attached (DataParallel(model, optimizer=opt) or finish_gradients(opt)): "
                                "the all-reduced gradient is a sum over ranks and nobody would divide it by world_size")
         if self.overlap:
-            for w in self._pending:
-                w.wait()
+            for work, buf, grad_slice in self._pending:
+                work.wait()
+                if buf is not None:
+                    grad_slice.copy_(buf)                  # widen the reduced bf16 bucket back into the flat fp32 gradient
             self._pending = []
         elif m.flat_grad is not None:
-            dist.all_reduce(m.flat_grad[:m.n_live], op=dist.ReduceOp.SUM, group=self.group)
+            _, buf = self._reduce(m.flat_grad[:m.n_live], False)
+            if buf is not None:
+                m.flat_grad[:m.n_live].copy_(buf)
         if self._scale_in_place and self.world > 1 and m.flat_grad is not None:
             m.flat_grad[:m.n_live].mul_(1.0 / self.world)         # p.grad of every live parameter is a view of this array
 

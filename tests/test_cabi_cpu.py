@@ -165,3 +165,101 @@ def test_unsupported_configurations_raise_like_the_reference():
     assert isinstance(K.load_model(args), K.KASportsFormer)
     with pytest.raises(Exception):
         K.load_model(dict(args, model_name="MotionAGFormer"))
+
+
+def test_device_free_entry_points_under_address_and_ub_sanitizers(tmp_path):
+    """SURVEY section 5.2 (sanitizers; GPU ASan is not available on the pool, so: the host side).  `make asan` builds engine.hip's host code with
+    -fsanitize=address,undefined; a C driver built with the same runtime creates layout-only handles for the shipped and for corner configurations and walks
+    every query that needs no device -- names with exact-fit and too-short buffers, out-of-range indices, every stage and workspace entry in every flag
+    combination -- then destroys them.  Any heap / stack / global overflow, use after free, signed overflow or misaligned access in that code aborts the driver."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    clang = "/opt/rocm/lib/llvm/bin/clang"
+    if not (os.path.exists(hipcc) and os.path.exists(clang)):
+        pytest.skip("ROCm clang not available")
+    csrc = os.path.join(ROOT, "kasportsformer_amd", "csrc")
+    r = subprocess.run(["make", "-C", csrc, "-j", "4", "all", "asan"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    src = tmp_path / "walk.c"
+    src.write_text(r'''#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "kasf.h"
+static int walk(kasf_config cfg) {
+    kasf_model* m = 0;
+    if (kasf_model_create_layout_only(&cfg, &m) != 0) { printf("create failed: %s\n", kasf_last_error()); return 2; }
+    long long total = 0;
+    int32_t n = kasf_param_entries(m);
+    for (int32_t i = -1; i <= n; ++i) {                          /* one past both ends on purpose */
+        char* name = malloc(96);                                 /* heap buffers: ASan sees a one-byte overrun */
+        int64_t off = 0, shape[4] = {0, 0, 0, 0};
+        int32_t nd = 0;
+        int rc = kasf_param_entry(m, i, name, 96, &off, &nd, shape);
+        if ((i < 0 || i >= n) != (rc != 0)) { printf("param index %d: rc %d\n", i, rc); return 3; }
+        if (rc == 0) {
+            size_t len = strlen(name);
+            char* tight = malloc(len + 1);                       /* exact fit */
+            if (kasf_param_entry(m, i, tight, (int32_t)len + 1, &off, &nd, shape) != 0 || strcmp(tight, name) != 0) { printf("exact-fit name %s\n", name); return 4; }
+            free(tight);
+            char* small = malloc(4);                             /* too short: an error or a truncated, terminated name -- never a write past 4 bytes */
+            (void)kasf_param_entry(m, i, small, 4, &off, &nd, shape);
+            free(small);
+            total += off;
+        }
+        free(name);
+    }
+    n = kasf_buffer_entries(m);
+    for (int32_t i = -1; i <= n; ++i) {
+        char name[96];
+        int64_t off = 0, shape[4];
+        int32_t nd = 0;
+        (void)kasf_buffer_entry(m, i, name, 96, &off, &nd, shape);
+    }
+    for (int32_t st = -1; st <= kasf_backward_stages(m); ++st) {
+        int64_t b = 0, e = 0;
+        int rc = kasf_stage_grad_range(m, st, &b, &e);
+        if (rc == 0 && (b < 0 || e < b || e > kasf_param_count(m))) { printf("stage %d: [%lld, %lld)\n", st, (long long)b, (long long)e); return 5; }
+    }
+    const int32_t batches[4] = {0, 1, 7, 256};
+    for (int bi = 0; bi < 4; ++bi)
+        for (int32_t flags = 0; flags < 8; ++flags) {
+            int64_t bytes = kasf_workspace_bytes(m, batches[bi], flags);
+            int32_t ne = kasf_ws_entries(m, batches[bi], flags);
+            for (int32_t i = -1; i <= ne; ++i) {
+                char* name = malloc(64);
+                int64_t off = 0, numel = 0;
+                int32_t kind = 0;
+                int rc = kasf_ws_entry(m, batches[bi], flags, i, name, 64, &off, &numel, &kind);
+                if (rc == 0 && (off < 0 || off > bytes)) { printf("ws entry %s outside the workspace\n", name); return 6; }
+                free(name);
+            }
+        }
+    total += kasf_packed_bytes(m) + kasf_param_live_count(m) + kasf_buffer_count(m);
+    kasf_model_destroy(m);
+    kasf_model_destroy(0);
+    return total > 0 ? 0 : 7;
+}
+int main(void) {
+    kasf_config shipped = {26, 27, 8, 4, 1, KASF_DTYPE_BF16};
+    kasf_config long_clip = {1, 256, 8, 4, 1, KASF_DTYPE_F32};
+    kasf_config short_clip = {2, 4, 4, 1, 0, KASF_DTYPE_BF16};
+    kasf_config t81 = {26, 81, 8, 4, 1, KASF_DTYPE_BF16};
+    int rc;
+    if ((rc = walk(shipped)) || (rc = walk(long_clip)) || (rc = walk(short_clip)) || (rc = walk(t81))) return rc;
+    kasf_model* m = 0;
+    (void)kasf_model_create_layout_only(0, &m);                  /* null arguments are errors, not crashes */
+    (void)kasf_model_create_layout_only(&shipped, 0);
+    printf("ok %s\n", kasf_last_error());
+    return 0;
+}
+''')
+    exe = tmp_path / "walk"
+    libdir = os.path.join(ROOT, "kasportsformer_amd")
+    r = subprocess.run([clang, "-std=c99", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-shared-libsan", "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                        "-L" + libdir, "-l:libkasf_hip_asan.so", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib/llvm/lib/clang/22/lib/linux"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0:halt_on_error=1", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    r = subprocess.run([str(exe)], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and r.stdout.startswith("ok"), (r.stdout[-2000:], r.stderr[-4000:])

@@ -18,6 +18,44 @@ def _free_port():
     return p
 
 
+def _worker_bf16(rank, world, port, overlap, q):
+    """grad_dtype="bf16": the bucket travels as bf16 and comes back widened; fp32 master gradients elsewhere untouched."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import kasportsformer_amd as K
+        from kasportsformer_amd import _lib
+        torch.manual_seed(7)
+        m = K.KASportsFormer(n_layers=2, num_heads=8, n_frames=27)
+        opt = K.FusedAdamW(m)
+        dp = K.DataParallel(m, overlap=overlap, optimizer=opt, grad_dtype="bf16")
+        lib = _lib.load()
+        gen = torch.Generator().manual_seed(1000 + rank)
+        g = torch.zeros(m.n_flat)
+        mine = torch.randn(m.n_flat, generator=gen) * 1e-3
+        b, e = C.c_int64(), C.c_int64()
+        for st in range(lib.kasf_backward_stages(m._layout)):
+            _lib.check(lib.kasf_stage_grad_range(m._layout, st, C.byref(b), C.byref(e)))
+            if e.value > b.value:
+                g[b.value:e.value] = mine[b.value:e.value]
+                if m.grad_stage_hook is not None:
+                    m.grad_stage_hook(st, g[b.value:e.value])
+        m.flat_grad = g
+        dp.finish_gradients()
+        # what the wire format allows: each rank's contribution rounded to bf16, summed (in bf16 by the collective), widened
+        parts = [(torch.randn(m.n_flat, generator=torch.Generator().manual_seed(1000 + r)) * 1e-3).bfloat16() for r in range(world)]
+        expect = sum(p.float() for p in parts)
+        err = (g[:m.n_live] - expect[:m.n_live]).abs().max() / expect[:m.n_live].abs().max()
+        assert float(err) < 2 ** -7, float(err)             # one more bf16 rounding of the sum
+        assert torch.count_nonzero(g[m.n_live:]) == 0 and g.dtype == torch.float32
+        assert opt.grad_scale == 1.0 / world
+        q.put((rank, "ok"))
+    except Exception as ex:  # pragma: no cover
+        q.put((rank, repr(ex)))
+    finally:
+        dist.destroy_process_group()
+
+
 def _worker(rank, world, port, overlap, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -117,11 +155,11 @@ def _worker(rank, world, port, overlap, q):
         dist.destroy_process_group()
 
 
-def _run(overlap):
+def _run(overlap, worker=None):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, overlap, q)) for r in range(2)]
+    procs = [ctx.Process(target=worker or _worker, args=(r, 2, port, overlap, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in procs]
@@ -136,3 +174,8 @@ def test_data_parallel_bucketed_allreduce_gloo():
 
 def test_data_parallel_single_allreduce_gloo():
     _run(overlap=False)
+
+
+def test_data_parallel_bf16_gradient_allreduce_gloo():
+    _run(overlap=True, worker=_worker_bf16)
+    _run(overlap=False, worker=_worker_bf16)

@@ -529,7 +529,7 @@ def _full_depth_sample(cd, seed, salt):
 
 
 def _write_parity_report(cd, samples):
-    """The observed figures go to gpurun_out/r4_parity_26layers_<cd>.json (merged back from the GPU box; the copy committed under profiles/ is what
+    """The observed figures go to gpurun_out/r5_parity_26layers_<cd>.json (merged back from the GPU box; the copy committed under profiles/ is what
     bench.py quotes in its `parity` field instead of a typed-in string)."""
     import json, os, statistics
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
@@ -538,7 +538,17 @@ def _write_parity_report(cd, samples):
            "forward_rel_err_median": statistics.median(s["forward_rel_err"] for s in samples), "forward_rel_err_max": max(s["forward_rel_err"] for s in samples),
            "gradient_cosine_median": statistics.median(s["gradient_cosine"] for s in samples), "gradient_cosine_min": min(s["gradient_cosine"] for s in samples),
            "topk_rows_identical_pct": 100.0 * sum(s["topk_rows_identical"] for s in samples) / max(1, sum(s["topk_rows"] for s in samples))}
-    with open(os.path.join(out, f"r4_parity_26layers_{cd}.json"), "w") as f:
+    rep["forward_rel_err_free_running_max"] = max(s["forward_rel_err_free_running"] for s in samples)      # the oracle taking its OWN top-4 decisions
+    rep["topk_rows_differ"] = sum(s["topk_rows"] - s["topk_rows_identical"] for s in samples)
+    rep["topk_rows_differ_not_near_tie"] = sum(s["topk_rows_differ_not_near_tie"] for s in samples)
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(out), "tools"))
+    try:
+        import stamp
+        rep["stamp"] = stamp.stamp()             # which build these figures were observed on (bench.py quotes the file only if it matches the library it times)
+    finally:
+        sys.path.pop(0)
+    with open(os.path.join(out, f"r5_parity_26layers_{cd}.json"), "w") as f:
         json.dump(rep, f, indent=1)
     return rep
 
@@ -574,13 +584,17 @@ def test_full_depth_26_layers_against_oracle(cd):
           f"CPU emulation of the same roundings: forward {statistics.median(s_['emulated_forward_rel_err'] for s_ in samples):.3e}, cosine {emu_cos:.4f} "
           f"({min(s_['emulated_gradient_cosine'] for s_ in samples):.4f} worst)")
     # bf16: activations are re-rounded to bf16 by every one of the 156 blocks; with O(1) layer scales this network amplifies rounding noise chaotically (DESIGN
-    # section 10).  Judged against the emulation: every sample's forward error within 2 x its emulated one, the median cosine within 0.05 of the emulated median;
-    # and absolutely: median / worst forward 0.15 / 0.3, median / worst cosine 0.85 / 0.6 (observed 0.096 / 0.204 and 0.910 / 0.716)
+    # section 10).  Judged against the emulation, sample by sample: forward error within 2 x its emulated one, gradient cosine no
+    # more than 0.1 below its emulated one; the median cosine within 0.02 of the emulated median; and absolutely: median / worst forward 0.15 / 0.3, median /
+    # worst cosine 0.9 / 0.85.  Observed in round 5 (the MLP's GELU / GELU' in fp16 instead of bf16-rounded: H carries 11 significant bits into GEMM2):
+    # forward 0.081 / 0.225, cosine 0.955 / 0.936 -- every sample at or above its emulation (0.906 ... 0.942) except (7, 2002): 0.9356 against 0.9400.
+    # Round 4: 0.910 / 0.716, that sample 0.22 below its emulation.
     for s_ in samples:
         assert s_["forward_rel_err"] < 2.0 * s_["emulated_forward_rel_err"], s_
-    assert rep["gradient_cosine_median"] > emu_cos - 0.05, (rep["gradient_cosine_median"], emu_cos)
+        assert s_["gradient_cosine"] > s_["emulated_gradient_cosine"] - 0.1, s_
+    assert rep["gradient_cosine_median"] > emu_cos - 0.02, (rep["gradient_cosine_median"], emu_cos)
     assert rep["forward_rel_err_median"] < 0.15 and rep["forward_rel_err_max"] < 0.3
-    assert rep["gradient_cosine_median"] > 0.85 and rep["gradient_cosine_min"] > 0.6
+    assert rep["gradient_cosine_median"] > 0.9 and rep["gradient_cosine_min"] > 0.85
 
 
 @pytest.mark.parametrize("T,B", [(243, 1), (100, 2), (33, 2), (5, 3), (4, 8), (64, 2), (96, 2), (32, 2), (130, 1), (200, 1), (256, 1), (50, 2)])      # 64 / 96: the three-tile fused temporal forward with an empty / a full last tile; 32: the largest one-tile group
