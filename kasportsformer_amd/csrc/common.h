@@ -120,72 +120,6 @@ template <typename T = float> __device__ __forceinline__ float gelu_f(float x) {
     gelu_tail<GeluMode<T>::FAST>(x, s, e);
     return fmaf(-fabsf(x), s, fmaxf(x, 0.0f));
 }
-// Two bf16-mode GELUs at once in packed fp32 (v_pk_fma_f32 / v_pk_mul_f32): 15 instructions per pair instead of 2 x 12.
-//   GELU(x) = x/2 + |x| (1/2 - s),  s = e . G(|x|) as in gelu_tail<true>.  No clamp of |x|: e underflows to 0 long before G overflows
-//   (|x| > 8e6), so the product stays finite for every activation a LayerNorm'd input can produce.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-template <int N> __device__ __forceinline__ void gelu_pairs_fast(f32x2 (&x)[N]) {      // in place; the N Horner chains advance together: a dependent
-    auto C = [](float v) { return f32x2{v, v}; };                                        // v_pk_fma_f32 issued back to back costs a wait state
-    auto fma2 = [](f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); };
-    f32x2 a[N], e[N], G[N];
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-        a[k][0] = __builtin_fabsf(x[k][0]);
-        a[k][1] = __builtin_fabsf(x[k][1]);
-        const f32x2 u = x[k] * x[k] * C(-0.72134752044448170f);
-        e[k][0] = __builtin_amdgcn_exp2f(u[0]);
-        e[k][1] = __builtin_amdgcn_exp2f(u[1]);
-    }
-#pragma unroll
-    for (int k = 0; k < N; ++k) G[k] = fma2(a[k], C(7.042173346e-04f), C(-8.041790507e-03f));
-#pragma unroll
-    for (int k = 0; k < N; ++k) G[k] = fma2(a[k], G[k], C(3.967198035e-02f));
-#pragma unroll
-    for (int k = 0; k < N; ++k) G[k] = fma2(a[k], G[k], C(-1.169407755e-01f));
-#pragma unroll
-    for (int k = 0; k < N; ++k) G[k] = fma2(a[k], G[k], C(2.444233516e-01f));
-#pragma unroll
-    for (int k = 0; k < N; ++k) G[k] = fma2(a[k], G[k], C(-3.982094769e-01f));
-#pragma unroll
-    for (int k = 0; k < N; ++k) G[k] = fma2(a[k], G[k], C(4.999843037e-01f));
-#pragma unroll
-    for (int k = 0; k < N; ++k) G[k] = fma2(-G[k], e[k], C(0.5f));
-#pragma unroll
-    for (int k = 0; k < N; ++k) x[k] = fma2(a[k], G[k], x[k] * C(0.5f));
-}
-// The forward pass's form: no exponential at all.  Phi(x) - 1/2 = erf(x / sqrt2) / 2 is odd, so on |x| <= 4 it is x . P(x^2) with P of degree 7
-// (minimax fit under the constraint 4 . P(16) = 1/2, so that Phi(+-4) = 1 / 0 and the clamp continues it exactly: GELU(x) = x above 4, 0 below -4);
-// |Phi error| <= 3.3e-5 (all of it the forced Phi(4) = 1; 6e-6 inside), |GELU error| <= 1.3e-4 at x = 4 (3e-5 relative), the class of the form
-// above (6e-5) and two orders below bf16 rounding of the result.  13 full-rate instructions per pair against 13 + two quarter-rate v_exp_f32:
-// 52 instead of 84 issue cycles -- the producer waves of k_mlp_fwd_s spend 40 % of their time here.  The backward pass keeps the exponential
-// form (it needs the density as well, and the derivative of a fitted polynomial is ten times less accurate than the fit).
-template <int N> __device__ __forceinline__ void gelu_pairs_poly(f32x2 (&x)[N]) {
-    auto C = [](float v) { return f32x2{v, v}; };
-    auto fma2 = [](f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); };
-    f32x2 xc[N], t[N], p[N];
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-        xc[k][0] = __builtin_amdgcn_fmed3f(x[k][0], -4.0f, 4.0f);
-        xc[k][1] = __builtin_amdgcn_fmed3f(x[k][1], -4.0f, 4.0f);
-        t[k] = xc[k] * xc[k];
-    }
-#pragma unroll
-    for (int k = 0; k < N; ++k) p[k] = fma2(t[k], C(-1.2787216243e-09f), C(1.0448693267e-07f));
-#pragma unroll
-    for (int k = 0; k < N; ++k) p[k] = fma2(p[k], t[k], C(-3.7106711956e-06f));
-#pragma unroll
-    for (int k = 0; k < N; ++k) p[k] = fma2(p[k], t[k], C(7.6202898886e-05f));
-#pragma unroll
-    for (int k = 0; k < N; ++k) p[k] = fma2(p[k], t[k], C(-1.0211265497e-03f));
-#pragma unroll
-    for (int k = 0; k < N; ++k) p[k] = fma2(p[k], t[k], C(9.5816479941e-03f));
-#pragma unroll
-    for (int k = 0; k < N; ++k) p[k] = fma2(p[k], t[k], C(-6.6064453538e-02f));
-#pragma unroll
-    for (int k = 0; k < N; ++k) p[k] = fma2(p[k], t[k], C(3.9880567958e-01f));
-#pragma unroll
-    for (int k = 0; k < N; ++k) x[k] = fma2(x[k], xc[k] * p[k], x[k] * C(0.5f));
-}
 // Round 5, the forward pass's form in bf16 mode: the same odd polynomial evaluated in PACKED FP16 (v_pk_fma_f16: two elements per lane, the issue cost of a
 // plain fp32 instruction, and -- unlike v_pk_*_f32 -- beside another wave's MFMAs instead of in the matrix pipe: tools/valu_probe.hip cases 30-40,
 // profiles/r5_valu_probe.txt), its result kept as FP16: the hidden activation reaches GEMM2 (v_mfma_f32_16x16x32_f16 against an fp16 copy of W2) with
@@ -277,42 +211,6 @@ template <int N> __device__ __forceinline__ void gelu_grad_pairs_h(const f32x2 (
     for (int k = 0; k < N; ++k) r[k] = fma2(r[k], v[k], C(KASF_GR0));
 #pragma unroll
     for (int k = 0; k < N; ++k) { phi[k] = fma2(zc[k], q[k], C(0.5f)); dg[k] = fma2(zc[k], r[k], C(0.5f)); }
-}
-// ... and GELU with its derivative for N pairs (fp32 form: rounds 1-4, KASF_BWD_F16=0):  GELU'(x) = Phi + x phi = 1/2 + copysign(1/2 - s, x) + x e / sqrt(2 pi)
-template <int N> __device__ __forceinline__ void gelu_grad_pairs_fast(f32x2 (&x)[N], f32x2 (&dy)[N]) {
-    auto C = [](float v) { return f32x2{v, v}; };
-    auto fma2 = [](f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); };
-    f32x2 a[N], e[N], G[N];
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-        a[k][0] = __builtin_fabsf(x[k][0]);
-        a[k][1] = __builtin_fabsf(x[k][1]);
-        const f32x2 u = x[k] * x[k] * C(-0.72134752044448170f);
-        e[k][0] = __builtin_amdgcn_exp2f(u[0]);
-        e[k][1] = __builtin_amdgcn_exp2f(u[1]);
-    }
-#pragma unroll
-    for (int k = 0; k < N; ++k) G[k] = fma2(a[k], C(7.042173346e-04f), C(-8.041790507e-03f));
-#pragma unroll
-    for (int k = 0; k < N; ++k) G[k] = fma2(a[k], G[k], C(3.967198035e-02f));
-#pragma unroll
-    for (int k = 0; k < N; ++k) G[k] = fma2(a[k], G[k], C(-1.169407755e-01f));
-#pragma unroll
-    for (int k = 0; k < N; ++k) G[k] = fma2(a[k], G[k], C(2.444233516e-01f));
-#pragma unroll
-    for (int k = 0; k < N; ++k) G[k] = fma2(a[k], G[k], C(-3.982094769e-01f));
-#pragma unroll
-    for (int k = 0; k < N; ++k) G[k] = fma2(a[k], G[k], C(4.999843037e-01f));
-#pragma unroll
-    for (int k = 0; k < N; ++k) G[k] = fma2(-G[k], e[k], C(0.5f));              // 1/2 - s
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-        f32x2 cs;
-        cs[0] = __builtin_copysignf(G[k][0], x[k][0]);
-        cs[1] = __builtin_copysignf(G[k][1], x[k][1]);
-        dy[k] = fma2(x[k] * C(0.3989422804014327f), e[k], cs + C(0.5f));
-        x[k] = fma2(a[k], G[k], x[k] * C(0.5f));
-    }
 }
 template <typename T = float> __device__ __forceinline__ void gelu_and_grad(float x, float& y, float& dy) {
     float s, e;

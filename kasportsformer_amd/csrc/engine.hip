@@ -196,7 +196,7 @@ void build_layout(kasf_model* m) {
             o.fc2b = A.add(p + "mlp.fc2.bias", {128});
             o.p_fc1 = packd(o.fc1w, 512, 128, -1, 0);
             o.p_fc1T = packd(o.fc1w, 512, 128, -1, 1);
-            o.p_fc2 = packd(o.fc2w, 128, 512, -1, 0, KASF_FWD_F16);      // read by k_mlp_fwd_s only: fp16 (ignored by the fp32 arena)
+            o.p_fc2 = packd(o.fc2w, 128, 512, -1, 0, 1);      // read by k_mlp_fwd_s only: fp16 (ignored by the fp32 arena)
             o.p_fc2Ts = packd(o.fc2w, 128, 512, o.ls2, 1);             // (ls2 . W2)^T
         }
         if (m->cfg.use_adaptive_fusion) {

@@ -33,9 +33,6 @@ __device__ long long g_prof[32];
 #ifndef KASF_FWD_SGB            // vector instructions scheduled behind each MFMA of the next slice
 #define KASF_FWD_SGB 9
 #endif
-#ifndef KASF_FWD_GELU_POLY      // measurement switch (-DKASF_FWD_GELU_POLY=0): the exponential form in the forward pass as well
-#define KASF_FWD_GELU_POLY 1
-#endif
 
 namespace {
 
@@ -44,11 +41,7 @@ constexpr int S_BM = 32, S_THR = 512, TL = S_BM * 128;
 __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 // GEMM2 of the forward pass: H and W2 are FP16 bit patterns in bf16-typed registers / tiles (same size, same layouts)
 __device__ __forceinline__ f32x4 mfma16h(bf16x8 a, bf16x8 b, f32x4 c) {
-#if KASF_FWD_F16
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-#else
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-#endif
 }
 __device__ __forceinline__ bf16x8 tok_frag(const bf16* s, int row, int ks) {
     const int g = (threadIdx.x & 63) >> 4;
@@ -126,7 +119,6 @@ __global__ __launch_bounds__(S_THR) void k_mlp_fwd_s(const bf16* __restrict__ X,
                         y[2 * mt] = f32x2{acc[nt & 1][mt][0], acc[nt & 1][mt][1]};
                         y[2 * mt + 1] = f32x2{acc[nt & 1][mt][2], acc[nt & 1][mt][3]};
                     }
-#if KASF_FWD_F16
                     f16x2 hh[4];
 #ifdef KASF_KO_FGELU
 #pragma unroll
@@ -139,14 +131,6 @@ __global__ __launch_bounds__(S_THR) void k_mlp_fwd_s(const bf16* __restrict__ X,
                         const f16x4 h4 = {hh[2 * mt][0], hh[2 * mt][1], hh[2 * mt + 1][0], hh[2 * mt + 1][1]};
                         *reinterpret_cast<f16x4*>(hT + Tile<bf16>::off4(mt * 16 + i, 16 * nt + 4 * g)) = h4;
                     }
-#else
-                    if (KASF_FWD_GELU_POLY) gelu_pairs_poly(y); else gelu_pairs_fast(y);
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) {
-                        const float h[4] = {y[2 * mt][0], y[2 * mt][1], y[2 * mt + 1][0], y[2 * mt + 1][1]};
-                        store4(hT + Tile<bf16>::off4(mt * 16 + i, 16 * nt + 4 * g), h);
-                    }
-#endif
                     if (nt < 7) {
 #pragma unroll
                         for (int k = 0; k < 8; ++k) {
@@ -425,7 +409,6 @@ __global__ __launch_bounds__(S_THR) void k_mlp_bwd_s(const bf16* __restrict__ XN
                         }
                 };
                 const bool ragged = nvalid != S_BM;      // rows past M (only the last tile of the last range has any) must not leak GELU(b1) into anything
-#if KASF_BWD_F16
                 auto act = [&](int nt) {                 // Phi and GELU' in packed fp16, the products in fp32 (v_fma_mix_f32), H / dZ rounded to bf16 once
                     f32x2 z[4];
                     f16x2 ph[4], dgh[4];
@@ -462,30 +445,6 @@ __global__ __launch_bounds__(S_THR) void k_mlp_bwd_s(const bf16* __restrict__ XN
                         store4(cD + Tile<bf16>::off4(mt * 16 + i, h0 + 16 * nt + 4 * g), dz);
                     }
                 };
-#else
-                auto act = [&](int nt) {
-                    f32x2 z[4], dg[4];
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                        for (int hp = 0; hp < 2; ++hp)
-                            z[2 * mt + hp] = f32x2{accZ[nt][mt][2 * hp], accZ[nt][mt][2 * hp + 1]};
-                    gelu_grad_pairs_fast(z, dg);
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) {
-                        float h[4], dz[4];
-                        const float live = (!ragged || mt * 16 + i < nvalid) ? 1.0f : 0.0f;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            h[r] = z[2 * mt + (r >> 1)][r & 1] * live;
-                            dz[r] = accH[nt][mt][r] * dg[2 * mt + (r >> 1)][r & 1] * live;
-                            db1acc[nt][r] += dz[r];
-                        }
-                        store4(cH + Tile<bf16>::off4(mt * 16 + i, h0 + 16 * nt + 4 * g), h);
-                        store4(cD + Tile<bf16>::off4(mt * 16 + i, h0 + 16 * nt + 4 * g), dz);
-                    }
-                };
-#endif
                 gemm(0);
                 __builtin_amdgcn_sched_barrier(0);
                 TMARK(16);

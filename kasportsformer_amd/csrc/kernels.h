@@ -7,14 +7,6 @@
 #define KASF_F32 0
 #define KASF_BF16 1
 
-#ifndef KASF_FWD_F16            // measurement switch (-DKASF_FWD_F16=0): the round-4 MLP forward, packed-fp32 GELU and a bf16 H / W2
-#define KASF_FWD_F16 1
-#endif
-
-#ifndef KASF_BWD_F16            // measurement switch (-DKASF_BWD_F16=0): the round-4 MLP backward producers (fp32 GELU / GELU' with one exponential)
-#define KASF_BWD_F16 1
-#endif
-
 struct KasfPackDesc {
     int64_t src;        // element offset into the fp32 parameter buffer
     int64_t dst;        // element offset into the packed arena

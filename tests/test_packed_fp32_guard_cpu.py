@@ -3,11 +3,12 @@
 Round 3 found `k_gcn_bwd2_spatial` / `_temporal` returning values that depended on which other kernels shared the SIMD.  The source there is plain scalar C
 (`dy = sc * (r - c1 - (y - mean) * rstd * c2)`); hipcc's SLP vectoriser had turned it into `v_pk_add_f32` / `v_pk_mul_f32` whose scalar operand is broadcast
 with `op_sel` / `op_sel_hi` out of a register PAIR of which only one half is ever written (tools/packed_fp32_repro.hip keeps the pattern and the ISA).
-The library is built with `-fno-slp-vectorize` since then, and packed fp32 exists only where the source writes two-float vectors out by hand: the GELU / GELU'
-chains of the fused MLP kernels (csrc/common.h `gelu_pairs_*`, used by k_mlp3.hip).
+The library is built with `-fno-slp-vectorize` since then.  Rounds 1-4 had ONE hand-written packed-fp32 site, the GELU / GELU' chains of the fused MLP kernels;
+round 5 moved those to packed FP16 (`gelu_pairs_h`, `gelu_grad_pairs_h`: v_pk_*_f16 runs beside another wave's MFMAs, v_pk_*_f32 runs IN the matrix pipe), so
+the library now holds no packed-fp32 arithmetic with operand select at all.
 
 This test takes the compiler flags FROM THE MAKEFILE (so removing the flag there fails here), compiles every product source to gfx950 assembly (no GPU needed) and
-fails on any `v_pk_{add,mul,fma}_f32` carrying `op_sel` / `op_sel_hi` in a kernel outside the whitelist of those hand-written sites.  A second check compiles
+fails on any `v_pk_{add,mul,fma}_f32` carrying `op_sel` / `op_sel_hi` in any kernel.  A second check compiles
 csrc/k_gcn.hip WITHOUT the flag and expects the pattern to appear in the kernels that showed the defect -- if a compiler update stops producing it, the flag
 (and this guard) can be reconsidered instead of being carried forever.
 """
@@ -25,8 +26,8 @@ CSRC = os.path.join(ROOT, "kasportsformer_amd", "csrc")
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 PK = re.compile(r"^\s+(v_pk_(?:add|mul|fma)_f32)\b(.*)$")
-# kernels whose packed fp32 is written out by hand in the source (two-float vector types): the fused MLP forward / backward of bf16 mode
-HAND_WRITTEN = (r"k_mlp_fwd_s", r"k_mlp_bwd_s")
+# kernels whose packed fp32 is written out by hand in the source (two-float vector types): none since round 5
+HAND_WRITTEN = ()
 
 
 def makefile_vars():
@@ -82,7 +83,7 @@ def test_no_compiler_generated_packed_fp32_with_operand_select(shipped_asm):
                 hand += len(hits)
                 continue
             problems.append(f"{src}: {name}: {len(hits)} packed-fp32 instructions with op_sel / op_sel_hi, e.g. `{hits[0]}`")
-    assert hand > 0, "the hand-written packed GELU of the fused MLP kernels was not recognised: the scanner is broken"
+    assert hand == 0          # (that the scanner recognises the pattern at all is the negative control's job, below)
     assert not problems, ("compiler-generated packed fp32 with operand select (is -fno-slp-vectorize still in csrc/Makefile?):\n" + "\n".join(problems))
 
 
