@@ -23,7 +23,7 @@
 
 #ifdef KASF_PROBE_TIMERS
 __device__ long long g_prof[32];
-#define TMARK(k) do { const long long _n = clock64(); if (lane == 0 && blockIdx.x == 7) g_prof[k] += _n - _t; _t = _n; } while (0)
+#define TMARK(k) do { const long long _n = clock64(); if (lane == 0 && blockIdx.x == 7 && (w & 3) == 0) g_prof[k] += _n - _t; _t = _n; } while (0)   // wave 0 (producer) and wave 4 (consumer) of one workgroup only: no lost updates
 #define TSTART() long long _t = clock64()
 #else
 #define TMARK(k) do {} while (0)
@@ -37,6 +37,16 @@ __device__ long long g_prof[32];
 namespace {
 
 constexpr int S_BM = 32, S_THR = 512, TL = S_BM * 128;
+#ifndef KASF_BWD_DASTORE_EARLY
+#define KASF_BWD_DASTORE_EARLY 0
+#endif
+#ifndef KASF_BWD_RING
+#define KASF_BWD_RING 5
+#endif
+#ifndef KASF_BWD_ISSUE_AT          // where in the producers' iteration the look-ahead loads are issued: 0 at the loop top, 1 behind the first MFMA phase (shipped), 2 in front of the
+#define KASF_BWD_ISSUE_AT 1        // last GELU slice.  At the loop top they follow the consumers' dA stores of the previous iteration through the same address path: k_mlp_bwd_s
+#endif                             // 156.7 us in step (0), 146.5 (1), 151.3 (2); the dA stores in front of the weight-gradient MFMAs instead (KASF_BWD_DASTORE_EARLY): 147.1, both: 148.9
+constexpr int BW_RING = KASF_BWD_RING, BW_AHEAD = BW_RING - 2;      // backward: LN(x) / g ring slots; tiles t-1 .. t+AHEAD live (t+2 .. t+AHEAD in flight)
 
 __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 // GEMM2 of the forward pass: H and W2 are FP16 bit patterns in bf16-typed registers / tiles (same size, same layouts)
@@ -302,9 +312,9 @@ __global__ __launch_bounds__(S_THR) void k_mlp_bwd_s(const bf16* __restrict__ XN
                                                      bf16* __restrict__ dApart, bf16* __restrict__ dW1part, bf16* __restrict__ dW2part,
                                                      float* __restrict__ db1, float* __restrict__ db1_rows, int64_t M, int tiles_per_range) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16* sA = reinterpret_cast<bf16*>(smem);            // [5][32][128] LN(x) ring
-    bf16* sG = sA + 5 * TL;                              // [5][32][128] upstream gradient ring
-    bf16* sH = sG + 5 * TL;                              // [2][32][128] H of this quarter
+    bf16* sA = reinterpret_cast<bf16*>(smem);            // [RING][32][128] LN(x) ring
+    bf16* sG = sA + BW_RING * TL;                        // [RING][32][128] upstream gradient ring
+    bf16* sH = sG + BW_RING * TL;                        // [2][32][128] H of this quarter
     bf16* sD = sH + 2 * TL;                              // [2][32][128] dZ of this quarter
     int q, range;
     {   // the four hidden quarters of one token range sit on one XCD
@@ -352,9 +362,8 @@ __global__ __launch_bounds__(S_THR) void k_mlp_bwd_s(const bf16* __restrict__ XN
                 glds16_s(ua, off, ldsA + lo);
             }
         };
-        issue(0, 0);                                     // the first tiles are in flight while the weights arrive from L2
-        issue(1, 1);
-        issue(2, 2);
+#pragma unroll
+        for (int k = 0; k < BW_AHEAD; ++k) issue(k, k);  // the first tiles are in flight while the weights arrive from L2
         bf16x8 w1f[2][4], w2f[2][4];
         f32x4 bias4[2], db1acc[2];
 #pragma unroll
@@ -377,9 +386,11 @@ __global__ __launch_bounds__(S_THR) void k_mlp_bwd_s(const bf16* __restrict__ XN
         }
         barrier_keep_async();                            // every producer's rows of tile 0 have landed
         TSTART();
-        int sp = 0, si = 3;                              // ring slots of tile t and of tile t+3 (mod 5, rolling)
-        for (int64_t t = 0; t <= ntiles; ++t, sp = sp == 4 ? 0 : sp + 1, si = si == 4 ? 0 : si + 1) {
-            issue((int)t + 3, si);                       // into the slot of tile t-2 (free since the barrier that ended iteration t-1): three tiles of HBM latency cover
+        int sp = 0, si = BW_AHEAD;                       // ring slots of tile t and of tile t+AHEAD (mod RING, rolling)
+        for (int64_t t = 0; t <= ntiles; ++t, sp = sp == BW_RING - 1 ? 0 : sp + 1, si = si == BW_RING - 1 ? 0 : si + 1) {
+#if KASF_BWD_ISSUE_AT == 0
+            issue((int)t + BW_AHEAD, si);                // into the slot of tile t-2 (free since the barrier that ended iteration t-1): AHEAD tiles of HBM latency cover
+#endif
             TMARK(19);
             if (t < ntiles) {
                 const bf16* cA = sA + sp * TL;
@@ -447,6 +458,10 @@ __global__ __launch_bounds__(S_THR) void k_mlp_bwd_s(const bf16* __restrict__ XN
                 };
                 gemm(0);
                 __builtin_amdgcn_sched_barrier(0);
+#if KASF_BWD_ISSUE_AT == 1
+                issue((int)t + BW_AHEAD, si);
+                __builtin_amdgcn_sched_barrier(0);
+#endif
                 TMARK(16);
                 gemm(1);
                 act(0);
@@ -456,10 +471,18 @@ __global__ __launch_bounds__(S_THR) void k_mlp_bwd_s(const bf16* __restrict__ XN
                     __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+#if KASF_BWD_ISSUE_AT == 2
+                issue((int)t + BW_AHEAD, si);
+                __builtin_amdgcn_sched_barrier(0);
+#endif
                 act(1);
                 TMARK(17);
             }
-            wait_async_le<8>();                          // tile t+1 has landed: only the requests of tiles t+3 and t+2 (4 loads each, this wave's only vector-memory traffic) may be in flight
+#if KASF_BWD_ISSUE_AT == 1 || KASF_BWD_ISSUE_AT == 2
+            else issue((int)t + BW_AHEAD, si);           // (the iteration past the last tile keeps the per-iteration load count)
+#endif
+            wait_async_le<4 * (BW_AHEAD - 1)>();         // tile t+1 has landed: only the requests of the BW_AHEAD - 1 tiles behind it (4 loads each, this wave's only vector-memory traffic) may be in flight
+            TMARK(21);
             barrier_keep_async();
             TMARK(18);
         }
@@ -494,10 +517,24 @@ __global__ __launch_bounds__(S_THR) void k_mlp_bwd_s(const bf16* __restrict__ XN
             for (int ks = 0; ks < 4; ++ks) wtf[nt][ks] = *reinterpret_cast<const bf16x8*>(W1t + (int64_t)(ch0 + 16 * nt + i) * 512 + q * 128 + 32 * ks + 8 * g);
         barrier_keep_async();                            // (the producers' rows of tile 0 have landed)
         TSTART();
-        int sc = 4;                                      // ring slot of tile t-1 (consumed), rolling mod 5
-        for (int64_t t = 0; t <= ntiles; ++t, sc = sc == 4 ? 0 : sc + 1) {
+        int sc = BW_RING - 1;                            // ring slot of tile t-1 (consumed), rolling mod RING
+        for (int64_t t = 0; t <= ntiles; ++t, sc = sc == BW_RING - 1 ? 0 : sc + 1) {
             TMARK(24);
             f32x4 accA[2][2];
+            auto store_dA = [&]() {
+                const int64_t row0 = (tile0 + t - 1) * S_BM;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const int64_t row = row0 + mt * 16 + i;
+                    if (row < M) {
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) {
+                            const float v[4] = {accA[nt][mt][0], accA[nt][mt][1], accA[nt][mt][2], accA[nt][mt][3]};
+                            store4(dApart + ((int64_t)q * M + row) * 128 + ch0 + 16 * nt + 4 * g, v);
+                        }
+                    }
+                }
+            };
             if (t >= 1) {
                 const bf16* cA = sA + sc * TL;
                 const bf16* cG = sG + sc * TL;
@@ -525,6 +562,10 @@ __global__ __launch_bounds__(S_THR) void k_mlp_bwd_s(const bf16* __restrict__ XN
                 }
 #endif
                 TMARK(25);
+#if KASF_BWD_DASTORE_EARLY                  // the dA partial rows leave BEFORE the weight-gradient MFMAs: their address arithmetic and the four stores issue under the matrix pipe's time
+                store_dA();
+                __builtin_amdgcn_sched_barrier(0);
+#endif
 #ifndef KASF_KO_WGRAD
                 {   // ---- weight gradients: reduction over the 32 tokens of the tile (one k-step) ----
                     bf16x8 ra[4], cb[4];
@@ -551,24 +592,13 @@ __global__ __launch_bounds__(S_THR) void k_mlp_bwd_s(const bf16* __restrict__ XN
 #endif
             }
             TMARK(26);
+#if !KASF_BWD_DASTORE_EARLY
 #ifdef KASF_KO_DASTORE
-            if (t >= 1 && accA[0][0][0] == 123.456f) {
+            if (t >= 1 && accA[0][0][0] == 123.456f) store_dA();
 #else
-            if (t >= 1) {
+            if (t >= 1) store_dA();
 #endif
-                const int64_t row0 = (tile0 + t - 1) * S_BM;
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    const int64_t row = row0 + mt * 16 + i;
-                    if (row < M) {
-#pragma unroll
-                        for (int nt = 0; nt < 2; ++nt) {
-                            const float v[4] = {accA[nt][mt][0], accA[nt][mt][1], accA[nt][mt][2], accA[nt][mt][3]};
-                            store4(dApart + ((int64_t)q * M + row) * 128 + ch0 + 16 * nt + 4 * g, v);
-                        }
-                    }
-                }
-            }
+#endif
             TMARK(28);
             barrier_keep_async();
             TMARK(29);
@@ -624,7 +654,7 @@ extern "C" void kasf_debug_read_prof(long long* dst, int reset) {
 
 void kasf_launch_mlp_bwd_s(hipStream_t s, const void* xn, const void* g, const void* W1, const float* b1, const void* W2ts, const void* W1t, void* dApart,
                            void* p1, void* p2, float* db1, float* db1_rows, int64_t M, int tiles_per_range, int used) {
-    const size_t sh = (size_t)(14 * TL) * sizeof(bf16);
+    const size_t sh = (size_t)((2 * BW_RING + 4) * TL) * sizeof(bf16);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_bwd_s), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     hipLaunchKernelGGL(k_mlp_bwd_s, dim3(4 * used), dim3(S_THR), sh, s, (const bf16*)xn, (const bf16*)g, (const bf16*)W1, b1, (const bf16*)W2ts,
                        (const bf16*)W1t, (bf16*)dApart, (bf16*)p1, (bf16*)p2, db1, db1_rows, M, tiles_per_range);

@@ -13,7 +13,7 @@ w1 = (torch.randn(512, 128, device=dev) * 0.05).to(bf); w2 = (torch.randn(128, 5
 b1 = torch.zeros(512, device=dev); b2 = torch.zeros(128, device=dev); ls = torch.ones(128, device=dev); gam = torch.ones(128, device=dev); bet = torch.zeros(128, device=dev)
 p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
 st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
-bnames = {16: "P Z/dH mfma", 17: "P gelu+store", 18: "P barrier", 24: "C issue", 25: "C dA", 26: "C wgrad", 27: "C wait vmcnt", 28: "C dA stores", 29: "C barrier"}
+bnames = {19: "P issue loads", 16: "P frags+gemm(0)", 20: "P gemm(1)+act(0) [fine]", 17: "P act(1) (or gemm1+act0+act1)", 21: "P vmcnt wait", 18: "P barrier", 24: "C loop top", 25: "C dA", 26: "C wgrad", 27: "C wait vmcnt", 28: "C dA stores", 29: "C barrier"}
 names = {0: "P frag+gemm1(0)", 1: "P slices", 2: "P barrier", 8: "C issue", 9: "C gemm2", 10: "C wait vmcnt", 11: "C layernorm", 12: "C epilogue", 13: "C barrier"}
 for label, xo in (("with xn store", xn), ("no xn store", None)):
     lib.kasf_op_mlp_fwd(1, p(x), p(gam), p(bet), p(w1), p(b1), p(w2), p(b2), p(ls), p(out), M, p(xo), st())
