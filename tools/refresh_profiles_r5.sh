@@ -70,6 +70,9 @@ need $O/r5_configs.jsonl
 say "strong-scaling bench lines at the per-rank shapes of BASELINE configs[2] (one global batch of 256 over 8 / 4 ranks), data-parallel path, one rank"
 timeout -k 10 300 python bench.py --force-dp --global-batch 32 --det-conf --steps 20 --warmup 5 --no-cpu-baseline --no-fp32 --no-kernel-roofline > $O/r5_bench_strong_b32.json 2> $O/bench32.err; need $O/r5_bench_strong_b32.json
 timeout -k 10 300 python bench.py --force-dp --global-batch 64 --det-conf --steps 20 --warmup 5 --no-cpu-baseline --no-fp32 --no-kernel-roofline > $O/r5_bench_strong_b64.json 2> $O/bench64.err; need $O/r5_bench_strong_b64.json
+say "26-layer parity samples (tests/test_gpu_model.py writes gpurun_out/r5_parity_26layers_{fp32,bf16}.json; the bench line's parity object is read from them)"
+timeout -k 10 600 python -m pytest tests/test_gpu_model.py -x -q -m gpu -k "full_depth_26" > $O/parity26.log 2>&1 || { tail -5 $O/parity26.log; echo "refresh_profiles_r5: the 26-layer parity test failed"; exit 4; }
+need gpurun_out/r5_parity_26layers_bf16.json
 say "bench line (quotes the files above)"
 for f in r5_parity_26layers_fp32.json r5_parity_26layers_bf16.json; do [ -s gpurun_out/$f ] && cp gpurun_out/$f $O/ || true; done
 stamp_all
