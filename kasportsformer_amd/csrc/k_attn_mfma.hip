@@ -815,6 +815,9 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_2p(const bf16* __restrict__
 
 // NR: score registers that can hold a live key (register g holds keys (g & 3) + 8 (g >> 2) + 4 hh: 9 for groups of <= 17 positions, the spatial
 // blocks): the softmax / dS arithmetic and the P / dS tile stores skip the registers past NR, which are identically zero.
+#ifndef KASF_PERS_FLUSH_AT          // where group t-1's dq | dk | dv leave: 0 at the top of group t, right in front of the look-ahead loads (rounds 2-4); 1 behind the barrier; 2 behind d_o
+#define KASF_PERS_FLUSH_AT 2        // (shipped, round 5); 3 behind pass 1.  Stores and loads issued back to back by one wave cost both: in step <9> 66.8 / 58.3 / 56.1 / 61.1 us, <16> 60.1 / 53.2 / 54.0 / 57.4
+#endif
 template <int NR>
 __global__ __launch_bounds__(512, 4) void k_attn_bwd_pers(const bf16* __restrict__ Q, int64_t ldq, const bf16* __restrict__ K, const bf16* __restrict__ V,
                                                           int64_t ldkv, bf16* __restrict__ dQ, int64_t lddq, bf16* __restrict__ dK, bf16* __restrict__ dV,
@@ -889,11 +892,16 @@ __global__ __launch_bounds__(512, 4) void k_attn_bwd_pers(const bf16* __restrict
         *reinterpret_cast<bf16x8*>(sGt + Tile<bf16>::chunk_off(grow, gch)) = grow < L ? gcN : zero8();
         *reinterpret_cast<bf16x8*>(sK + r * 16 + 8 * hh) = kf;
         *reinterpret_cast<bf16x8*>(sQ + r * 16 + 8 * hh) = qf;
+#if KASF_PERS_FLUSH_AT == 0
         if (t > 0) flush(g0 + t - 1);
+#endif
         if (t + 1 < ng) fetch(t + 1);
         PQ(0);
         __syncthreads();          // g_mid rows of group t visible; every wave is past its reads of the other buffer (group t-1)
         PQ(1);
+#if KASF_PERS_FLUSH_AT == 1
+        if (t > 0) flush(g0 + t - 1);
+#endif
         bf16x8 df;
         {   // d_o of this head: [32 positions][16 channels] = g_mid . (ls1 . Wproj)^T rows 16h .. 16h+15
             f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -912,6 +920,9 @@ __global__ __launch_bounds__(512, 4) void k_attn_bwd_pers(const bf16* __restrict
             df = *reinterpret_cast<const bf16x8*>(sD + r * 16 + 8 * hh);
         }
         PQ(2);
+#if KASF_PERS_FLUSH_AT == 2
+        if (t > 0) flush(g0 + t - 1);
+#endif
         // ---------------- pass 1: lane = query ----------------
         f32x16 st = mfma32(kf, qf, zero16());                    // S^T[key][query]
         f32x16 dp = mfma32(vf, df, zero16());                    // dP^T[key][query]
@@ -949,6 +960,9 @@ __global__ __launch_bounds__(512, 4) void k_attn_bwd_pers(const bf16* __restrict
             store4(sdS + r * 32 + 8 * a4 + 4 * hh, v4);
         }
         PQ(3);
+#if KASF_PERS_FLUSH_AT == 3
+        if (t > 0) flush(g0 + t - 1);
+#endif
         // ---------------- pass 2: dV^T = dO^T . P, dK^T = Q^T . dS with P / dS read back transposed (lane = key) ----------------
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the tiles were written by other lanes of this wave (LDS is in order per wave)
         f32x16 dv = zero16(), dk = zero16();
@@ -957,8 +971,8 @@ __global__ __launch_bounds__(512, 4) void k_attn_bwd_pers(const bf16* __restrict
             dv = mfma32(tr_frag(sD, ks), tr_frag32(sP, ks), dv);
             dk = mfma32(tr_frag(sQ, ks), tr_frag32(sdS, ks), dk);
         }
-        pq = swap_t16(dq);       // stored at the top of the next group, in FRONT of that group's look-ahead loads: the wait for those loads then
-        pv = swap_t16(dv);       // never has this group's stores (issued a moment ago) ahead of it in the in-order vmcnt queue
+        pq = swap_t16(dq);       // stored during the NEXT group (KASF_PERS_FLUSH_AT): behind that group's look-ahead loads in the in-order vmcnt queue, so the wait
+        pv = swap_t16(dv);       // for those loads never has stores ahead of it -- and not back to back with them either (round 5: -16 % / -11 %)
         pk = swap_t16(dk);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's LDS reads are done before the next group's tile writes
         PQ(4);

@@ -10,6 +10,9 @@
 #include "common.h"
 #include "kernels.h"
 #include "tile_ops.h"
+#ifndef KASF_LINEAR_ISSUE_AT        // k_linear_r: the look-ahead loads of tile t+2 behind B1 (1, shipped since round 5) or behind B2, back to back with the LayerNorm / copy-out stores (0): 29.3 -> 28.6 us in step
+#define KASF_LINEAR_ISSUE_AT 1
+#endif
 
 namespace {
 
@@ -409,6 +412,9 @@ __global__ __launch_bounds__(R_THR) void k_linear_r(const bf16* __restrict__ A, 
         const bf16* cA = LN ? sA + (int)(t & 1) * R_TILE : slot;
         const int64_t row0 = (tile0 + t) * R_BM;
         barrier_keep_async();                            // B1: operand tile t complete and visible; everyone is past the copy-out of tile t-1
+#if KASF_LINEAR_ISSUE_AT == 1
+        issue(t + 2, nx3(nx3(sl)));                      // slot (t+2)%3 held tile t-1: its last reader (the copy-out of t-1) is behind B1
+#endif
         {
             f32x4 acc[NC][2];
             zero_acc(acc);
@@ -442,7 +448,9 @@ __global__ __launch_bounds__(R_THR) void k_linear_r(const bf16* __restrict__ A, 
                 }
         }
         barrier_keep_async();                            // B2: output tile complete
+#if KASF_LINEAR_ISSUE_AT == 0
         issue(t + 2, nx3(nx3(sl)));                      // slot (t+2)%3 held tile t-1: its last reader (epilogue of t-1) is behind B1
+#endif
         wait_async_le<NSTREAM>();                        // tile t+1 landed (only tile t+2 outstanding); this tile's stores come after
         if (LN && t + 1 < ntiles) layernorm(t + 1, nx3(sl));
 #pragma unroll
