@@ -15,6 +15,15 @@ namespace {
 // skeleton neighbours (graph.py:16-17) and D^-1/2 A D^-1/2 coefficients, filled by the host at load time
 struct SkelTable { int nb[KASF_J][4]; float coef[KASF_J][4]; };
 __constant__ SkelTable c_skel;
+// The table as the spatial kernels read it (round 5): in LDS, and with a missing neighbour (nb < 0) replaced by the joint itself at coefficient 0, so that the gather needs no branch.
+struct SkelLds { int nb[KASF_J][4]; __attribute__((aligned(16))) float coef[KASF_J][4]; };
+__device__ __forceinline__ void skel_to_lds(SkelLds& d) {            // the caller's next __syncthreads() publishes it
+    for (int k = threadIdx.x; k < KASF_J * 4; k += blockDim.x) {
+        const int i = k >> 2, e = k & 3, nb = c_skel.nb[i][e];
+        d.nb[i][e] = nb >= 0 ? nb : i;
+        d.coef[i][e] = nb >= 0 ? c_skel.coef[i][e] : 0.0f;
+    }
+}
 
 constexpr int COEF_LD = 8;      // per node: scale, shift, mean, rstd, c1, c2, -, -
 constexpr int MASK_W = 3;       // 32-bit words per adjacency row of the T <= 96 instantiations (any T: kasf_gcn_mask_words)
@@ -76,7 +85,9 @@ __global__ __launch_bounds__(256) void k_gcn_agg_spatial(const T* __restrict__ u
     // one private row of node sums per 16-lane group, touched by that group's lane 0 only (in program order), and a fixed-order sum over the 16 rows:
     // the workgroup's contribution does not depend on wave scheduling (LDS float atomics from several waves would)
     __shared__ float sStat[16][KASF_J * 2];
+    __shared__ SkelLds sSk;
     for (int k = threadIdx.x; k < 16 * KASF_J * 2; k += 256) (&sStat[0][0])[k] = 0.f;
+    skel_to_lds(sSk);
     __syncthreads();
     const int sub = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int n_items = (int)(M * 16);
@@ -84,18 +95,20 @@ __global__ __launch_bounds__(256) void k_gcn_agg_spatial(const T* __restrict__ u
         const int tk = item >> 4, fr = (tk / KASF_J) * KASF_J;
         const int64_t tok = tk, frame0 = fr;
         const int i = tk - fr;
-        float acc[8];
+        // Round 5: the four neighbour rows are requested TOGETHER with the token's own -- a missing neighbour reads the token's own V row with coefficient 0 -- instead of one
+        // guarded load after another (hipcc turns `if (nb >= 0) load` into a branch with a full wait per neighbour, and the per-lane table lookups in constant memory were
+        // vector loads of their own in front of each): five independent 16-byte loads per lane in flight, the table in LDS.
+        const f32x4 cf = *reinterpret_cast<const f32x4*>(sSk.coef[i]);
+        const int nbs[4] = {sSk.nb[i][0], sSk.nb[i][1], sSk.nb[i][2], sSk.nb[i][3]};
+        float acc[8], v[4][8];
         load8(uv + tok * 256 + sub * 8, acc);                        // U
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int nb = c_skel.nb[i][e];
-            if (nb >= 0) {
-                float v[8];
-                load8(uv + (frame0 + nb) * 256 + 128 + sub * 8, v);  // V of the neighbour joint
-                const float c = c_skel.coef[i][e];
+        for (int e = 0; e < 4; ++e) load8(uv + (frame0 + nbs[e]) * 256 + 128 + sub * 8, v[e]);      // V of the neighbour joints
 #pragma unroll
-                for (int k = 0; k < 8; ++k) acc[k] += c * v[k];
-            }
+        for (int e = 0; e < 4; ++e) {
+            const float c = cf[e];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] += c * v[e][k];
         }
         store8(y + tok * 128 + sub * 8, acc);
         float s1 = 0.f, s2 = 0.f;
@@ -521,8 +534,8 @@ __global__ __launch_bounds__(256) void k_gcn_bwd2_spatial(const T* __restrict__ 
 #pragma unroll
         for (int e = 0; e < 8; ++e) dv[e] = 0.f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {                                // A_hat is symmetric: dV_i = sum_nb coef * dy_nb
-            const int nb = c_skel.nb[i][e];
+        for (int e = 0; e < 4; ++e) {                                // A_hat is symmetric: dV_i = sum_nb coef * dy_nb  (the branch-free gather of k_gcn_agg_spatial measured +3 % here: five
+            const int nb = c_skel.nb[i][e];                          //  dy_chunk evaluations in flight instead of one at a time; round 5)
             if (nb >= 0) {
                 float t[8];
                 dy_chunk(rbuf, y, coef, frame0 + nb, nb, sub, t);
