@@ -174,8 +174,8 @@ void kasf_launch_gather_clips(hipStream_t s, const float* xa, const float* ya, c
 // fill (weights into registers, a three-deep pipeline) and drain are paid with nothing beside them.  Inside the engine's forward / backward these launches therefore take HALF the
 // chip below 150,000 tokens: two branches' MLPs run side by side, one's fill under the other's steady state (tools/smallb_probe.py, T = 27 training: +3.1 % step throughput at
 // B = 256, +8 % at 128, +9 % at 32; evaluation +12 % at B = 32 ... 0 at 512; T = 81, B = 128 = 176,256 tokens: -0.4 %, hence the threshold; a third of the chip each is
-// worse: the branches are not equally long).  Below 80,000 tokens the LDS-ring data-gradient / linear kernels do the same (more tiles per workgroup
-// per fill; at B = 256 it costs 1.5 %).  The widths are a function of the token count only -- never of the stream mode -- so results stay bit-identical between the one-stream
+// worse: the branches are not equally long).  The LDS-ring linear kernels do the same below 80,000 tokens (more tiles per workgroup per fill), the data-gradient kernels
+// below 150,000 since round 5 (tools/width_sweep.sh, B = 256: 4,617-4,658 clips/s at 50 %, 4,633-4,649 at 66 %, 4,560-4,642 at the full grid on the same boxes; in round 4 it cost 1.5 % there).  The widths are a function of the token count only -- never of the stream mode -- so results stay bit-identical between the one-stream
 // and three-stream engines; the operator entry points (tests, bench.py's hot loop) launch at full width.
 // KASF_NARROW_PCTS = "fwd,bwd,dgrad,linear,attn_fwd,attn_bwd,wgrad" (percent of the full grid) and KASF_NARROW_BELOW = tokens override the table: measurement knobs.
 #include <cstdlib>
@@ -184,7 +184,7 @@ enum { KASF_NG_MLP_FWD = 0, KASF_NG_MLP_BWD = 1, KASF_NG_DGRAD = 2, KASF_NG_LINE
 inline thread_local int kasf_tls_model_path = 0;        // 1 while the engine's forward / backward is enqueueing (engine.hip)
 inline int kasf_narrow_grid(int cls, int full, int64_t tokens) {
     static int pcts[7] = {-1, 0, 0, 0, 0, 0, 0};
-    static int64_t below[7] = {150000, 150000, 80000, 80000, 0, 0, 0};
+    static int64_t below[7] = {150000, 150000, 150000, 80000, 0, 0, 0};      // (round 5: the data-gradient kernels too below 150,000 tokens: +0.7 % at B = 256 with this round's kernels; -1.5 % in round 4)
     if (pcts[0] < 0) {
         const int def[7] = {50, 50, 50, 50, 100, 100, 100};
         int tmp[7];
