@@ -728,6 +728,26 @@ int kasf_ws_entry(const kasf_model* m, int32_t batch, int32_t flags, int32_t idx
     return 0;
 }
 
+// Which branch of a layer runs on the CALLER's stream (the other two go to the side streams).  The gate / column-finish kernels are launched on the caller's stream behind the
+// joins, and a join costs 12-18 us from the end of a side stream's last kernel to the start of the waiting kernel (event record -> barrier packet -> dispatch; three-stream trace,
+// round 5: 1.15 ms of a 57 ms step sit in these hand-overs).  In the BACKWARD pass the bone branch finishes last in 26 of 26 layers (T = 27 and 81, B = 32 ... 256): on the caller's
+// stream its last kernel is followed by the stage's finishing kernels without a hand-over, and the shorter branches pay the fork / join latency inside their slack: 4,681 against
+// 4,643 clips/s, same box, alternating runs (tools/main_branch_sweep.sh).  In the FORWARD pass the graph branch finishes last (24-26 of 26 layers) -- and moving it to the caller's
+// stream measured 1 % SLOWER (4,632 with bone-in-backward against 4,681): which hardware queue a branch's kernels come from matters as much as the hand-over (DESIGN section 6, round 4,
+// stream placement), so the forward keeps the attention branch there.  KASF_MAIN_BRANCH_FWD / _BWD = 0 | 1 | 2 override.  Results do not depend on the choice
+// (tests/test_gpu_determinism.py: one stream == three streams, bit for bit).
+static int main_branch(bool backward) {
+    static int mb[2] = {-1, -1};
+    if (mb[0] < 0) {
+        const char* b = getenv("KASF_MAIN_BRANCH_BWD");
+        const char* f = getenv("KASF_MAIN_BRANCH_FWD");
+        mb[1] = (b && *b >= '0' && *b <= '2') ? *b - '0' : 2;
+        mb[0] = (f && *f >= '0' && *f <= '2') ? *f - '0' : 0;
+    }
+    return mb[backward ? 1 : 0];
+}
+static inline int side_index(int br, int mainbr) { return br < mainbr ? br : br - 1; }      // 0 / 1: which side stream (and join event) a non-main branch uses
+
 int kasf_forward(const kasf_model* m, const float* params, const void* packed, float* buffers, const float* x, float* out, void* workspace,
                  int64_t workspace_bytes, int32_t batch, int32_t flags, void* stream) {
     struct ModelPath { ModelPath() { kasf_tls_model_path = 1; } ~ModelPath() { kasf_tls_model_path = 0; } } model_path;      // grid widths of the persistent launches (kernels.h)
@@ -755,23 +775,21 @@ int kasf_forward(const kasf_model* m, const float* params, const void* packed, f
         const LayerOff& lo = m->layers[l];
         const LayerWs& lw = p.layers[train ? l : 0];
         if (!train && l > 0) HIPCHK(hipMemsetAsync(c.w(p.stats_begin), 0, p.stats_bytes, c.s));
+        const int mainbr = main_branch(false);
         HIPCHK(hipEventRecord(m->ev_fork, c.s));
         for (int br = 0; br < 3; ++br) {
             Ctx cb = c;
-            if (br > 0) {
-                cb.s = one_stream ? c.s : m->side[br - 1];
+            if (br != mainbr) {
+                cb.s = one_stream ? c.s : m->side[side_index(br, mainbr)];
                 if (!one_stream) HIPCHK(hipStreamWaitEvent(cb.s, m->ev_fork, 0));
             }
             const void* in0 = (br == 2 && l == 0) ? c.w(p.xb) : xcur;         // layer 0: bone branch starts from the bone embedding (:332-336)
             block_forward(cb, lo.blk[2 * br], lw.b[2 * br], in0, c.w(p.xl), p, p.sc[br]);
             block_forward(cb, lo.blk[2 * br + 1], lw.b[2 * br + 1], c.w(lw.b[2 * br].x_out), c.w(p.xl), p, p.sc[br]);
-            if (br > 0) {
-                if (!one_stream) {
-                    HIPCHK(hipEventRecord(m->ev_join[br - 1], cb.s));
-                    HIPCHK(hipStreamWaitEvent(c.s, m->ev_join[br - 1], 0));
-                }
-            }
+            if (br != mainbr && !one_stream) HIPCHK(hipEventRecord(m->ev_join[side_index(br, mainbr)], cb.s));
         }
+        if (!one_stream)                                 // the joins go behind the caller's stream's OWN branch (enqueued above whatever its index)
+            for (int k = 0; k < 2; ++k) HIPCHK(hipStreamWaitEvent(c.s, m->ev_join[k], 0));
         kasf_launch_gate_fwd(c.dt, c.s, c.w(lw.b[1].x_out), c.w(lw.b[3].x_out), c.w(lw.b[5].x_out), params + lo.fus_w, params + lo.fus_b, c.w(lw.gate_out),
                              (float*)c.w(lw.alpha), c.M, m->cfg.use_adaptive_fusion);
         xcur = c.w(lw.gate_out);
@@ -833,12 +851,13 @@ int kasf_backward(const kasf_model* m, const float* params, const void* packed, 
                                  c.w(lw.b[1].x_out), c.w(lw.b[3].x_out), c.w(lw.b[5].x_out), params + lo.fus_w, (const float*)c.w(lw.alpha), c.w(p.ga), c.w(p.gg),
                                  c.w(p.gb), grads + lo.fus_w, grads + lo.fus_b, c.M, m->cfg.use_adaptive_fusion, c.sink);
             const int64_t gsrc[3] = {p.ga, p.gg, p.gb};
+            const int mainbr = main_branch(true);
             HIPCHK(hipEventRecord(m->ev_fork, c.s));
             for (int br = 0; br < 3; ++br) {
                 Ctx cb = c;
                 cb.sink = &sinks[br];
-                if (br > 0) {
-                    cb.s = one_stream ? c.s : m->side[br - 1];
+                if (br != mainbr) {
+                    cb.s = one_stream ? c.s : m->side[side_index(br, mainbr)];
                     if (!one_stream) HIPCHK(hipStreamWaitEvent(cb.s, m->ev_fork, 0));
                 }
                 const Scratch& sc = p.sc[br];
@@ -846,13 +865,10 @@ int kasf_backward(const kasf_model* m, const float* params, const void* packed, 
                 const void* in0 = bone0 ? c.w(p.xb) : x_in;
                 block_backward(cb, lo.blk[2 * br + 1], lw.b[2 * br + 1], c.w(lw.b[2 * br].x_out), c.w(p.xl), c.w(gsrc[br]), c.w(sc.t1), 0, p, sc);
                 block_backward(cb, lo.blk[2 * br], lw.b[2 * br], in0, c.w(p.xl), c.w(sc.t1), bone0 ? c.w(p.g_bone) : c.w(sc.g_in), 0, p, sc);
-                if (br > 0) {
-                    if (!one_stream) {
-                        HIPCHK(hipEventRecord(m->ev_join[br - 1], cb.s));
-                        HIPCHK(hipStreamWaitEvent(c.s, m->ev_join[br - 1], 0));
-                    }
-                }
+                if (br != mainbr && !one_stream) HIPCHK(hipEventRecord(m->ev_join[side_index(br, mainbr)], cb.s));
             }
+            if (!one_stream)
+                for (int k = 0; k < 2; ++k) HIPCHK(hipStreamWaitEvent(c.s, m->ev_join[k], 0));
             // gradient w.r.t. the layer input = sum over the branches (layer 0: the bone branch fed on the bone embedding instead)
             // Only the bottom layer materialises the sum (for the embedding backward); elsewhere the next gate_bwd adds the three on the fly.
             if (l == 0) kasf_launch_add3(c.dt, c.s, g_in, c.w(p.sc[0].g_in), c.w(p.sc[1].g_in), nullptr, c.M * 128);
