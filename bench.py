@@ -301,8 +301,8 @@ def launch_ranks(args, argv):
     import subprocess
     import threading
     n = args.gpus
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
+    with socket.socket() as sk:                          # a free port now; rank 0 binds it a moment later (another process could take it in between: the ranks then
+        sk.bind(("127.0.0.1", 0))                        # fail at rendezvous, this launcher returns non-zero and prints no line -- run again)
         port = sk.getsockname()[1]
     base = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
     procs = []
@@ -315,6 +315,7 @@ def launch_ranks(args, argv):
     reader.start()
     rc = 0
     alive = set(range(n))
+    kill_at = None                                       # a rank that ignores SIGTERM (stuck in a collective) is killed a few seconds later
     while alive:
         for r in sorted(alive):
             c = procs[r].poll()
@@ -326,13 +327,19 @@ def launch_ranks(args, argv):
                 print(f"[bench] rank {r} exited with code {c}: stopping the other ranks", file=sys.stderr, flush=True)
                 for q in alive:
                     procs[q].terminate()             # exactly the processes started above
+                kill_at = time.monotonic() + 5.0
+        if kill_at is not None and alive and time.monotonic() > kill_at:
+            for q in alive:
+                procs[q].kill()
+            kill_at = time.monotonic() + 1e9
         time.sleep(0.05)
     reader.join(timeout=10)
     out = (line[0] if line else b"").decode()
-    sys.stdout.write(out)
-    sys.stdout.flush()
-    if rc == 0 and not out.strip():
-        rc = 1
+    if rc == 0:                                          # a failed run prints no line: a rank 0 that finished before another rank failed must not look like a result
+        sys.stdout.write(out)
+        sys.stdout.flush()
+        if not out.strip():
+            rc = 1
     return rc
 
 
@@ -374,36 +381,41 @@ def extra_config_legs(log):
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / steps
 
-    torch.manual_seed(114514)
-    m = K.KASportsFormer(n_layers=LAYERS, num_heads=8, n_frames=81, compute_dtype="bf16").cuda().train()
-    m.attach_param_grads = False
-    opt = K.FusedAdamW(m, lr=5e-4, weight_decay=0.01)
-    x, y = (t.cuda() for t in K.synthetic_clips(128, 81, seed=1234))
+    def leg_train81():
+        torch.manual_seed(114514)
+        m = K.KASportsFormer(n_layers=LAYERS, num_heads=8, n_frames=81, compute_dtype="bf16").cuda().train()
+        m.attach_param_grads = False
+        opt = K.FusedAdamW(m, lr=5e-4, weight_decay=0.01)
+        x, y = (t.cuda() for t in K.synthetic_clips(128, 81, seed=1234))
 
-    def step():
-        opt.zero_grad()
-        loss, _ = K.loss3(m(x), y)
-        loss.backward()
-        opt.step()
-    dt = timed(step, 10, 2)
-    legs["configs[3]"] = {"workload": "SportsPose-GT 81-frame bf16 training, batch=128, 1 GPU", "clips_per_sec": 128 / dt, "ms_per_step": dt * 1e3, "steps": 10,
-                          "model_mfma_frac": 128 / dt * 3 * FLOP_PER_CLIP_FWD[81] / (PEAK_BF16_TFLOPS * 1e12)}
-    log(f"configs[3] leg done: {128 / dt:.0f} clips/s")
-    del m, opt, x, y
-    torch.cuda.empty_cache()
+        def step():
+            opt.zero_grad()
+            loss, _ = K.loss3(m(x), y)
+            loss.backward()
+            opt.step()
+        dt = timed(step, 10, 2)
+        log(f"configs[3] leg done: {128 / dt:.0f} clips/s")
+        return {"workload": "SportsPose-GT 81-frame bf16 training, batch=128, 1 GPU", "clips_per_sec": 128 / dt, "ms_per_step": dt * 1e3, "steps": 10,
+                "model_mfma_frac": 128 / dt * 3 * FLOP_PER_CLIP_FWD[81] / (PEAK_BF16_TFLOPS * 1e12)}
 
-    torch.manual_seed(114514)
-    m = K.KASportsFormer(n_layers=LAYERS, num_heads=8, n_frames=T, compute_dtype="bf16").cuda().eval()
-    x, _ = K.synthetic_clips(2048, T, seed=1234)
-    x = x.cuda()
-    with torch.no_grad():
-        dt = timed(lambda: m(x), 5, 2)
-    legs["configs[4]"] = {"workload": "synthetic [B=2048, T=27, J=17] inference only, the whole global batch in ONE pass on 1 GPU (8 GPUs: 256 per rank, no communication)",
-                          "clips_per_sec": 2048 / dt, "ms_per_step": dt * 1e3, "steps": 5,
-                          "model_mfma_frac": 2048 / dt * FLOP_PER_CLIP_FWD[27] / (PEAK_BF16_TFLOPS * 1e12)}
-    log(f"configs[4] leg done: {2048 / dt:.0f} clips/s")
-    del m, x
-    torch.cuda.empty_cache()
+    def leg_eval2048():
+        torch.manual_seed(114514)
+        m = K.KASportsFormer(n_layers=LAYERS, num_heads=8, n_frames=T, compute_dtype="bf16").cuda().eval()
+        x, _ = K.synthetic_clips(2048, T, seed=1234)
+        x = x.cuda()
+        with torch.no_grad():
+            dt = timed(lambda: m(x), 5, 2)
+        log(f"configs[4] leg done: {2048 / dt:.0f} clips/s")
+        return {"workload": "synthetic [B=2048, T=27, J=17] inference only, the whole global batch in ONE pass on 1 GPU (8 GPUs: 256 per rank, no communication)",
+                "clips_per_sec": 2048 / dt, "ms_per_step": dt * 1e3, "steps": 5,
+                "model_mfma_frac": 2048 / dt * FLOP_PER_CLIP_FWD[27] / (PEAK_BF16_TFLOPS * 1e12)}
+
+    for name, leg in (("configs[3]", leg_train81), ("configs[4]", leg_eval2048)):
+        try:                                         # a failed leg (out of memory on a smaller part, a kernel error) must not cost the headline its line
+            legs[name] = leg()
+        except Exception as e:
+            legs[name] = {"error": repr(e)}
+        torch.cuda.empty_cache()
 
     cmd = [sys.executable, os.path.abspath(__file__), "--force-dp", "--global-batch", "32", "--det-conf", "--steps", "20", "--warmup", "5",
            "--no-cpu-baseline", "--no-fp32", "--no-kernel-roofline", "--no-extra-configs"]

@@ -159,7 +159,10 @@ int kasf_op_linear(int32_t dtype, const void* a, const void* w, const float* bia
 /* modules/mlp.py inside a FormerModule: out = x + ls2 * (GELU(LN(x) W1^T + b1) W2^T + b2) */
 /* xn_out (optional; bf16 only): also receives LN(x), which kasf_op_mlp_bwd_fused streams instead of recomputing (what training mode does).
  * ABI 7: with dtype = bf16, w2 [128,512] is IEEE FP16 (torch.float16), not bf16: the forward evaluates GELU in packed fp16 and keeps the hidden
- * activation in fp16 for GEMM2 (v_mfma_f32_16x16x32_f16); x, w1 and out stay bf16.  kasf_pack_weights writes that fp16 copy into the arena itself. */
+ * activation in fp16 for GEMM2 (v_mfma_f32_16x16x32_f16); x, w1 and out stay bf16.  kasf_pack_weights writes that fp16 copy into the arena itself.
+ * RANGE (bf16 mode only): the pre-activation z = LN(x) W1^T + b1 and the fc2 weights pass through fp16, whose largest finite value is 65504: |z| > 65504
+ * converts to +-inf (GELU(+inf) = inf, GELU(-inf) = -inf . 0 = NaN where the fp32 form returns x and 0), and a fc2 weight beyond 65504 packs to inf.  LayerNorm'd
+ * inputs with trained weights are five orders of magnitude below that; a checkpoint that is not should be run with dtype = fp32 (exact erf GELU, no fp16 anywhere). */
 int kasf_op_mlp_fwd(int32_t dtype, const void* x, const float* ln_g, const float* ln_b, const void* w1, const float* b1, const void* w2, const float* b2,
                     const float* ls2, void* out, int64_t M, void* xn_out, void* stream);
 int kasf_op_mlp_bwd(int32_t dtype, const void* x, const void* g, const float* ln_g, const float* ln_b, const void* w1, const float* b1,

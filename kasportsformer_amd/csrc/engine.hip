@@ -510,7 +510,7 @@ void block_backward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void*
         const int64_t qb_ = (int64_t)256 * 128 * 128 * 2, kvb_ = (int64_t)256 * 256 * 128 * 2;
         // both fused launches or neither (the q launch registers its dgamma / dbeta rows in the sink; a kv launch declining afterwards would have sent
         // q through the two-kernel sequence a second time)
-        if (jobs && c.M >= WG_FUSE_MIN_TOKENS && kasf_dgrad_wg_supported(128, true, false, false, false, true, c.M, qb_) &&
+        if (jobs && c.M >= WG_FUSE_MIN_TOKENS && kasf_dgrad_wg_supported(128, true, accumulate != 0, false, false, true, c.M, qb_) &&
             kasf_dgrad_wg_supported(256, false, true, false, false, false, c.M, kvb_)) {
             // q: data gradient + dW_q + the block's PROJ gradient (g_mid is its residual operand, o one more ring stream); kv: data gradient + dW_kv.  No streaming
             // weight-gradient launch in this block at all: one finish launch adds the three sets of bf16 partial tiles.
@@ -521,7 +521,10 @@ void block_backward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void*
                                                  wpart, qb, nullptr, nullptr, c.w(w.o), ppart, pbrow);
             const int npk = kasf_launch_dgrad_wg(c.s, dkv, 256, c.pk(o.p_kvT), x_limb, P + o.n1lw, P + o.n1lb, nullptr, c.w(p.g_limb), 1, G + o.n1lw,
                                                  G + o.n1lb, c.M, c.sink, wpart + qb, kvb);
-            if (npq <= 0 || npk <= 0) return;            // cannot happen after the check above; if it ever does, the missing gradients fail every test instead of being double-counted
+            if (npq <= 0 || npk <= 0) {                  // cannot happen after the check above; if it ever does the block's remaining gradients are missing: kasf_backward returns non-zero
+                kasf_set_error(3, "bone block: a fused data + weight gradient launch declined after kasf_dgrad_wg_supported accepted it");
+                return;
+            }
             {
                 fusedwg = proj_fused = true;
                 red[nred++] = KasfBf16Reduce{wpart, G + o.mix_w, npq, 128 * 128};
@@ -737,14 +740,13 @@ int kasf_ws_entry(const kasf_model* m, int32_t batch, int32_t flags, int32_t idx
 // stream placement), so the forward keeps the attention branch there.  KASF_MAIN_BRANCH_FWD / _BWD = 0 | 1 | 2 override.  Results do not depend on the choice
 // (tests/test_gpu_determinism.py: one stream == three streams, bit for bit).
 static int main_branch(bool backward) {
-    static int mb[2] = {-1, -1};
-    if (mb[0] < 0) {
+    struct MB { int v[2]; };
+    static const MB mb = [] {                            // function-local static: initialised once, thread-safe (models may be driven from different host threads)
         const char* b = getenv("KASF_MAIN_BRANCH_BWD");
         const char* f = getenv("KASF_MAIN_BRANCH_FWD");
-        mb[1] = (b && *b >= '0' && *b <= '2') ? *b - '0' : 2;
-        mb[0] = (f && *f >= '0' && *f <= '2') ? *f - '0' : 0;
-    }
-    return mb[backward ? 1 : 0];
+        return MB{{(f && *f >= '0' && *f <= '2') ? *f - '0' : 0, (b && *b >= '0' && *b <= '2') ? *b - '0' : 2}};
+    }();
+    return mb.v[backward ? 1 : 0];
 }
 static inline int side_index(int br, int mainbr) { return br < mainbr ? br : br - 1; }      // 0 / 1: which side stream (and join event) a non-main branch uses
 

@@ -48,7 +48,7 @@ __device__ __forceinline__ double stat_sum(const double* stats, int idx) {
 #pragma unroll
         for (int k = 0; k < KASF_STAT_WORDS; ++k) acc[k] += w[((int64_t)sl * KASF_STAT_LD + idx) * KASF_STAT_WORDS + k];
     if (acc[KASF_STAT_WORDS - 1] != 0) return __builtin_nan("");
-    double v = 0.0;                              // most significant word first; every term is an exactly scaled integer, the three additions round deterministically
+    double v = 0.0;                              // most significant word first; every word is an integer scaled by an exact power of two (its conversion to double rounds once above 2^53, always the same way), the three additions round deterministically: the total does not depend on arrival order
 #pragma unroll
     for (int k = KASF_STAT_WORDS - 2; k >= 0; --k) v += ldexp((double)acc[k], KASF_STAT_E0 + 52 * k);
     return v;

@@ -132,12 +132,27 @@ __device__ __forceinline__ void lnbwd_rows(const T* sC, const T* __restrict__ X,
 // ---- transposed fragments: the reduction index is the ROW index of a row-major swizzled [m][128] tile ----
 template <typename T> __device__ __forceinline__ int eoff(int row, int col) { return Tile<T>::chunk_off(row, col / Tile<T>::EPC) + (col % Tile<T>::EPC); }
 
+// Row order inside a group of 8 reduction rows (round 6).  The swizzle puts element (row, col) at 16-byte slot (col / 8) ^ (row & 15) of its 256-byte row, and a
+// ds_read_b64_tr_b16 is serviced in two 32-lane halves whose lanes read 4 rows x 2 adjacent chunks each (c0 = col0 / 8, always even, and c0 + 1): with CONSECUTIVE
+// rows {m, m+1, m+2, m+3} and {m+8, ..., m+11} slot c0 ^ r of row r is also slot (c0 + 1) ^ (r ^ 1) of row r ^ 1 -- every lane shares its two banks with one
+// other lane (2-way conflict on every transposed read: SQ_LDS_BANK_CONFLICT = 33 % of SQ_LDS_IDX_ACTIVE in k_mlp_bwd_s, rounds 4-5; profiles/r6_mlp_sq_counters.txt).
+// With the EVEN rows of the group in the first read and the ODD rows in the second the 32 lanes of a half touch 16 distinct slots x 2 halves = all 64 banks once.
+// The reduction index inside an MFMA k-step is then a permutation (j < 4: row m + 2j, j >= 4: row m + 2(j - 4) + 1) -- the same one for BOTH operands of every
+// product that uses frag_tr (all of them take both from this function), so the sums are the same sums.
+#ifndef KASF_FRAG_TR_INTERLEAVE
+#define KASF_FRAG_TR_INTERLEAVE 1
+#endif
 __device__ __forceinline__ bf16x8 frag_tr(const bf16* s, int mbase, int col0) {
-    // group of 16 lanes: lane u = 4q+p supplies row (mbase+q), columns col0+4p..; lane u receives column col0+u of 4 rows
+    // group of 16 lanes: lane u = 4q+p supplies one row of the group, columns col0+4p..; lane u receives column col0+u of the 4 rows supplied by q = 0..3
     const int u = threadIdx.x & 15, q = u >> 2, p = u & 3;
     typedef __attribute__((address_space(3))) bf16x4 lds_v4;
+#if KASF_FRAG_TR_INTERLEAVE
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)(s + eoff<bf16>(mbase + 2 * q, col0 + 4 * p)));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)(s + eoff<bf16>(mbase + 2 * q + 1, col0 + 4 * p)));
+#else
     const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)(s + eoff<bf16>(mbase + q, col0 + 4 * p)));
     const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)(s + eoff<bf16>(mbase + 4 + q, col0 + 4 * p)));
+#endif
     return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 

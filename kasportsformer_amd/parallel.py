@@ -31,7 +31,8 @@ class DataParallel:
         if grad_dtype not in ("fp32", "bf16"):
             raise ValueError(f"grad_dtype {grad_dtype!r}: 'fp32' or 'bf16'")
         self.grad_dtype = grad_dtype
-        self._wire = {}                  # (bucket address, elements) -> persistent bf16 staging buffer
+        self._wire = {}                  # bucket index within the step -> persistent bf16 staging buffer (grown when a later step's bucket is larger)
+        self._bucket = 0                 # buckets reduced so far in this step (reset by finish_gradients)
         if not dist.is_initialized():
             raise RuntimeError("init torch.distributed first (backend 'nccl' = RCCL on ROCm; 'gloo' for CPU rehearsal)")
         if model._flat.is_cuda and os.environ.get("GPU_MAX_HW_QUEUES") is None:
@@ -79,10 +80,14 @@ class DataParallel:
         """One bucket: returns (work, staging buffer or None).  bf16: cast on the current stream (the bucket's gradients are final there), reduce the copy."""
         if self.grad_dtype == "fp32":
             return dist.all_reduce(grad_slice, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op), None
-        key = (grad_slice.data_ptr(), grad_slice.numel())
+        # keyed by the bucket's ORDER in the step, never by its address: the flat gradient is a fresh allocation every step (model.py: _launch_backward), so an
+        # address key grew a new 58 MB set whenever the caching allocator moved it (a different batch size, an evaluation pass in between) and never freed one
+        key, n = self._bucket, grad_slice.numel()
+        self._bucket += 1
         buf = self._wire.get(key)
-        if buf is None:
-            buf = self._wire[key] = torch.empty(grad_slice.numel(), dtype=torch.bfloat16, device=grad_slice.device)
+        if buf is None or buf.numel() < n or buf.device != grad_slice.device:
+            buf = self._wire[key] = torch.empty(n, dtype=torch.bfloat16, device=grad_slice.device)
+        buf = buf[:n]
         buf.copy_(grad_slice)
         return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op), buf
 
@@ -108,9 +113,11 @@ class DataParallel:
                     grad_slice.copy_(buf)                  # widen the reduced bf16 bucket back into the flat fp32 gradient
             self._pending = []
         elif m.flat_grad is not None:
+            self._bucket = 0
             _, buf = self._reduce(m.flat_grad[:m.n_live], False)
             if buf is not None:
                 m.flat_grad[:m.n_live].copy_(buf)
+        self._bucket = 0
         if self._scale_in_place and self.world > 1 and m.flat_grad is not None:
             m.flat_grad[:m.n_live].mul_(1.0 / self.world)         # p.grad of every live parameter is a view of this array
 

@@ -49,6 +49,24 @@ def _worker_bf16(rank, world, port, overlap, q):
         assert float(err) < 2 ** -7, float(err)             # one more bf16 rounding of the sum
         assert torch.count_nonzero(g[m.n_live:]) == 0 and g.dtype == torch.float32
         assert opt.grad_scale == 1.0 / world
+        # the staging buffers are keyed by bucket ORDER: later steps -- whose flat gradient is a fresh allocation at another address (another batch size, an
+        # evaluation pass in between) -- reuse them instead of adding a set per address
+        n_wire, ptrs = len(dp._wire), sorted(v.data_ptr() for v in dp._wire.values())
+        keep_alive = []
+        for step in range(3):
+            g2 = torch.zeros(m.n_flat)
+            keep_alive.append(g2)                          # keeps the allocator from handing the same address out again
+            assert g2.data_ptr() != g.data_ptr()
+            for st in range(lib.kasf_backward_stages(m._layout)):
+                _lib.check(lib.kasf_stage_grad_range(m._layout, st, C.byref(b), C.byref(e)))
+                if e.value > b.value:
+                    g2[b.value:e.value] = mine[b.value:e.value]
+                    if m.grad_stage_hook is not None:
+                        m.grad_stage_hook(st, g2[b.value:e.value])
+            m.flat_grad = g2
+            dp.finish_gradients()
+            assert len(dp._wire) == n_wire and sorted(v.data_ptr() for v in dp._wire.values()) == ptrs, (step, len(dp._wire), n_wire)
+            assert torch.equal(g2[:m.n_live], g[:m.n_live])
         q.put((rank, "ok"))
     except Exception as ex:  # pragma: no cover
         q.put((rank, repr(ex)))
