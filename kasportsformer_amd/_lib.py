@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("KASF_LIB") or os.path.join(_HERE, "libkasf_hip.so")
 DTYPE_F32, DTYPE_BF16 = 0, 1
 FLAG_TRAIN, FLAG_RETURN_REP, FLAG_KEEP = 1, 2, 4
 EVAL_COLS = 22
-ABI_VERSION = 7          # kasf_version() of the library these prototypes describe (a stale in-tree .so is refused)
+ABI_VERSION = 8          # kasf_version() of the library these prototypes describe (a stale in-tree .so is refused)
 
 
 class KasfConfig(C.Structure):
@@ -38,6 +38,8 @@ SIGNATURES = {
     "kasf_set_fused_wgrad_min_tokens": (None, [_i64]),
     "kasf_get_fused_wgrad_min_tokens": (_i64, []),
     "kasf_get_single_stream": (_i32, []),
+    "kasf_set_fused_attn_bwd": (None, [_i32]),
+    "kasf_get_fused_attn_bwd": (_i32, []),
     "kasf_set_deterministic": (None, [_i32]),
     "kasf_get_deterministic": (_i32, []),
     "kasf_model_create": (_i32, [C.POINTER(KasfConfig), C.POINTER(_vp)]),

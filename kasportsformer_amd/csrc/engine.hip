@@ -53,6 +53,19 @@ static bool single_stream() {
 #endif
 static std::atomic<int64_t> g_wg_fuse_min_tokens{KASF_WG_FUSE_MIN_TOKENS};      // kasf_set_fused_wgrad_min_tokens(): tests compare the fused with the two-kernel sequence on one shape
 #define WG_FUSE_MIN_TOKENS (g_wg_fuse_min_tokens.load(std::memory_order_relaxed))
+// Round 6: the backward of an attention / bone block with groups of <= 32 positions (bf16, 8 heads) is ONE launch that re-forms q | k | v and the attention output from x
+// (csrc/k_attn_bwd_f.hip): the forward then saves nothing for it and the workspace has no qkv / kv / o slots.  kasf_set_fused_attn_bwd(0) (or KASF_ATTN_BWD_FUSED=0 in the
+// environment, read once) selects the four-launch sequence of rounds 1-5 -- the tests compare the two; forward and backward of one step must run under the same setting.
+static std::atomic<int> g_fused_attn_bwd{-1};
+static bool fused_attn_bwd_on() {
+    int v = g_fused_attn_bwd.load(std::memory_order_relaxed);
+    if (v < 0) { const char* e = getenv("KASF_ATTN_BWD_FUSED"); v = (e != nullptr && *e == '0') ? 0 : 1; g_fused_attn_bwd.store(v, std::memory_order_relaxed); }
+    return v != 0;
+}
+static bool fused_attn_bwd(const kasf_config& cfg, int kind, int mode) {
+    const int Lg = mode == 0 ? 17 : cfg.n_frames;
+    return kind != 1 /* KIND_GRAPH */ && cfg.dtype == KASF_BF16 && cfg.num_heads == 8 && Lg <= 32 && fused_attn_bwd_on();
+}
 constexpr int64_t WG_JOBS_FLOATS = 248 * 128 * 128 + 248 * 128 + 4096;   // the proj job alone: 248 splits of one 128 x 128 tile + their bias rows
 constexpr int64_t WG_BF16_BYTES = (int64_t)256 * 384 * 128 * 2 + (int64_t)256 * 128 * 128 * 2 + 256 * 128 * 4;         // <= 256 bf16 partial tiles of the block's fused data + weight gradient launches (qkv: 384 rows; q + kv: 128 + 256)
 constexpr int64_t WG_PARTIAL_FLOATS = (KASF_MLP_PARTIAL_FLOATS + 65536 > WG_JOBS_FLOATS + WG_BF16_BYTES / 4 ? KASF_MLP_PARTIAL_FLOATS + 65536 : WG_JOBS_FLOATS + WG_BF16_BYTES / 4);   // per-split weight-gradient tiles (256 workgroups x 128x128, or 64 ranges x (dW1 + dW2) of the MLP) + the per-split rows of a bias gradient
@@ -296,9 +309,11 @@ void build_plan(const kasf_model* m, int B, bool train, bool names, Plan& p) {
         for (int b = 0; b < 6; ++b) {
             BlkWs& w = lw.b[b];
             const int kind = BLOCK_KIND[b];
-            if (kind == KIND_ATT) w.qkv = take(M * 384, 0, "qkv", l, b);
-            if (kind == KIND_BONE) { w.qkv = take(M * 128, 0, "q", l, b); w.kv = take(M * 256, 0, "kv", l, b); }
-            if (kind != KIND_GRAPH) w.o = take(M * 128, 0, "o", l, b);
+            const bool recompute = train && fused_attn_bwd(m->cfg, kind, b & 1);      // the fused backward re-forms q | k | v | o from x: nothing to keep
+            w.qkv = w.kv = w.o = -1;
+            if (kind == KIND_ATT && !recompute) w.qkv = take(M * 384, 0, "qkv", l, b);
+            if (kind == KIND_BONE && !recompute) { w.qkv = take(M * 128, 0, "q", l, b); w.kv = take(M * 256, 0, "kv", l, b); }
+            if (kind != KIND_GRAPH && !recompute) w.o = take(M * 128, 0, "o", l, b);
             // temporal attention over 33..96 frames (T = 81): log-sum-exp of the scores per (token, head), left by the fused forward for k_attn_bwd_kt
             w.lse = (train && kind != KIND_GRAPH && (b & 1) && T > 32 && T <= 96 && m->cfg.dtype == KASF_BF16 && m->cfg.num_heads == 8) ? take(M * 8, 1, "lse", l, b) : -1;
             if (kind == KIND_GRAPH) {
@@ -376,8 +391,8 @@ void block_forward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void* 
         const bool bone = o.kind == KIND_BONE;
         mixer_done = kasf_launch_attn_block_fwd(c.s, bone ? 1 : 0, x_in, bone ? x_limb : nullptr, P + o.n1w, P + o.n1b, bone ? P + o.n1lw : nullptr,
                                                 bone ? P + o.n1lb : nullptr, c.pk(o.p_mix), bone ? c.pk(o.p_kv) : nullptr, c.pk(o.p_proj), P + o.proj_b,
-                                                P + o.ls1, c.train ? c.w(w.qkv) : nullptr, (c.train && bone) ? c.w(w.kv) : nullptr,
-                                                c.train ? c.w(w.o) : nullptr, c.w(w.x_mid), c.B, c.T, o.mode, (c.train && w.lse >= 0) ? (float*)c.w(w.lse) : nullptr);
+                                                P + o.ls1, (c.train && w.qkv >= 0) ? c.w(w.qkv) : nullptr, (c.train && bone && w.kv >= 0) ? c.w(w.kv) : nullptr,
+                                                (c.train && w.o >= 0) ? c.w(w.o) : nullptr, c.w(w.x_mid), c.B, c.T, o.mode, (c.train && w.lse >= 0) ? (float*)c.w(w.lse) : nullptr);
     }
     if (mixer_done) {
     } else if (o.kind == KIND_ATT) {
@@ -445,6 +460,30 @@ void block_backward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void*
         kasf_launch_dgrad_lnbwd(c.dt, c.s, c.w(sc.duv), 256, c.pk(o.p_mixT), c.w(sc.rbuf), x_in, P + o.n1w, g_mid, dst, accumulate, G + o.n1w, G + o.n1b,
                                 c.M, nullptr, nullptr, c.sink);
         kasf_launch_wgrad(c.dt, c.s, c.w(sc.duv), 256, 256, c.w(w.xn), 128, 128, nullptr, nullptr, G + o.mix_w, 128, G + o.uv_b, c.M, part, WG_PARTIAL_FLOATS);
+        return;
+    }
+    if (fused_attn_bwd(c.m->cfg, o.kind, o.mode)) {
+        // one launch: LN, q | k | v, d_o, the 8 attention cores, the data gradient with its LayerNorm backward + residual, and every weight gradient of the block as bf16
+        // partial tiles (qkv | q, kv, proj) + per-workgroup rows (LayerNorm gamma / beta, colsum(g_mid)); one finishing launch adds them in a fixed order
+        const bool bone = o.kind == KIND_BONE;
+        char* wpart = (char*)(part + WG_JOBS_FLOATS);
+        const int64_t qb = (int64_t)256 * (bone ? 128 : 384) * 128 * 2, kvb = bone ? (int64_t)256 * 256 * 128 * 2 : 0;
+        char* ppart = wpart + qb + kvb;
+        float* pbrow = (float*)(ppart + (int64_t)256 * 128 * 128 * 2);
+        const int np = (accumulate != 0 || c.sink == nullptr) ? 0 :
+            kasf_launch_attn_block_bwd(c.s, bone ? 1 : 0, x_in, bone ? x_limb : nullptr, g_mid, P + o.n1w, P + o.n1b, bone ? P + o.n1lw : nullptr, bone ? P + o.n1lb : nullptr,
+                                       c.pk(o.p_mix), bone ? c.pk(o.p_kv) : nullptr, c.pk(o.p_mixT), bone ? c.pk(o.p_kvT) : nullptr, c.pk(o.p_projTs), dst,
+                                       bone ? c.w(p.g_limb) : nullptr, G + o.n1w, G + o.n1b, bone ? G + o.n1lw : nullptr, bone ? G + o.n1lb : nullptr, c.sink, wpart,
+                                       bone ? wpart + qb : nullptr, ppart, pbrow, c.B, c.T, o.mode);
+        if (np <= 0) {                                   // the forward kept nothing for the four-launch sequence: there is no other way to finish this block
+            kasf_set_error(3, "fused attention-block backward did not launch (column-sum scratch exhausted or unsupported call)");
+            return;
+        }
+        KasfBf16Reduce red[2];
+        int nred = 0;
+        red[nred++] = KasfBf16Reduce{wpart, G + o.mix_w, np, (bone ? 128 : 384) * 128};
+        if (bone) red[nred++] = KasfBf16Reduce{wpart + qb, G + o.kv_w, np, 256 * 128};
+        kasf_launch_proj_finish(c.s, ppart, pbrow, np, G + o.proj_w, P + o.proj_w, P + o.proj_b, P + o.ls1, G + o.proj_b, G + o.ls1, nred, red);
         return;
     }
     // d_o = g_mid . (ls1 . Wproj);  G_proj = g_mid^T o (unscaled) -> finish: dWproj, dbproj, dls1
@@ -575,9 +614,11 @@ int32_t kasf_get_single_stream(void) { return single_stream() ? 1 : 0; }
 // the round-3 names: the setting never was about determinism (gradients are bit-reproducible either way)
 void kasf_set_fused_wgrad_min_tokens(int64_t tokens) { g_wg_fuse_min_tokens.store(tokens < 0 ? (int64_t)KASF_WG_FUSE_MIN_TOKENS : tokens, std::memory_order_relaxed); }
 int64_t kasf_get_fused_wgrad_min_tokens(void) { return g_wg_fuse_min_tokens.load(std::memory_order_relaxed); }
+void kasf_set_fused_attn_bwd(int32_t on) { g_fused_attn_bwd.store(on < 0 ? -1 : (on ? 1 : 0), std::memory_order_relaxed); }
+int32_t kasf_get_fused_attn_bwd(void) { return fused_attn_bwd_on() ? 1 : 0; }
 void kasf_set_deterministic(int32_t on) { kasf_set_single_stream(on); }
 int32_t kasf_get_deterministic(void) { return kasf_get_single_stream(); }
-int kasf_version(void) { return 7; }
+int kasf_version(void) { return 8; }
 
 int kasf_model_create(const kasf_config* cfg, kasf_model** out) {
     if (cfg == nullptr || out == nullptr) return kasf_set_error(2, "null argument");

@@ -818,6 +818,28 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_2p(const bf16* __restrict__
 #ifndef KASF_PERS_FLUSH_AT          // where group t-1's dq | dk | dv leave: 0 at the top of group t, right in front of the look-ahead loads (rounds 2-4); 1 behind the barrier; 2 behind d_o
 #define KASF_PERS_FLUSH_AT 2        // (shipped, round 5); 3 behind pass 1.  Stores and loads issued back to back by one wave cost both: in step <9> 66.8 / 58.3 / 56.1 / 61.1 us, <16> 60.1 / 53.2 / 54.0 / 57.4
 #endif
+// [32 queries][32 keys] P / dS tiles of the persistent kernel (round 6): the four 16-byte chunks of row r are stored at chunk ^ ((r >> 1) & 3).  Unswizzled, the 8-byte row
+// writes of 16 consecutive rows hit banks 16 r mod 32 -- 8-way conflicts on every write: SQ_LDS_BANK_CONFLICT was 60 % of SQ_LDS_IDX_ACTIVE in this kernel and the LDS
+// busy 63 % of its time (profiles/r6_attn_sq_counters_before.txt); swizzled they are 2-way, and the transposed reads still cover whole 64-byte rows (conflict-free).
+__device__ __forceinline__ int ps_off(int r, int col) { return r * 32 + ((((col >> 3) ^ (r >> 1)) & 3) << 3) + (col & 7); }
+__device__ __forceinline__ bf16x8 tr_frag32z(const bf16* s_tile, int ks) {
+    const int lane = threadIdx.x & 63, u = lane & 15, hh = lane >> 5, q = u >> 2, p = u & 3, c0 = 16 * ((lane >> 4) & 1);
+    typedef __attribute__((address_space(3))) bf16x4 lds_v4;
+    const int k0 = 16 * ks + 4 * hh;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)(s_tile + ps_off(k0 + q, c0 + 4 * p)));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)(s_tile + ps_off(k0 + 8 + q, c0 + 4 * p)));
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+#ifndef KASF_PERS_PSWZ
+#define KASF_PERS_PSWZ 1
+#endif
+#if KASF_PERS_PSWZ
+#define PERS_POFF(r, col) ps_off(r, col)
+#define PERS_TR32(t, ks) tr_frag32z(t, ks)
+#else
+#define PERS_POFF(r, col) ((r) * 32 + (col))
+#define PERS_TR32(t, ks) tr_frag32(t, ks)
+#endif
 template <int NR>
 __global__ __launch_bounds__(512, 4) void k_attn_bwd_pers(const bf16* __restrict__ Q, int64_t ldq, const bf16* __restrict__ K, const bf16* __restrict__ V,
                                                           int64_t ldkv, bf16* __restrict__ dQ, int64_t lddq, bf16* __restrict__ dK, bf16* __restrict__ dV,
@@ -872,8 +894,8 @@ __global__ __launch_bounds__(512, 4) void k_attn_bwd_pers(const bf16* __restrict
 #pragma unroll
         for (int a4 = NA4; a4 < 4; ++a4) {
             float z4[4] = {0.f, 0.f, 0.f, 0.f};
-            store4(sP + r * 32 + 8 * a4 + 4 * hh, z4);
-            store4(sdS + r * 32 + 8 * a4 + 4 * hh, z4);
+            store4(sP + PERS_POFF(r, 8 * a4 + 4 * hh), z4);
+            store4(sdS + PERS_POFF(r, 8 * a4 + 4 * hh), z4);
         }
     }
 #ifdef PERS_PROF
@@ -948,7 +970,7 @@ __global__ __launch_bounds__(512, 4) void k_attn_bwd_pers(const bf16* __restrict
 #pragma unroll
         for (int a4 = 0; a4 < NA4; ++a4) {
             float v4[4] = {st[4 * a4], st[4 * a4 + 1], st[4 * a4 + 2], st[4 * a4 + 3]};
-            store4(sP + r * 32 + 8 * a4 + 4 * hh, v4);
+            store4(sP + PERS_POFF(r, 8 * a4 + 4 * hh), v4);
         }
 #pragma unroll
         for (int g = 0; g < NR; ++g) st[g] = st[g] * (dp[g] - delta) * 0.25f;       // dS^T (scale folded)
@@ -957,7 +979,7 @@ __global__ __launch_bounds__(512, 4) void k_attn_bwd_pers(const bf16* __restrict
 #pragma unroll
         for (int a4 = 0; a4 < NA4; ++a4) {
             float v4[4] = {st[4 * a4], st[4 * a4 + 1], st[4 * a4 + 2], st[4 * a4 + 3]};
-            store4(sdS + r * 32 + 8 * a4 + 4 * hh, v4);
+            store4(sdS + PERS_POFF(r, 8 * a4 + 4 * hh), v4);
         }
         PQ(3);
 #if KASF_PERS_FLUSH_AT == 3
@@ -968,8 +990,8 @@ __global__ __launch_bounds__(512, 4) void k_attn_bwd_pers(const bf16* __restrict
         f32x16 dv = zero16(), dk = zero16();
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            dv = mfma32(tr_frag(sD, ks), tr_frag32(sP, ks), dv);
-            dk = mfma32(tr_frag(sQ, ks), tr_frag32(sdS, ks), dk);
+            dv = mfma32(tr_frag(sD, ks), PERS_TR32(sP, ks), dv);
+            dk = mfma32(tr_frag(sQ, ks), PERS_TR32(sdS, ks), dk);
         }
         pq = swap_t16(dq);       // stored during the NEXT group (KASF_PERS_FLUSH_AT): behind that group's look-ahead loads in the in-order vmcnt queue, so the wait
         pv = swap_t16(dv);       // for those loads never has stores ahead of it -- and not back to back with them either (round 5: -16 % / -11 %)

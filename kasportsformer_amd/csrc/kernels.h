@@ -220,6 +220,14 @@ bool kasf_launch_attn_block_fwd(hipStream_t s, int bone, const void* x, const vo
                                 const float* lnl_b, const void* Wq, const void* Wkv, const void* Wproj, const float* bproj, const float* ls1, void* q_save,
                                 void* kv_save, void* o_save, void* out, int B, int T, int mode, float* lse_save = nullptr);   // lse_save [M][8]: groups of 33..96 positions in training
 
+// ---- k_attn_bwd_f.hip (bf16, 8 heads, groups of <= 32 positions): the whole backward of an attention / bone block from x (, x_limb) and g_mid in one launch ----
+// Returns the number of per-workgroup partial tiles written (0: nothing launched, nothing registered in the sink).  wpart: 256 x [384 | 128][128] bf16 (self qkv | bone q),
+// wpart_kv: bone, 256 x [256][128]; ppart: 256 x [128][128] (G_proj = g_mid^T o); pbrow: 256 x 128 floats (colsum g_mid): the operands of kasf_launch_proj_finish.
+int kasf_launch_attn_block_bwd(hipStream_t s, int bone, const void* x, const void* x_limb, const void* g_mid, const float* ln_g, const float* ln_b, const float* lnl_g,
+                               const float* lnl_b, const void* Wf, const void* Wkvf, const void* WT, const void* WkvT, const void* WprojTs, void* out, void* out_limb,
+                               float* dgamma, float* dbeta, float* dgamma_l, float* dbeta_l, KasfColSink* sink, void* wpart, void* wpart_kv, void* ppart, float* pbrow,
+                               int B, int T, int mode);
+
 // ---- k_gemm.hip: several bf16 weight gradients dW_j[N_j][128] += G_j^T X_j in one streaming launch + one finishing launch ----
 bool kasf_launch_wgrad_jobs(hipStream_t s, int njobs, const void* const* G, const void* const* X, const int* N, float* const* dW, float* const* dbias,
                             int fin_job, const float* fin_W, const float* fin_bias, const float* fin_ls, float* fin_dls, int64_t M, float* partial,

@@ -145,3 +145,37 @@ def test_fused_and_two_kernel_weight_gradients_agree():
     rel = float((ga - gb).abs().max() / gb.abs().max())
     print(f"[fused vs two-kernel weight gradients, B = 96] cosine {cos:.8f}, max |diff| / max |g| {rel:.3e}")
     assert cos > 0.99999 and rel < 5e-3, (cos, rel)
+
+
+@pytest.mark.parametrize("T,B", [(27, 8), (27, 96), (9, 5)])          # 96 clips: several groups per workgroup and the fused MLP / GCN weight-gradient kernels beside it; T = 9: short temporal groups
+def test_fused_attention_backward_agrees_with_the_four_launch_sequence(T, B):
+    """The same step with the attention / bone blocks' backward as ONE launch that re-forms q | k | v | o from x (csrc/k_attn_bwd_f.hip, the default) and as the
+    four-launch sequence of rounds 1-5 (saved q | k | v | o, k_attn_bwd_pers, k_dgrad_r, weight-gradient jobs): the same products with different bf16 rounding
+    points, so not the same bits -- but the forward is untouched (it only stops saving), every gradient agrees far inside the bf16 bars of the oracle tests, both
+    forms reproduce themselves bit for bit, and the workspace of the fused form has no q | k | v | o slots."""
+    from kasportsformer_amd import _lib
+    lib = _lib.load()
+    assert lib.kasf_get_fused_attn_bwd() == 1
+    a = _three_runs("bf16", T, B)
+    assert torch.equal(a[0][2], a[1][2]) and torch.equal(a[0][2], a[2][2])
+    _, model = make_pair(3, T, "bf16")
+    ws_fused = lib.kasf_workspace_bytes(model._device_handle(), B, 1)
+    lib.kasf_set_fused_attn_bwd(0)
+    try:
+        assert lib.kasf_get_fused_attn_bwd() == 0
+        ws_plain = lib.kasf_workspace_bytes(model._device_handle(), B, 1)
+        runs = _three_runs("bf16", T, B)
+    finally:
+        lib.kasf_set_fused_attn_bwd(-1)
+    assert lib.kasf_get_fused_attn_bwd() == 1
+    M = B * T * 17
+    assert ws_plain - ws_fused >= 3 * 4 * M * 512 * 2, (ws_plain, ws_fused)      # 4 blocks per layer x (384 + 128) bf16 elements per token
+    b = runs[0]
+    assert torch.equal(runs[0][2], runs[1][2]) and torch.equal(runs[0][2], runs[2][2])
+    assert torch.equal(a[0][0], b[0]) and torch.equal(a[0][3], b[3])                          # predictions and BatchNorm statistics: the forward is the same forward
+    ga, gb = a[0][2].double(), b[2].double()
+    assert not torch.equal(a[0][2], b[2]), "the switch did not change the path"
+    cos = float((ga * gb).sum() / (ga.norm() * gb.norm()))
+    rel = float((ga - gb).abs().max() / gb.abs().max())
+    print(f"[fused attention backward vs four launches, T = {T}, B = {B}] cosine {cos:.8f}, max |diff| / max |g| {rel:.3e}")
+    assert cos > 0.9999 and rel < 2e-2, (cos, rel)
