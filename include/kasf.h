@@ -66,13 +66,14 @@ int32_t kasf_get_single_stream(void);
  * level (tests/test_gpu_determinism.py compares them on one shape). */
 void kasf_set_fused_wgrad_min_tokens(int64_t tokens);
 int64_t kasf_get_fused_wgrad_min_tokens(void);
-/* Process-wide (ABI 8): 1 (default; 0 when KASF_ATTN_BWD_FUSED=0 is in the environment) = in bf16 mode with 8 heads the backward of an attention / bone block whose groups
- * have at most 32 positions (every spatial block; temporal blocks up to n_frames = 32) is ONE launch that re-forms LN(x), q | k | v and the attention output from the block
- * input (csrc/k_attn_bwd_f.hip; reference: modules/selfattention.py:18-57, modules/bone_crossattention.py:19-62, KASportsFormer.py:103-110): the training forward then
- * saves no q | k | v | o for these blocks and kasf_workspace_bytes shrinks accordingly (T = 27, B = 256: 26.9 -> 14.4 GB).  0 = the four-launch sequence of ABI <= 7
- * (saved q | k | v | o, attention cores, data gradient + LayerNorm backward, streaming weight gradients).  Both are bit-reproducible; they agree with each other at bf16
- * rounding level (tests/test_gpu_determinism.py).  kasf_workspace_bytes, kasf_forward and kasf_backward of one step must see the SAME setting (the workspace layout and
- * what the forward saves depend on it): change it only between steps, then re-query kasf_workspace_bytes.  on < 0 restores the default. */
+/* Process-wide (ABI 8), OPT-IN: 1 (default 0; 1 when KASF_ATTN_BWD_FUSED=1 is in the environment) = in bf16 mode with 8 heads the backward of an attention / bone block whose
+ * groups have at most 32 positions (every spatial block; temporal blocks up to n_frames = 32) is ONE launch that re-forms LN(x), q | k | v and the attention output from the
+ * block input (csrc/k_attn_bwd_f.hip; reference: modules/selfattention.py:18-57, modules/bone_crossattention.py:19-62, KASportsFormer.py:103-110) followed by one streaming
+ * weight-gradient launch: the training forward then saves no q | k | v | o for these blocks and kasf_workspace_bytes shrinks accordingly (T = 27, B = 256: 26.9 -> 14.4 GB).
+ * 0 = the four-launch sequence (saved q | k | v | o, attention cores, data gradient + LayerNorm backward with the fused weight gradient, proj weight gradient): 15 % FASTER per
+ * training step on MI355X, hence the default.  Both are bit-reproducible; they agree with each other at bf16 rounding level
+ * (tests/test_gpu_determinism.py).  kasf_workspace_bytes, kasf_forward and kasf_backward of one step must see the SAME setting (the workspace layout and what the forward saves
+ * depend on it): change it only between steps, then re-query kasf_workspace_bytes.  on < 0 restores the default. */
 void kasf_set_fused_attn_bwd(int32_t on);
 int32_t kasf_get_fused_attn_bwd(void);
 void kasf_set_deterministic(int32_t on);

@@ -53,13 +53,15 @@ static bool single_stream() {
 #endif
 static std::atomic<int64_t> g_wg_fuse_min_tokens{KASF_WG_FUSE_MIN_TOKENS};      // kasf_set_fused_wgrad_min_tokens(): tests compare the fused with the two-kernel sequence on one shape
 #define WG_FUSE_MIN_TOKENS (g_wg_fuse_min_tokens.load(std::memory_order_relaxed))
-// Round 6: the backward of an attention / bone block with groups of <= 32 positions (bf16, 8 heads) is ONE launch that re-forms q | k | v and the attention output from x
-// (csrc/k_attn_bwd_f.hip): the forward then saves nothing for it and the workspace has no qkv / kv / o slots.  kasf_set_fused_attn_bwd(0) (or KASF_ATTN_BWD_FUSED=0 in the
-// environment, read once) selects the four-launch sequence of rounds 1-5 -- the tests compare the two; forward and backward of one step must run under the same setting.
+// Round 6, OPT-IN (kasf_set_fused_attn_bwd(1) or KASF_ATTN_BWD_FUSED=1 in the environment, read once): the backward of an attention / bone block with groups of <= 32 positions
+// (bf16, 8 heads) as ONE launch that re-forms q | k | v and the attention output from x (csrc/k_attn_bwd_f.hip) + one streaming weight-gradient launch: the forward then saves
+// nothing for these blocks and the workspace has no qkv / kv / o slots (T = 27, B = 256: 26.9 -> 14.4 GB).  Parity-green, bit-reproducible -- and SLOWER than the four-launch
+// sequence of rounds 1-5, which therefore stays the default (3,926 against 4,620 clips/s; the phase timers say why).  Forward and backward of one
+// step must run under the same setting.
 static std::atomic<int> g_fused_attn_bwd{-1};
 static bool fused_attn_bwd_on() {
     int v = g_fused_attn_bwd.load(std::memory_order_relaxed);
-    if (v < 0) { const char* e = getenv("KASF_ATTN_BWD_FUSED"); v = (e != nullptr && *e == '0') ? 0 : 1; g_fused_attn_bwd.store(v, std::memory_order_relaxed); }
+    if (v < 0) { const char* e = getenv("KASF_ATTN_BWD_FUSED"); v = (e != nullptr && *e == '1') ? 1 : 0; g_fused_attn_bwd.store(v, std::memory_order_relaxed); }
     return v != 0;
 }
 static bool fused_attn_bwd(const kasf_config& cfg, int kind, int mode) {
@@ -463,27 +465,31 @@ void block_backward(const Ctx& c, const BlockOff& o, const BlkWs& w, const void*
         return;
     }
     if (fused_attn_bwd(c.m->cfg, o.kind, o.mode)) {
-        // one launch: LN, q | k | v, d_o, the 8 attention cores, the data gradient with its LayerNorm backward + residual, and every weight gradient of the block as bf16
-        // partial tiles (qkv | q, kv, proj) + per-workgroup rows (LayerNorm gamma / beta, colsum(g_mid)); one finishing launch adds them in a fixed order
+        // one launch: LN, q | k | v, d_o, the 8 attention cores, the data gradient with its LayerNorm backward + residual, the proj weight gradient (bf16 partial tiles + rows of
+        // colsum(g_mid)) and per-workgroup rows of the LayerNorm gamma / beta gradients; it leaves dq | dk | dv and LN(x) for ONE streaming weight-gradient launch, whose finish
+        // launch also adds the proj tiles and applies the layer-scale algebra
         const bool bone = o.kind == KIND_BONE;
-        char* wpart = (char*)(part + WG_JOBS_FLOATS);
-        const int64_t qb = (int64_t)256 * (bone ? 128 : 384) * 128 * 2, kvb = bone ? (int64_t)256 * 256 * 128 * 2 : 0;
-        char* ppart = wpart + qb + kvb;
+        char* ppart = (char*)(part + WG_JOBS_FLOATS);
         float* pbrow = (float*)(ppart + (int64_t)256 * 128 * 128 * 2);
+        char* dq = (char*)c.w(sc.dqkv);
+        char* dkv = dq + c.M * 128 * c.es;
         const int np = (accumulate != 0 || c.sink == nullptr) ? 0 :
             kasf_launch_attn_block_bwd(c.s, bone ? 1 : 0, x_in, bone ? x_limb : nullptr, g_mid, P + o.n1w, P + o.n1b, bone ? P + o.n1lw : nullptr, bone ? P + o.n1lb : nullptr,
-                                       c.pk(o.p_mix), bone ? c.pk(o.p_kv) : nullptr, c.pk(o.p_mixT), bone ? c.pk(o.p_kvT) : nullptr, c.pk(o.p_projTs), dst,
-                                       bone ? c.w(p.g_limb) : nullptr, G + o.n1w, G + o.n1b, bone ? G + o.n1lw : nullptr, bone ? G + o.n1lb : nullptr, c.sink, wpart,
-                                       bone ? wpart + qb : nullptr, ppart, pbrow, c.B, c.T, o.mode);
-        if (np <= 0) {                                   // the forward kept nothing for the four-launch sequence: there is no other way to finish this block
-            kasf_set_error(3, "fused attention-block backward did not launch (column-sum scratch exhausted or unsupported call)");
-            return;
+                                       c.pk(o.p_mix), bone ? c.pk(o.p_kv) : nullptr, bone ? c.pk(o.p_mixT) : nullptr, c.pk(o.p_projTs), dst, bone ? c.w(p.g_limb) : nullptr,
+                                       dq, bone ? dkv : nullptr, c.w(sc.xn_a), bone ? c.w(sc.xn_b) : nullptr, G + o.n1w, G + o.n1b, bone ? G + o.n1lw : nullptr,
+                                       bone ? G + o.n1lb : nullptr, c.sink, ppart, pbrow, c.B, c.T, o.mode);
+        bool done = false;
+        if (np > 0) {
+            const void* Gs[2] = {dq, dkv};
+            const void* Xs[2] = {c.w(sc.xn_a), bone ? c.w(sc.xn_b) : nullptr};
+            const int Ns[2] = {bone ? 128 : 384, 256};
+            float* dWs[2] = {G + o.mix_w, bone ? G + o.kv_w : nullptr};
+            float* dbs[2] = {nullptr, nullptr};
+            done = kasf_launch_wgrad_jobs(c.s, bone ? 2 : 1, Gs, Xs, Ns, dWs, dbs, -1, P + o.proj_w, P + o.proj_b, P + o.ls1, G + o.ls1, c.M, part, WG_JOBS_FLOATS, 0, nullptr,
+                                          ppart, pbrow, np, G + o.proj_w, G + o.proj_b);
         }
-        KasfBf16Reduce red[2];
-        int nred = 0;
-        red[nred++] = KasfBf16Reduce{wpart, G + o.mix_w, np, (bone ? 128 : 384) * 128};
-        if (bone) red[nred++] = KasfBf16Reduce{wpart + qb, G + o.kv_w, np, 256 * 128};
-        kasf_launch_proj_finish(c.s, ppart, pbrow, np, G + o.proj_w, P + o.proj_w, P + o.proj_b, P + o.ls1, G + o.proj_b, G + o.ls1, nred, red);
+        if (!done)                                       // the forward kept nothing for the four-launch sequence: there is no other way to finish this block
+            kasf_set_error(3, "fused attention-block backward did not launch (column-sum scratch exhausted or unsupported call)");
         return;
     }
     // d_o = g_mid . (ls1 . Wproj);  G_proj = g_mid^T o (unscaled) -> finish: dWproj, dbproj, dls1

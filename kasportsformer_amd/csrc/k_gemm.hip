@@ -468,6 +468,7 @@ struct FinJob {
     const float *W, *bias, *ls;   // W != nullptr (K == 128): out += ls[n] * G, dls[n] += <W[n], G[n]> + bias[n] * colsum[n], db[n] += ls[n] * colsum[n]
     float *db, *dls;
     const float* brow;            // [splits][N] per-split column sums of G (colsum = their fixed-order sum)
+    int nsplit;                   // partial tiles of THIS job (round 6: a job whose tiles come out of a fused kernel -- one per workgroup -- rides beside streaming jobs)
 };
 struct FinRed {                // bf16 partial tiles of a fused data + weight gradient launch (k_dgrad_r<..., WG>): out[e] += sum_z part[z][e]
     const bf16* part;
@@ -535,14 +536,14 @@ __global__ __launch_bounds__(256) void k_wgrad_finish_jobs(const FinJobs js) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) { s0[k] = 0.f; s1[k] = 0.f; }
     int z = zl;
-    for (; z + 16 < js.splits; z += 32) {
+    for (; z + 16 < jb.nsplit; z += 32) {
         float a[8], b[8];
         load8(reinterpret_cast<const bf16*>(jb.partial) + (int64_t)z * stride + e, a);           // (the jobs launch leaves bf16 tiles)
         load8(reinterpret_cast<const bf16*>(jb.partial) + (int64_t)(z + 16) * stride + e, b);
 #pragma unroll
         for (int k = 0; k < 8; ++k) { s0[k] += a[k]; s1[k] += b[k]; }
     }
-    if (z < js.splits) {
+    if (z < jb.nsplit) {
         float a[8];
         load8(reinterpret_cast<const bf16*>(jb.partial) + (int64_t)z * stride + e, a);
 #pragma unroll
@@ -552,7 +553,7 @@ __global__ __launch_bounds__(256) void k_wgrad_finish_jobs(const FinJobs js) {
     for (int k = 0; k < 8; ++k) sR[zl][l * 8 + k] = s0[k] + s1[k];
     float gs = 0.f;                                      // colsum(g)[n] = fixed-order sum of the per-split rows (threads 128..255: two waves)
     if (jb.W != nullptr && threadIdx.x >= 128) {
-        for (int z2 = threadIdx.x - 128; z2 < js.splits; z2 += 128) gs += jb.brow[(int64_t)z2 * jb.N + n];
+        for (int z2 = threadIdx.x - 128; z2 < jb.nsplit; z2 += 128) gs += jb.brow[(int64_t)z2 * jb.N + n];
         gs = reduce64(gs);
         if ((threadIdx.x & 63) == 0) sDot[2 + ((threadIdx.x - 128) >> 6)] = gs;
     }
@@ -814,7 +815,7 @@ void kasf_launch_proj_finish(hipStream_t s, const void* proj_part, const float* 
     if (nparts < 1 || nred < 0 || nred > 2) return;
     FinJobs fj;
     fj.n = 1; fj.splits = nparts; fj.nred = nred;
-    fj.j[0] = FinJob{(const float*)proj_part, dW, 128, 128, 0, W, bias, ls, db, dls, proj_brow};
+    fj.j[0] = FinJob{(const float*)proj_part, dW, 128, 128, 0, W, bias, ls, db, dls, proj_brow, nparts};
     int first = 128;
     for (int k = 0; k < nred; ++k) {
         fj.r[k] = FinRed{(const bf16*)red[k].part, red[k].out, red[k].nparts, red[k].elems, first};
@@ -840,8 +841,12 @@ void kasf_launch_bf16_reduce(hipStream_t s, int nred, const KasfBf16Reduce* red)
 // Returns false (nothing launched) when the scratch is too small.
 bool kasf_launch_wgrad_jobs(hipStream_t s, int njobs, const void* const* G, const void* const* X, const int* N, float* const* dW, float* const* dbias,
                             int fin_job, const float* fin_W, const float* fin_bias, const float* fin_ls, float* fin_dls, int64_t M, float* partial,
-                            int64_t partial_floats, int nred, const KasfBf16Reduce* red) {
+                            int64_t partial_floats, int nred, const KasfBf16Reduce* red, const void* ext_part, const float* ext_brow, int ext_nparts,
+                            float* ext_dW, float* ext_db) {
+    // ext_* (round 6): the proj job when its tiles G = g_mid^T o and rows colsum(g_mid) were accumulated by the fused attention-block backward (one bf16 tile and one row per
+    // workgroup): it takes no part in the streaming launch and is finished -- fin_W / fin_bias / fin_ls / fin_dls are then ITS layer-scale algebra -- by the same finish launch
     if (njobs < 1 || njobs > 3 || M <= 0 || nred < 0 || nred > 2) return false;
+    if (ext_part != nullptr && (njobs > 2 || fin_job >= 0 || ext_brow == nullptr || ext_nparts < 1 || ext_dW == nullptr || ext_db == nullptr)) return false;
     int tiles = 0;
     for (int j = 0; j < njobs; ++j) tiles += N[j] / 128;
     const int target = kasf_narrow_grid(KASF_NG_WGRAD, 248, M);
@@ -867,10 +872,15 @@ bool kasf_launch_wgrad_jobs(hipStream_t s, int njobs, const void* const* G, cons
         float* brow = dbias[j] != nullptr ? pp + (int64_t)splits * N[j] * 128 : nullptr;      // per-split rows of the bias gradient, behind the job's tiles
         js.j[j] = WgJob{(const bf16*)G[j], (const bf16*)X[j], N[j], 128, pp, dbias[j], brow, N[j], 128, first};
         const bool fin = j == fin_job;
-        fj.j[j] = FinJob{pp, dW[j], N[j], 128, ffirst, fin ? fin_W : nullptr, fin_bias, fin_ls, dbias[j], fin_dls, brow};
+        fj.j[j] = FinJob{pp, dW[j], N[j], 128, ffirst, fin ? fin_W : nullptr, fin_bias, fin_ls, dbias[j], fin_dls, brow, splits};
         first += (N[j] / 128) * splits;
         ffirst += N[j];                                   // one finishing workgroup per output row
         pp += (int64_t)splits * N[j] * 128 + (brow != nullptr ? (int64_t)splits * N[j] : 0);
+    }
+    if (ext_part != nullptr) {
+        fj.j[njobs] = FinJob{(const float*)ext_part, ext_dW, 128, 128, ffirst, fin_W, fin_bias, fin_ls, ext_db, fin_dls, ext_brow, ext_nparts};
+        fj.n = njobs + 1;
+        ffirst += 128;
     }
     const size_t shr = (size_t)WR_ST * 2 * WR_BM * 128 * sizeof(bf16);
     set_smem(k_wgrad_ring_jobs, shr);

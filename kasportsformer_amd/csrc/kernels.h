@@ -220,18 +220,20 @@ bool kasf_launch_attn_block_fwd(hipStream_t s, int bone, const void* x, const vo
                                 const float* lnl_b, const void* Wq, const void* Wkv, const void* Wproj, const float* bproj, const float* ls1, void* q_save,
                                 void* kv_save, void* o_save, void* out, int B, int T, int mode, float* lse_save = nullptr);   // lse_save [M][8]: groups of 33..96 positions in training
 
-// ---- k_attn_bwd_f.hip (bf16, 8 heads, groups of <= 32 positions): the whole backward of an attention / bone block from x (, x_limb) and g_mid in one launch ----
-// Returns the number of per-workgroup partial tiles written (0: nothing launched, nothing registered in the sink).  wpart: 256 x [384 | 128][128] bf16 (self qkv | bone q),
-// wpart_kv: bone, 256 x [256][128]; ppart: 256 x [128][128] (G_proj = g_mid^T o); pbrow: 256 x 128 floats (colsum g_mid): the operands of kasf_launch_proj_finish.
+// ---- k_attn_bwd_f.hip (bf16, 8 heads, groups of <= 32 positions): the backward of an attention / bone block from x (, x_limb) and g_mid in one launch ----
+// Writes the input gradient(s), dq | dk | dv and LN(x) (LN_limb(x_limb)) for the streaming weight-gradient launch, and accumulates G_proj = g_mid^T o.
+// Returns the number of per-workgroup G_proj tiles written (0: nothing launched, nothing registered in the sink).  dq: [M][384] (self) / [M][128] (bone), dkv: bone [M][256];
+// ppart: 256 x [128][128] bf16; pbrow: 256 x 128 floats (colsum g_mid): the ext_* operands of kasf_launch_wgrad_jobs.
 int kasf_launch_attn_block_bwd(hipStream_t s, int bone, const void* x, const void* x_limb, const void* g_mid, const float* ln_g, const float* ln_b, const float* lnl_g,
-                               const float* lnl_b, const void* Wf, const void* Wkvf, const void* WT, const void* WkvT, const void* WprojTs, void* out, void* out_limb,
-                               float* dgamma, float* dbeta, float* dgamma_l, float* dbeta_l, KasfColSink* sink, void* wpart, void* wpart_kv, void* ppart, float* pbrow,
+                               const float* lnl_b, const void* Wf, const void* Wkvf, const void* WT, const void* WprojTs, void* out, void* out_limb, void* dq, void* dkv,
+                               void* xn_a, void* xn_b, float* dgamma, float* dbeta, float* dgamma_l, float* dbeta_l, KasfColSink* sink, void* ppart, float* pbrow,
                                int B, int T, int mode);
 
 // ---- k_gemm.hip: several bf16 weight gradients dW_j[N_j][128] += G_j^T X_j in one streaming launch + one finishing launch ----
 bool kasf_launch_wgrad_jobs(hipStream_t s, int njobs, const void* const* G, const void* const* X, const int* N, float* const* dW, float* const* dbias,
                             int fin_job, const float* fin_W, const float* fin_bias, const float* fin_ls, float* fin_dls, int64_t M, float* partial,
-                            int64_t partial_floats, int nred = 0, const KasfBf16Reduce* red = nullptr);
+                            int64_t partial_floats, int nred = 0, const KasfBf16Reduce* red = nullptr, const void* ext_part = nullptr, const float* ext_brow = nullptr,
+                            int ext_nparts = 0, float* ext_dW = nullptr, float* ext_db = nullptr);
 bool kasf_launch_attn_bwd_fused_do(hipStream_t s, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, const void* g_mid,
                                    const void* WprojTs, void* dq, int64_t lddq, void* dk, void* dv, int64_t lddkv, int B, int Tn, int mode, int form = 0 /* 0: persistent, 1: one group per workgroup (bit-equal comparison form for the tests) */,
                                    const void* o_saved = nullptr, const float* lse = nullptr);   // o_saved [M][128] + lse [M][8] (both from the forward): groups of 33..96 positions take the key-tile-outer kernel

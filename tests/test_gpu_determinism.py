@@ -149,33 +149,61 @@ def test_fused_and_two_kernel_weight_gradients_agree():
 
 @pytest.mark.parametrize("T,B", [(27, 8), (27, 96), (9, 5)])          # 96 clips: several groups per workgroup and the fused MLP / GCN weight-gradient kernels beside it; T = 9: short temporal groups
 def test_fused_attention_backward_agrees_with_the_four_launch_sequence(T, B):
-    """The same step with the attention / bone blocks' backward as ONE launch that re-forms q | k | v | o from x (csrc/k_attn_bwd_f.hip, the default) and as the
-    four-launch sequence of rounds 1-5 (saved q | k | v | o, k_attn_bwd_pers, k_dgrad_r, weight-gradient jobs): the same products with different bf16 rounding
+    """The same step with the attention / bone blocks' backward as ONE launch that re-forms q | k | v | o from x (csrc/k_attn_bwd_f.hip, opt-in: kasf_set_fused_attn_bwd)
+    and as the default four-launch sequence (saved q | k | v | o, k_attn_bwd_pers, k_dgrad_r, weight-gradient jobs): the same products with different bf16 rounding
     points, so not the same bits -- but the forward is untouched (it only stops saving), every gradient agrees far inside the bf16 bars of the oracle tests, both
     forms reproduce themselves bit for bit, and the workspace of the fused form has no q | k | v | o slots."""
     from kasportsformer_amd import _lib
     lib = _lib.load()
-    assert lib.kasf_get_fused_attn_bwd() == 1
-    a = _three_runs("bf16", T, B)
-    assert torch.equal(a[0][2], a[1][2]) and torch.equal(a[0][2], a[2][2])
+    assert lib.kasf_get_fused_attn_bwd() == 0
+    b = _three_runs("bf16", T, B)
+    assert torch.equal(b[0][2], b[1][2]) and torch.equal(b[0][2], b[2][2])
     _, model = make_pair(3, T, "bf16")
-    ws_fused = lib.kasf_workspace_bytes(model._device_handle(), B, 1)
-    lib.kasf_set_fused_attn_bwd(0)
+    ws_plain = lib.kasf_workspace_bytes(model._device_handle(), B, 1)
+    lib.kasf_set_fused_attn_bwd(1)
     try:
-        assert lib.kasf_get_fused_attn_bwd() == 0
-        ws_plain = lib.kasf_workspace_bytes(model._device_handle(), B, 1)
-        runs = _three_runs("bf16", T, B)
+        assert lib.kasf_get_fused_attn_bwd() == 1
+        ws_fused = lib.kasf_workspace_bytes(model._device_handle(), B, 1)
+        a = _three_runs("bf16", T, B)
     finally:
         lib.kasf_set_fused_attn_bwd(-1)
-    assert lib.kasf_get_fused_attn_bwd() == 1
+    assert lib.kasf_get_fused_attn_bwd() == 0
     M = B * T * 17
     assert ws_plain - ws_fused >= 3 * 4 * M * 512 * 2, (ws_plain, ws_fused)      # 4 blocks per layer x (384 + 128) bf16 elements per token
-    b = runs[0]
-    assert torch.equal(runs[0][2], runs[1][2]) and torch.equal(runs[0][2], runs[2][2])
-    assert torch.equal(a[0][0], b[0]) and torch.equal(a[0][3], b[3])                          # predictions and BatchNorm statistics: the forward is the same forward
-    ga, gb = a[0][2].double(), b[2].double()
-    assert not torch.equal(a[0][2], b[2]), "the switch did not change the path"
+    assert torch.equal(a[0][2], a[1][2]) and torch.equal(a[0][2], a[2][2])
+    assert torch.equal(a[0][0], b[0][0]) and torch.equal(a[0][3], b[0][3])                    # predictions and BatchNorm statistics: the forward is the same forward
+    ga, gb = a[0][2].double(), b[0][2].double()
+    assert not torch.equal(a[0][2], b[0][2]), "the switch did not change the path"
     cos = float((ga * gb).sum() / (ga.norm() * gb.norm()))
     rel = float((ga - gb).abs().max() / gb.abs().max())
     print(f"[fused attention backward vs four launches, T = {T}, B = {B}] cosine {cos:.8f}, max |diff| / max |g| {rel:.3e}")
     assert cos > 0.9999 and rel < 2e-2, (cos, rel)
+
+
+@pytest.mark.parametrize("L,T,B", [(2, 27, 2), (1, 27, 101), (1, 9, 3)])
+def test_fused_attention_backward_matches_oracle(L, T, B):
+    """The opt-in fused attention-block backward against the CPU oracle, at the bars of tests/test_gpu_model.py::test_backward_matches_oracle."""
+    from kasportsformer_amd import _lib
+    from tests.gpu_util import compare_grads
+    lib = _lib.load()
+    lib.kasf_set_fused_attn_bwd(1)
+    try:
+        oracle, model = make_pair(L, T, "bf16")
+        x, y = O.synthetic_clips(B, T)
+        oracle.train()
+        loss_ref, _ = O.loss_total(oracle(x), y)
+        loss_ref.backward()
+        model.train()
+        loss, _ = O.loss_total(model(x.cuda()), y.cuda())
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        lib.kasf_set_fused_attn_bwd(-1)
+    assert abs(loss.item() - loss_ref.item()) < 5e-2 * max(1.0, abs(loss_ref.item()))
+    rep = compare_grads(model, oracle, "bf16", floor_rel=0.05)
+    assert not rep["none_mismatch"], rep["none_mismatch"]
+    print(f"[fused attention backward vs oracle, L={L} T={T} B={B}] gradient cosine {rep['cosine']:.7f}, worst per-tensor error {rep['worst']:.3e} ({rep['worst_name']})")
+    assert rep["cosine"] > 0.999 and rep["pooled_small_cosine"] > 0.999, (rep["cosine"], rep["pooled_small_cosine"])
+    tol = 0.04 if B * T >= 900 else 0.35
+    bad = sorted(((v, k) for k, v in rep["errors"].items() if not v < tol), reverse=True)
+    assert not bad, f"{len(bad)} gradients above {tol}; worst (err, name): {bad[:12]}"
