@@ -104,13 +104,13 @@ PROFILES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
 
 
 def _profile(name):
-    """Newest committed round of a profile file (profiles/r5_<name>, else r4_ / r3_ / r2_<name>): counters cannot be read from inside the process, so the bench
-    line QUOTES the committed summaries of separate rocprofv3 runs of the same launches (tools/refresh_profiles_r5.sh) and says so (`*_source`)."""
-    for rnd in ("r5", "r4", "r3", "r2"):
+    """Newest committed round of a profile file (profiles/r6_<name>, else r5_ / r4_ / r3_ / r2_<name>): counters cannot be read from inside the process, so the bench
+    line QUOTES the committed summaries of separate rocprofv3 runs of the same launches (tools/refresh_profiles_r6.sh) and says so (`*_source`)."""
+    for rnd in ("r6", "r5", "r4", "r3", "r2"):
         f = os.path.join(PROFILES, f"{rnd}_{name}")
         if os.path.exists(f):
             return f
-    return os.path.join(PROFILES, f"r5_{name}")
+    return os.path.join(PROFILES, f"r6_{name}")
 
 
 STALE = []           # quoted profile files whose stamp is not this tree's (tools/stamp.py): reported as "profile_stale" and NOT quoted
@@ -131,6 +131,7 @@ def fresh(path):
     return ok
 
 
+SQ_FILE = _profile("mlp_sq_counters.json")             # tools/pmc_kernel.sh (six --pmc passes over tools/mlp_bench.py), per-launch means + mfma_busy
 TRAFFIC_FILE = _profile("pmc_traffic.json")            # tools/pmc_traffic.py (two --pmc passes over tools/mlp_bench.py)
 IN_STEP_STATS = _profile("train_kernel_stats.csv")     # rocprofv3 --kernel-trace --stats of tools/train_once.py 27 256 (three streams overlap)
 ISOLATED_STATS = _profile("single_stream_kernel_stats.csv")   # the same steps with the three branches on ONE stream (tools/prof27.sh): every launch alone on the chip
@@ -245,7 +246,7 @@ def workload_name(args, world, strong):
 
 def parity_summary():
     """What the parity tests OBSERVED on the shipped kernels, read from the files tests/test_gpu_model.py::test_full_depth_26_layers_against_oracle writes
-    (gpurun_out/r5_parity_26layers_<mode>.json, committed as profiles/...): nothing in this string is typed in."""
+    (gpurun_out/r6_parity_26layers_<mode>.json, committed as profiles/...): nothing in this string is typed in."""
     out = {}
     for cd in ("fp32", "bf16"):
         f = _profile(f"parity_26layers_{cd}.json")
@@ -619,6 +620,14 @@ def main():
                                                                            "frac": ks[dom]["algorithmic_flop"] / t_full / 1e12 / PEAK_BF16_TFLOPS, "cus": 256,
                                                                            "source": "committed file profiles/" + os.path.basename(ISOLATED_FULL_STATS) + " (the same with KASF_NARROW_PCTS=100,100,100,100,100,100,100); "
                                                                                      "the event-timed figure above is a back-to-back loop of this chain alone, where the same two kernels take longer per launch"}
+            if headline and fresh(SQ_FILE):            # matrix-pipe busy fraction and LDS bank conflicts of the dominant kernel's launches
+                sq = json.load(open(SQ_FILE))
+                part = {k: v for k, v in sq.items() if isinstance(v, dict) and any(k.startswith(p) for p in TRAFFIC_PARTS.get(dom, (dom,)))}
+                if part:
+                    out["roofline"]["mfma_busy"] = {k: v.get("mfma_busy") for k, v in part.items()}
+                    out["roofline"]["lds_bank_conflict_frac"] = {k: v.get("lds_bank_conflict_frac") for k, v in part.items()}
+                    out["roofline"]["mfma_busy_source"] = ("committed file profiles/" + os.path.basename(SQ_FILE) + " (six rocprofv3 --pmc passes over tools/mlp_bench.py, tools/pmc_kernel.sh): "
+                                                           "SQ_VALU_MFMA_BUSY_CYCLES / (32 x SQ_CYCLES), the share of the launch during which a SIMD's matrix pipe is busy, recomputed Z included")
             if headline and fresh(STEP_TRAFFIC_FILE):
                 out["step_hbm_GB"] = json.load(open(STEP_TRAFFIC_FILE))["hbm_GB_per_step"]
                 out["step_hbm_GB_source"] = "committed file profiles/" + os.path.basename(STEP_TRAFFIC_FILE)

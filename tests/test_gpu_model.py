@@ -559,7 +559,7 @@ def _full_depth_sample(cd, seed, salt):
 
 
 def _write_parity_report(cd, samples):
-    """The observed figures go to gpurun_out/r5_parity_26layers_<cd>.json (merged back from the GPU box; the copy committed under profiles/ is what
+    """The observed figures go to gpurun_out/r6_parity_26layers_<cd>.json (merged back from the GPU box; the copy committed under profiles/ is what
     bench.py quotes in its `parity` field instead of a typed-in string)."""
     import json, os, statistics
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
@@ -578,7 +578,7 @@ def _write_parity_report(cd, samples):
         rep["stamp"] = stamp.stamp()             # which build these figures were observed on (bench.py quotes the file only if it matches the library it times)
     finally:
         sys.path.pop(0)
-    with open(os.path.join(out, f"r5_parity_26layers_{cd}.json"), "w") as f:
+    with open(os.path.join(out, f"r6_parity_26layers_{cd}.json"), "w") as f:
         json.dump(rep, f, indent=1)
     return rep
 
