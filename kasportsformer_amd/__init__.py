@@ -15,7 +15,8 @@ Public surface mirrors the reference's interface for this path:
   slice_source, split_clips,            data/reader/sp_reader.py:25-169,205-249, data/reader/wp_reader.py:25-135,159-199 (offline clip slicing)
   mysplit_clips, resample
 """
-from .model import KASportsFormer, load_model, set_single_stream, is_single_stream, set_deterministic, is_deterministic
+from .model import (KASportsFormer, load_model, set_single_stream, is_single_stream, set_deterministic, is_deterministic, set_fused_attention_backward,
+                    is_fused_attention_backward)
 from .functional import loss3
 from .optim import FusedAdamW
 from .parallel import DataParallel
@@ -27,7 +28,7 @@ from .evaluate import joint_flip, predict_flip_tta, clip_metrics, Evaluator, eva
 from .synthetic import synthetic_clips, synthetic_test_extras, teacher_labels, teacher_clips
 from .slicing import slice_source, split_clips, mysplit_clips, resample
 
-__all__ = ["KASportsFormer", "load_model", "set_single_stream", "is_single_stream", "set_deterministic", "is_deterministic", "loss3", "FusedAdamW", "DataParallel", "joint_flip", "predict_flip_tta", "clip_metrics", "Evaluator",
+__all__ = ["KASportsFormer", "load_model", "set_single_stream", "is_single_stream", "set_deterministic", "is_deterministic", "set_fused_attention_backward", "is_fused_attention_backward", "loss3", "FusedAdamW", "DataParallel", "joint_flip", "predict_flip_tta", "clip_metrics", "Evaluator",
            "evaluate_one_epoch", "PackedClips", "DeviceClipLoader", "pack_clip_directory", "read_clip_file", "shard_indices",
            "checkpoint_save", "checkpoint_load", "strip_module_prefix", "adamw_state_dict", "load_adamw_state_dict", "warmup_lr", "apply_warmup", "ReduceLROnPlateau", "train_one_epoch",
            "synthetic_clips", "synthetic_test_extras", "teacher_labels", "teacher_clips", "slice_source", "split_clips", "mysplit_clips", "resample"]
