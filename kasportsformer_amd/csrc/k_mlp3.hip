@@ -21,6 +21,11 @@
 #include "tile_ops.h"
 #include <type_traits>
 
+#ifdef KASF_LSTAMP
+constexpr unsigned LSTAMP_CAP = 16384;
+__device__ long long g_lstamp[LSTAMP_CAP];
+__device__ unsigned g_lstamp_n;
+#endif
 #ifdef KASF_PROBE_TIMERS
 __device__ long long g_prof[32];
 #define TMARK(k) do { const long long _n = clock64(); if (lane == 0 && blockIdx.x == 7 && (w & 3) == 0) g_prof[k] += _n - _t; _t = _n; } while (0)   // wave 0 (producer) and wave 4 (consumer) of one workgroup only: no lost updates
@@ -311,6 +316,16 @@ __global__ __launch_bounds__(S_THR) void k_mlp_bwd_s(const bf16* __restrict__ XN
                                                      const float* __restrict__ b1, const bf16* __restrict__ W2ts, const bf16* __restrict__ W1t,
                                                      bf16* __restrict__ dApart, bf16* __restrict__ dW1part, bf16* __restrict__ dW2part,
                                                      float* __restrict__ db1, float* __restrict__ db1_rows, int64_t M, int tiles_per_range) {
+#ifdef KASF_LSTAMP                                       // un-profiled timeline of the MLP-backward launches (tools/mlp_launch_stamps.py): first and last workgroup, start / end, constant 100 MHz clock
+    unsigned ls_slot = 0;
+    const bool ls_on = (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && threadIdx.x == 0;
+    if (ls_on) {
+        ls_slot = atomicAdd(&g_lstamp_n, 4u) & (LSTAMP_CAP - 1);
+        g_lstamp[ls_slot] = (long long)(size_t)W1;
+        g_lstamp[ls_slot + 1] = (long long)blockIdx.x;
+        g_lstamp[ls_slot + 2] = wall_clock64();
+    }
+#endif
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* sA = reinterpret_cast<bf16*>(smem);            // [RING][32][128] LN(x) ring
     bf16* sG = sA + BW_RING * TL;                        // [RING][32][128] upstream gradient ring
@@ -632,6 +647,9 @@ __global__ __launch_bounds__(S_THR) void k_mlp_bwd_s(const bf16* __restrict__ XN
             *reinterpret_cast<f32x4*>(p2 + (int64_t)rr * 512 + ch * 8) = *reinterpret_cast<const f32x4*>(sW2 + rr * 128 + ch * 8);
         }
     }
+#ifdef KASF_LSTAMP
+    if (ls_on) g_lstamp[ls_slot + 3] = wall_clock64();
+#endif
 }
 
 }  // namespace
@@ -649,6 +667,17 @@ extern "C" void kasf_debug_read_prof(long long* dst, int reset) {
     hipDeviceSynchronize();
     hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_prof), sizeof(long long) * 32);
     if (reset) { long long z[32] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)); }
+}
+#endif
+
+#ifdef KASF_LSTAMP
+extern "C" int kasf_debug_read_lstamps(long long* dst, int reset) {      // dst: LSTAMP_CAP entries; returns the number of entries written since the last reset
+    (void)hipDeviceSynchronize();
+    unsigned n = 0;
+    (void)hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_lstamp_n), sizeof(n));
+    (void)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_lstamp), sizeof(long long) * LSTAMP_CAP);
+    if (reset) { const unsigned z = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lstamp_n), &z, sizeof(z)); }
+    return (int)n;
 }
 #endif
 
