@@ -58,15 +58,16 @@ static std::atomic<int64_t> g_wg_fuse_min_tokens{KASF_WG_FUSE_MIN_TOKENS};      
 // nothing for these blocks and the workspace has no qkv / kv / o slots (T = 27, B = 256: 26.9 -> 14.4 GB).  Parity-green, bit-reproducible -- and SLOWER than the four-launch
 // sequence of rounds 1-5, which therefore stays the default (3,926 against 4,620 clips/s; the phase timers say why).  Forward and backward of one
 // step must run under the same setting.
-static std::atomic<int> g_fused_attn_bwd{-1};
-static bool fused_attn_bwd_on() {
+static std::atomic<int> g_fused_attn_bwd{-1};            // bit mask: 1 self-attention spatial, 2 self-attention temporal, 4 bone spatial, 8 bone temporal (the setter's 1 = all four = 15)
+static int fused_attn_bwd_mask() {
     int v = g_fused_attn_bwd.load(std::memory_order_relaxed);
-    if (v < 0) { const char* e = getenv("KASF_ATTN_BWD_FUSED"); v = (e != nullptr && *e == '1') ? 1 : 0; g_fused_attn_bwd.store(v, std::memory_order_relaxed); }
-    return v != 0;
+    if (v < 0) { const char* e = getenv("KASF_ATTN_BWD_FUSED"); v = e != nullptr ? atoi(e) : 0; if (v == 1) v = 15; if (v < 0 || v > 15) v = 0; g_fused_attn_bwd.store(v, std::memory_order_relaxed); }
+    return v;
 }
 static bool fused_attn_bwd(const kasf_config& cfg, int kind, int mode) {
     const int Lg = mode == 0 ? 17 : cfg.n_frames;
-    return kind != 1 /* KIND_GRAPH */ && cfg.dtype == KASF_BF16 && cfg.num_heads == 8 && Lg <= 32 && fused_attn_bwd_on();
+    if (kind == 1 /* KIND_GRAPH */ || cfg.dtype != KASF_BF16 || cfg.num_heads != 8 || Lg > 32) return false;
+    return (fused_attn_bwd_mask() >> ((kind == 2 /* KIND_BONE */ ? 2 : 0) + (mode ? 1 : 0))) & 1;
 }
 constexpr int64_t WG_JOBS_FLOATS = 248 * 128 * 128 + 248 * 128 + 4096;   // the proj job alone: 248 splits of one 128 x 128 tile + their bias rows
 constexpr int64_t WG_BF16_BYTES = (int64_t)256 * 384 * 128 * 2 + (int64_t)256 * 128 * 128 * 2 + 256 * 128 * 4;         // <= 256 bf16 partial tiles of the block's fused data + weight gradient launches (qkv: 384 rows; q + kv: 128 + 256)
@@ -620,8 +621,8 @@ int32_t kasf_get_single_stream(void) { return single_stream() ? 1 : 0; }
 // the round-3 names: the setting never was about determinism (gradients are bit-reproducible either way)
 void kasf_set_fused_wgrad_min_tokens(int64_t tokens) { g_wg_fuse_min_tokens.store(tokens < 0 ? (int64_t)KASF_WG_FUSE_MIN_TOKENS : tokens, std::memory_order_relaxed); }
 int64_t kasf_get_fused_wgrad_min_tokens(void) { return g_wg_fuse_min_tokens.load(std::memory_order_relaxed); }
-void kasf_set_fused_attn_bwd(int32_t on) { g_fused_attn_bwd.store(on < 0 ? -1 : (on ? 1 : 0), std::memory_order_relaxed); }
-int32_t kasf_get_fused_attn_bwd(void) { return fused_attn_bwd_on() ? 1 : 0; }
+void kasf_set_fused_attn_bwd(int32_t on) { g_fused_attn_bwd.store(on < 0 ? -1 : (on == 1 ? 15 : (on > 15 ? 0 : on)), std::memory_order_relaxed); }
+int32_t kasf_get_fused_attn_bwd(void) { return fused_attn_bwd_mask(); }
 void kasf_set_deterministic(int32_t on) { kasf_set_single_stream(on); }
 int32_t kasf_get_deterministic(void) { return kasf_get_single_stream(); }
 int kasf_version(void) { return 8; }

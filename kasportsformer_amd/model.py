@@ -416,12 +416,12 @@ def is_single_stream() -> bool:
 set_deterministic, is_deterministic = set_single_stream, is_single_stream      # the round-3 names
 
 
-def set_fused_attention_backward(on: bool = True) -> None:
+def set_fused_attention_backward(on=True) -> None:
     """Process-wide, opt-in (round 6; C-ABI: ``kasf_set_fused_attn_bwd``): run the backward of every attention / bone block with groups of at most 32 positions (bf16,
     8 heads) as one launch that re-forms q | k | v and the attention output from the block input -- the training forward then saves none of them (workspace at T = 27,
     B = 256: 26.9 -> 14.4 GB) -- followed by one streaming weight-gradient launch.  Same results at bf16 rounding level, bit-reproducible, 15 % slower per training
     step than the default four-launch sequence on MI355X.  Change it only between steps: the forward and the backward of one step must agree."""
-    _lib.load().kasf_set_fused_attn_bwd(1 if on else 0)
+    _lib.load().kasf_set_fused_attn_bwd(int(on))          # True = all block kinds; an int selects kinds by bit (1 self spatial, 2 self temporal, 4 bone spatial, 8 bone temporal)
 
 
 def is_fused_attention_backward() -> bool:

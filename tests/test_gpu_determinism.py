@@ -162,7 +162,7 @@ def test_fused_attention_backward_agrees_with_the_four_launch_sequence(T, B):
     ws_plain = lib.kasf_workspace_bytes(model._device_handle(), B, 1)
     lib.kasf_set_fused_attn_bwd(1)
     try:
-        assert lib.kasf_get_fused_attn_bwd() == 1
+        assert lib.kasf_get_fused_attn_bwd() == 15             # 1 = all four block kinds (a bit mask: 1 self spatial, 2 self temporal, 4 bone spatial, 8 bone temporal)
         ws_fused = lib.kasf_workspace_bytes(model._device_handle(), B, 1)
         a = _three_runs("bf16", T, B)
     finally:
