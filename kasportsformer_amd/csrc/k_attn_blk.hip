@@ -20,6 +20,7 @@ namespace {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 constexpr int AB_THR = 512, AB_TILE = 32 * 128;
+constexpr int RP3_PAD = 16;                        // bf16 elements between the heads' q | k | v tile images of k_attn_blk_fwd_rp3
 
 __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
@@ -571,13 +572,14 @@ __global__ __launch_bounds__(AB_THR, BONE ? KASF_RP_BONE_WAVES : 4) void k_attn_
 // ---------------------------------------------------------------------------------------------------------------
 template <bool BONE>
 __global__ __launch_bounds__(AB_THR, 2) void k_attn_blk_fwd_rp3(const AttnBlkArgs a) {
-    constexpr int NKT = 3, R = 32 * NKT, RT = R * 128, HT = R * 16;
+    constexpr int NKT = 3, R = 32 * NKT, RT = R * 128, HT = R * 16, WS = 3 * HT + RP3_PAD;      // WS: one wave's q | k | v tiles + 32 bytes (the 8 heads' images 32 bytes apart
+                                                                                                   // modulo the 256 bytes of a read cycle: the row copy-out reads 16 lanes = 8 heads x 2 halves)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* sX = reinterpret_cast<bf16*>(smem);           // [96][128] raw x (the residual's operand)
     bf16* sA = sX + RT;                                 // [96][128] LN(x), then (bone) LN_limb(x_limb), then x_mid
     bf16* sO = sA + RT;                                 // [96][128] attention output of the 8 heads
     bf16* sHead = sO + RT;                              // [8 waves][q | k | v][96][16] wave-private operand tiles
-    float* sLn = reinterpret_cast<float*>(sHead + 8 * 3 * HT);       // [6][128]
+    float* sLn = reinterpret_cast<float*>(sHead + 8 * WS);           // [6][128]
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4, sub = lane & 15, rl = threadIdx.x >> 4;
     const int r32 = lane & 31, hh = lane >> 5;
     const int L = a.L;
@@ -586,7 +588,7 @@ __global__ __launch_bounds__(AB_THR, 2) void k_attn_blk_fwd_rp3(const AttnBlkArg
     int ng = a.groups - g0;
     if (ng > per) ng = per;
     if (ng <= 0) return;
-    bf16* sQh = sHead + w * 3 * HT;
+    bf16* sQh = sHead + w * WS;
     bf16* sKh = sQh + HT;
     bf16* sVh = sKh + HT;
     bf16x8 wq[3][4], wp[4];
@@ -708,26 +710,6 @@ __global__ __launch_bounds__(AB_THR, 2) void k_attn_blk_fwd_rp3(const AttnBlkArg
         }
         lds_fence();
         RT(2);
-        if (a.Qs != nullptr) {   // training: the backward pass reads q | k | v
-#pragma unroll
-            for (int jb = 0; jb < NKT; ++jb) {
-                const int pos = 32 * jb + r32;
-                if (pos < L) {
-                    const unsigned tok = (unsigned)(base_of(G) + pos * stride);
-                    const bf16x8 qv = *reinterpret_cast<const bf16x8*>(sQh + pos * 16 + 8 * hh), kv = *reinterpret_cast<const bf16x8*>(sKh + pos * 16 + 8 * hh),
-                                 vv = *reinterpret_cast<const bf16x8*>(sVh + pos * 16 + 8 * hh);
-                    if (BONE) {
-                        *reinterpret_cast<bf16x8*>(a.Qs + (size_t)(tok * 128u + 16 * w + 8 * hh)) = qv;
-                        *reinterpret_cast<bf16x8*>(a.KVs + (size_t)(tok * 256u + 16 * w + 8 * hh)) = kv;
-                        *reinterpret_cast<bf16x8*>(a.KVs + (size_t)(tok * 256u + 128 + 16 * w + 8 * hh)) = vv;
-                    } else {
-                        *reinterpret_cast<bf16x8*>(a.Qs + (size_t)(tok * 384u + 16 * w + 8 * hh)) = qv;
-                        *reinterpret_cast<bf16x8*>(a.Qs + (size_t)(tok * 384u + 128 + 16 * w + 8 * hh)) = kv;
-                        *reinterpret_cast<bf16x8*>(a.Qs + (size_t)(tok * 384u + 256 + 16 * w + 8 * hh)) = vv;
-                    }
-                }
-            }
-        }
         RT(3);
         {   // ---- attention core of head w (k_attn_fwd_mfma<3>) ----
             bf16x8 kf[NKT];
@@ -815,6 +797,37 @@ __global__ __launch_bounds__(AB_THR, 2) void k_attn_blk_fwd_rp3(const AttnBlkArg
                 if (a.Qs != nullptr) *reinterpret_cast<f32x4*>(a.Os + (size_t)(tok * 128u + sub * 8)) = *reinterpret_cast<const f32x4*>(sO + co);
             }
         }
+        if (a.Qs != nullptr) {   // training: the backward pass reads q | k | v.  Round 6: whole rows, thread = (position, 16-byte chunk), out of the heads' tiles (complete
+            // since B2, untouched until the next group's projections) -- rounds 2-5 had every wave store its head's 32-byte slice of each row right after the projections:
+            // 32 separate requests per store instruction, 24 partial writes per 768-byte row.
+            if (BONE) {          // q rows (256 bytes) and k | v rows (512 bytes) live in two arrays
+#pragma unroll
+                for (int j = 0; j < NKT; ++j) {
+                    const int row = rl + 32 * j;
+                    if (row < L) {
+                        const unsigned tok = (unsigned)(base_of(G) + row * stride);
+                        *reinterpret_cast<f32x4*>(a.Qs + (size_t)(tok * 128u + sub * 8)) = *reinterpret_cast<const f32x4*>(sHead + (sub >> 1) * WS + row * 16 + 8 * (sub & 1));
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 2 * NKT; ++k) {
+                    const int idx = (int)threadIdx.x + AB_THR * k, row = idx >> 5, c = idx & 31, part = 1 + (c >> 4), ch = c & 15;
+                    if (row < L) {
+                        const unsigned tok = (unsigned)(base_of(G) + row * stride);
+                        *reinterpret_cast<f32x4*>(a.KVs + (size_t)(tok * 256u + c * 8)) = *reinterpret_cast<const f32x4*>(sHead + (ch >> 1) * WS + part * HT + row * 16 + 8 * (ch & 1));
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < R * 48 / AB_THR; ++k) {
+                    const int idx = (int)threadIdx.x + AB_THR * k, row = idx / 48, c = idx - row * 48, part = c >> 4, ch = c & 15;
+                    if (row < L) {
+                        const unsigned tok = (unsigned)(base_of(G) + row * stride);
+                        *reinterpret_cast<f32x4*>(a.Qs + (size_t)(tok * 384u + c * 8)) = *reinterpret_cast<const f32x4*>(sHead + (ch >> 1) * WS + part * HT + row * 16 + 8 * (ch & 1));
+                    }
+                }
+            }
+        }
         __syncthreads();                                 // B4: the next group's LayerNorm overwrites sA
         RT(7);
     }
@@ -839,7 +852,7 @@ bool kasf_launch_attn_block_fwd(hipStream_t s, int bone, const void* x, const vo
     if (a.groups <= 0) return true;
     if (L > 32) {                                       // three-tile groups: one workgroup per CU
         const unsigned grid = (unsigned)(a.groups < 256 ? a.groups : 256);
-        const size_t sh = (size_t)3 * 96 * 128 * 2 + (size_t)8 * 3 * 96 * 16 * 2 + 6 * 128 * 4;
+        const size_t sh = (size_t)3 * 96 * 128 * 2 + (size_t)8 * (3 * 96 * 16 + RP3_PAD) * 2 + 6 * 128 * 4;
         if (bone) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_blk_fwd_rp3<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
             hipLaunchKernelGGL(k_attn_blk_fwd_rp3<true>, dim3(grid), dim3(AB_THR), sh, s, a);

@@ -441,7 +441,7 @@ __global__ __launch_bounds__(FDO ? 512 : 256, 2) void k_attn_bwd_long(const bf16
 //   * the group's rows (q | k | v, o, g_mid, lse) come in cooperatively, whole rows per wave load, and reach the heads' tiles through LDS; dq / dk / dv
 //     leave as 16-byte stores (see the prologue's comment: the first form, one wave per head loading its 32-byte slice of each row, was bound by the
 //     number of memory requests, not by anything the CUs did: 167 -> 142 us).
-// One wave per (group, head), the 8 heads of a group per workgroup (the group's g_mid rows are staged once for the d_o products), one workgroup per CU.
+// One wave per (group, head); rounds 3-5: the 8 heads of a group per workgroup (147 KB of LDS: one workgroup per CU); round 6: 4 heads per workgroup, two workgroups per CU.
 // ---------------------------------------------------------------------------------------------------------------
 // tr_frag32 for a block whose rows are LD elements apart (LD = 36: the 72-byte row stride spreads the 32 row stores of a block over all banks;
 // with 64-byte rows every fourth lane hit the same bank)
@@ -456,87 +456,94 @@ __device__ __forceinline__ bf16x8 tr_frag32s(const bf16* s_tile, int ks) {
 }
 
 constexpr int KT_LD = 36;                                         // row stride of a dS block
+constexpr int KT_HPW = 4;                                         // heads per workgroup
+#ifndef KT_PAD
+#define KT_PAD 32
+#endif
 // NR2: score registers of the LAST query tile that can hold a live query (register g holds queries (g & 3) + 8 (g >> 2) + 4 hh of the tile: 9 when
 // the tile has at most 17 positions -- T = 81 = 32 + 32 + 17 --, else 16); the vector work and block stores of the dead registers are skipped.
 template <int NKT, int NR2>
-__global__ __launch_bounds__(512, 2) void k_attn_bwd_kt(const bf16* __restrict__ Q, int64_t ldq, const bf16* __restrict__ K, const bf16* __restrict__ V,
+__global__ __launch_bounds__(256, 2) void k_attn_bwd_kt(const bf16* __restrict__ Q, int64_t ldq, const bf16* __restrict__ K, const bf16* __restrict__ V,
                                                         int64_t ldkv, const bf16* __restrict__ O, const float* __restrict__ LSE, bf16* __restrict__ dQ,
                                                         int64_t lddq, bf16* __restrict__ dK, bf16* __restrict__ dV, int64_t lddkv, int L, int Tn, int mode,
-                                                        const bf16* __restrict__ Gmid, const bf16* __restrict__ Wp) {
+                                                        const bf16* __restrict__ Gmid, const bf16* __restrict__ Wp, int groups) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TILE = NKT * 32 * 16;                           // [positions][16] operand tile (bf16 elements)
     constexpr int BLK = 32 * KT_LD;                               // one dS block
-    constexpr int WAVE_BYTES = 4 * TILE * 2 + BLK * 2 + 2 * NKT * 32 * 4;         // K, Q, d_o, V tiles; the dS block; lse, delta
+    constexpr int WAVE_BYTES = 3 * TILE * 2 + BLK * 2 + 2 * NKT * 32 * 4 + KT_PAD;         // K, Q, d_o tiles; the dS block; lse, delta; 32 bytes that put the four heads'
+    constexpr int VTILE = TILE + KT_PAD / 2;                      //   images 32 bytes apart modulo the 128 bytes of a write cycle: the 8 lanes of one have 8 places to go
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
-    const int G = blockIdx.x, h = wave;
+    // Round 6: FOUR heads of a group per workgroup (rounds 3-5: all eight; 147 KB of LDS = one workgroup per CU, nothing ran under the group's row loads and gradient
+    // stores: 123 + 74 KB per group = ~15 k of its ~38 k cycles at the CU's share of HBM).  73.7 KB per workgroup admits two per CU at different phases of their
+    // groups; blocks b and b + 8 -- the same XCD and neighbours in dispatch order -- are the two head halves of one group, so the g_mid rows both need (all 128
+    // columns: d_o of a head is a product over the whole row) meet in that XCD's L2.
+    const int G = ((int)blockIdx.x >> 4) * 8 + ((int)blockIdx.x & 7), hb = KT_HPW * (((int)blockIdx.x >> 3) & 1), h = hb + wave;
+    if (G >= groups) return;                                      // (workgroup-uniform: groups is rounded up to a multiple of 8 by the launcher)
+#ifdef KT_PROF
+    long long kt_t[8]; int kt_n = 0;
+#define KTQ() do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); kt_t[kt_n++] = clock64(); } while (0)
+#define KTQ0() do { kt_t[kt_n++] = clock64(); } while (0)
+#else
+#define KTQ() do {} while (0)
+#define KTQ0() do {} while (0)
+#endif
+    KTQ0();
     bf16* sK = reinterpret_cast<bf16*>(smem + wave * WAVE_BYTES);
     bf16* sQ = sK + TILE;
     bf16* sD = sQ + TILE;
-    bf16* sV = sD + TILE;
-    bf16* sdS = sV + TILE;                                        // [32 keys][KT_LD]
+    bf16* sdS = sD + TILE;                                        // [32 keys][KT_LD]
     float* sLse = reinterpret_cast<float*>(sdS + BLK);            // [32 NKT]  -lse
     float* sDel = sLse + NKT * 32;                                //           -delta
-    bf16* sG = reinterpret_cast<bf16*>(smem + 8 * WAVE_BYTES);    // [32 NKT][128] g_mid rows of the group (swizzled tile; rows past L zero)
-    auto wave_tile = [&](int hd, int which) { return reinterpret_cast<bf16*>(smem + hd * WAVE_BYTES) + which * TILE; };          // 0 K, 1 Q, 2 d_o, 3 V
-    auto wave_stat = [&](int hd, int which) { return reinterpret_cast<float*>(smem + hd * WAVE_BYTES + 4 * TILE * 2 + BLK * 2) + which * NKT * 32; };
-    // ---- the group's rows come in COOPERATIVELY: thread = (position, 16-byte chunk of the row), so a wave load covers whole 256-byte (q | k | v: 768-byte) rows.
-    // One wave per head loading its own 32-byte slice of each of 32 rows made every load and store 32-64 separate requests, and the launch was bound by
-    // exactly that: 55 us of its 167 for loads + stores alone, the same total whatever the occupancy, the phase of the co-resident workgroup or the
+    bf16* sG = reinterpret_cast<bf16*>(smem + KT_HPW * WAVE_BYTES);     // [32 NKT][128] g_mid rows of the group (swizzled tile; rows past L zero); once the d_o products
+    bf16* sV = sG + wave * VTILE;                                 //   have read them, the heads' V tiles (4 x 3 KB of its 24)
+    auto wave_tile = [&](int hd, int which) { return reinterpret_cast<bf16*>(smem + hd * WAVE_BYTES) + which * TILE; };          // 0 K, 1 Q, 2 d_o
+    auto wave_stat = [&](int hd, int which) { return reinterpret_cast<float*>(smem + hd * WAVE_BYTES + 3 * TILE * 2 + BLK * 2) + which * NKT * 32; };
+    // ---- the group's rows come in COOPERATIVELY: thread = (position, 16-byte chunk of the row), so a wave load covers whole 64-byte (this half's heads of q, k, v and
+    // o) or 256-byte (g_mid) row pieces.  One wave per head loading its own 32-byte slice of each of 32 rows made every load and store 32-64 separate requests, and the
+    // launch was bound by exactly that: 55 us of its 167 for loads + stores alone, the same total whatever the occupancy, the phase of the co-resident workgroup or the
     // number of vector instructions (in-kernel stamps: 20-30 k of a workgroup's 35-45 k cycles went by before its first loads had landed).
     // All loads are issued before anything waits; they are distributed to the heads' tiles through LDS.
-    constexpr int ROWS = NKT * 32, NQKV = ROWS * 48 / 512, NROW = ROWS * 16 / 512;                 // 9 and 3 chunks per thread
-    bf16x8 cq[NQKV], co[NROW], cg[NROW];
+    constexpr int ROWS = NKT * 32, NQKV = ROWS * 24 / 256, NRO = ROWS * 8 / 256, NRG = ROWS * 16 / 256;                 // 9, 3 and 6 chunks per thread
+    bf16x8 cq[NQKV], co[NRO], cg[NRG];
     float cl[2];
+    // Issue order = use order (the vector-memory counter retires in order): g_mid first -- the d_o products run while q | k | v, lse and o are still on their way.
 #pragma unroll
-    for (int k = 0; k < NQKV; ++k) {
-        const int idx = threadIdx.x + 512 * k, row = idx / 48, c = idx - row * 48, part = c >> 4, ch = c & 15;
-        cq[k] = zero8();
-        if (row < L) {
-            const int64_t tk = tok_of(G, row, Tn, mode);
-            cq[k] = *reinterpret_cast<const bf16x8*>(part == 0 ? Q + tk * ldq + ch * 8 : (part == 1 ? K : V) + tk * ldkv + ch * 8);
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < NROW; ++k) {
-        const int idx = threadIdx.x + 512 * k, row = idx >> 4, ch = idx & 15;
-        co[k] = zero8();
+    for (int k = 0; k < NRG; ++k) {
+        const int idx = threadIdx.x + 256 * k, row = idx >> 4, ch = idx & 15;
         cg[k] = zero8();
-        if (row < L) {
-            const int64_t tk = tok_of(G, row, Tn, mode);
-            co[k] = *reinterpret_cast<const bf16x8*>(O + tk * 128 + ch * 8);
-            cg[k] = *reinterpret_cast<const bf16x8*>(Gmid + tk * 128 + ch * 8);
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int idx = threadIdx.x + 512 * k, row = idx >> 3, hd = idx & 7;
-        cl[k] = INFINITY;                                         // rows past L: exp(s - inf) = 0 keeps them out of every product
-        if (idx < ROWS * 8 && row < L) cl[k] = LSE[tok_of(G, row, Tn, mode) * 8 + hd];
+        if (row < L) cg[k] = *reinterpret_cast<const bf16x8*>(Gmid + tok_of(G, row, Tn, mode) * 128 + ch * 8);
     }
     const int li = lane & 15, lg = lane >> 4;
     bf16x8 wp[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) wp[ks] = *reinterpret_cast<const bf16x8*>(Wp + (int64_t)(16 * h + li) * 128 + 32 * ks + 8 * lg);
 #pragma unroll
-    for (int k = 0; k < NROW; ++k) {
-        const int idx = threadIdx.x + 512 * k, row = idx >> 4, ch = idx & 15;
-        *reinterpret_cast<bf16x8*>(sG + Tile<bf16>::chunk_off(row, ch)) = cg[k];
-    }
-#pragma unroll
     for (int k = 0; k < NQKV; ++k) {
-        const int idx = threadIdx.x + 512 * k, row = idx / 48, c = idx - row * 48, part = c >> 4, ch = c & 15;
-        bf16x8 v = cq[k];
-        if (part == 0) {                                          // Q / 4 (a power of two: exact in bf16)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (bf16)((float)v[e] * 0.25f);
+        const int idx = threadIdx.x + 256 * k, row = idx / 24, c = idx - row * 24, part = c >> 3, ch = c & 7;
+        cq[k] = zero8();
+        if (row < L) {
+            const int64_t tk = tok_of(G, row, Tn, mode);
+            cq[k] = *reinterpret_cast<const bf16x8*>(part == 0 ? Q + tk * ldq + hb * 16 + ch * 8 : (part == 1 ? K : V) + tk * ldkv + hb * 16 + ch * 8);
         }
-        *reinterpret_cast<bf16x8*>(wave_tile(ch >> 1, part == 0 ? 1 : (part == 1 ? 0 : 3)) + row * 16 + 8 * (ch & 1)) = v;
     }
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-        const int idx = threadIdx.x + 512 * k, row = idx >> 3, hd = idx & 7;
-        if (idx < ROWS * 8) wave_stat(hd, 0)[row] = -cl[k];       // negated: lse and delta ride into the score products as initial accumulators
+        const int idx = threadIdx.x + 256 * k, row = idx >> 2, hd = idx & 3;
+        cl[k] = INFINITY;                                         // rows past L: exp(s - inf) = 0 keeps them out of every product
+        if (idx < ROWS * KT_HPW && row < L) cl[k] = LSE[tok_of(G, row, Tn, mode) * 8 + hb + hd];
     }
+#pragma unroll
+    for (int k = 0; k < NRO; ++k) {
+        const int idx = threadIdx.x + 256 * k, row = idx >> 3, ch = idx & 7;
+        co[k] = zero8();
+        if (row < L) co[k] = *reinterpret_cast<const bf16x8*>(O + tok_of(G, row, Tn, mode) * 128 + hb * 16 + ch * 8);
+    }
+#pragma unroll
+    for (int k = 0; k < NRG; ++k) {
+        const int idx = threadIdx.x + 256 * k, row = idx >> 4, ch = idx & 15;
+        *reinterpret_cast<bf16x8*>(sG + Tile<bf16>::chunk_off(row, ch)) = cg[k];
+    }
+    KTQ0();                                                       // 1: g_mid rows landed and written
     __syncthreads();
     {   // d_o = g_mid . (ls1 . Wproj)^T restricted to this head: 24 MFMAs against the wave's 16 rows of the packed weight
 #pragma unroll
@@ -549,10 +556,32 @@ __global__ __launch_bounds__(512, 2) void k_attn_bwd_kt(const bf16* __restrict__
             store4(sD + (16 * mt + li) * 16 + 4 * lg, v);
         }
     }
-    __syncthreads();                                              // every head's d_o tile is complete
+    KTQ0();                                                       // 2: d_o
 #pragma unroll
-    for (int k = 0; k < NROW; ++k) {   // delta = sum_d d_o . o per (position, head): the thread that loaded 8 channels of o meets the same 8 of d_o; the head's two halves are neighbours
-        const int idx = threadIdx.x + 512 * k, row = idx >> 4, ch = idx & 15;
+    for (int k = 0; k < NQKV; ++k) {
+        const int idx = threadIdx.x + 256 * k, row = idx / 24, c = idx - row * 24, part = c >> 3, ch = c & 7;
+        if (part == 2) continue;                                  // V waits in its registers for the g_mid rows' place
+        bf16x8 v = cq[k];
+        if (part == 0) {                                          // Q / 4 (a power of two: exact in bf16)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (bf16)((float)v[e] * 0.25f);
+        }
+        *reinterpret_cast<bf16x8*>(wave_tile(ch >> 1, part == 0 ? 1 : 0) + row * 16 + 8 * (ch & 1)) = v;
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int idx = threadIdx.x + 256 * k, row = idx >> 2, hd = idx & 3;
+        if (idx < ROWS * KT_HPW) wave_stat(hd, 0)[row] = -cl[k];  // negated: lse and delta ride into the score products as initial accumulators
+    }
+    __syncthreads();                                              // every head's d_o tile is complete, the g_mid rows have been read
+#pragma unroll
+    for (int k = 0; k < NQKV; ++k) {
+        const int idx = threadIdx.x + 256 * k, row = idx / 24, c = idx - row * 24, part = c >> 3, ch = c & 7;
+        if (part == 2) *reinterpret_cast<bf16x8*>(sG + (ch >> 1) * VTILE + row * 16 + 8 * (ch & 1)) = cq[k];
+    }
+#pragma unroll
+    for (int k = 0; k < NRO; ++k) {   // delta = sum_d d_o . o per (position, head): the thread that loaded 8 channels of o meets the same 8 of d_o; the head's two halves are neighbours
+        const int idx = threadIdx.x + 256 * k, row = idx >> 3, ch = idx & 7;
         const bf16x8 d8 = *reinterpret_cast<const bf16x8*>(wave_tile(ch >> 1, 2) + row * 16 + 8 * (ch & 1));
         float part = 0.f;
 #pragma unroll
@@ -561,6 +590,7 @@ __global__ __launch_bounds__(512, 2) void k_attn_bwd_kt(const bf16* __restrict__
         if ((ch & 1) == 0) wave_stat(ch >> 1, 1)[row] = -part;
     }
     __syncthreads();
+    KTQ0();                                                       // 3: d_o, V, delta + two barriers
     auto rowf = [&](const bf16* tile, int t) { return *reinterpret_cast<const bf16x8*>(tile + (32 * t + r) * 16 + 8 * hh); };
     const int nt = (L + 31) >> 5;                                 // live 32-position tiles (2 or 3)
     bf16x8 kf[NKT], vf[NKT];
@@ -637,6 +667,7 @@ __global__ __launch_bounds__(512, 2) void k_attn_bwd_kt(const bf16* __restrict__
             store_t16(dK + tok * lddkv + h * 16, dk, hh);
         }
     }
+    KTQ0();                                                       // 4: the tile pairs (dK / dV stores issued)
 #pragma unroll
     for (int qt = 0; qt < NKT; ++qt) {
         const int i = 32 * qt + r;
@@ -646,6 +677,12 @@ __global__ __launch_bounds__(512, 2) void k_attn_bwd_kt(const bf16* __restrict__
             store_t16(dQ + tok_of(G, i, Tn, mode) * lddq + h * 16, dq[qt], hh);
         }
     }
+#ifdef KT_PROF
+    KTQ();                                                        // 5: every store acknowledged
+    if ((blockIdx.x == 777 || blockIdx.x == 2000) && lane == 0 && (wave == 0 || wave == 3))
+        printf("kt prof block %d wave %d: g_mid landed + written %lld  B1 + d_o %lld  rest landed, tiles, V, delta, B2, B3 %lld  tile pairs %lld  dq stores+acks %lld  total %lld\n", (int)blockIdx.x, wave,
+               kt_t[1] - kt_t[0], kt_t[2] - kt_t[1], kt_t[3] - kt_t[2], kt_t[4] - kt_t[3], kt_t[5] - kt_t[4], kt_t[5] - kt_t[0]);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1292,15 +1329,16 @@ bool kasf_launch_attn_bwd_fused_do(hipStream_t s, const void* q, int64_t ldq, co
     if (L > 32) {                                       // three-tile groups (temporal attention at T = 81): one workgroup = the 8 heads of one group
         if (form == 1) return false;                    // (the one-group-per-workgroup comparison form exists for one-tile groups only)
         if (o_saved != nullptr && lse != nullptr) {     // key-tile-outer kernel: statistics and delta from what the forward left behind
-            const size_t shk = 8 * (size_t)(4 * 96 * 16 * 2 + 32 * KT_LD * 2 + 2 * 96 * 4) + (size_t)96 * 128 * 2;
+            const size_t shk = KT_HPW * (size_t)(3 * 96 * 16 * 2 + 32 * KT_LD * 2 + 2 * 96 * 4 + KT_PAD) + (size_t)96 * 128 * 2;      // 73,856 bytes: two workgroups per CU
+            const unsigned ktgrid = 16u * (unsigned)((groups + 7) / 8);          // two workgroups (head halves) per group, blocks b and b + 8
             if (L > 64 && L <= 81) {                    // last tile of at most 17 positions: 7 of its 16 query registers are dead
                 if (!set_smem(k_attn_bwd_kt<3, 9>, shk)) return true;
-                hipLaunchKernelGGL((k_attn_bwd_kt<3, 9>), dim3(groups), dim3(512), shk, s, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldkv, (const bf16*)o_saved, lse,
-                                   (bf16*)dq, lddq, (bf16*)dk, (bf16*)dv, lddkv, L, Tn, mode, (const bf16*)g_mid, (const bf16*)WprojTs);
+                hipLaunchKernelGGL((k_attn_bwd_kt<3, 9>), dim3(ktgrid), dim3(256), shk, s, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldkv, (const bf16*)o_saved, lse,
+                                   (bf16*)dq, lddq, (bf16*)dk, (bf16*)dv, lddkv, L, Tn, mode, (const bf16*)g_mid, (const bf16*)WprojTs, groups);
             } else {
                 if (!set_smem(k_attn_bwd_kt<3, 16>, shk)) return true;
-                hipLaunchKernelGGL((k_attn_bwd_kt<3, 16>), dim3(groups), dim3(512), shk, s, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldkv, (const bf16*)o_saved, lse,
-                                   (bf16*)dq, lddq, (bf16*)dk, (bf16*)dv, lddkv, L, Tn, mode, (const bf16*)g_mid, (const bf16*)WprojTs);
+                hipLaunchKernelGGL((k_attn_bwd_kt<3, 16>), dim3(ktgrid), dim3(256), shk, s, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldkv, (const bf16*)o_saved, lse,
+                                   (bf16*)dq, lddq, (bf16*)dk, (bf16*)dv, lddkv, L, Tn, mode, (const bf16*)g_mid, (const bf16*)WprojTs, groups);
             }
             return true;
         }

@@ -10,6 +10,7 @@
 #include "common.h"
 #include "kernels.h"
 #include "tile_ops.h"
+#include "mlp_fin.h"
 #ifndef KASF_LINEAR_ISSUE_AT        // k_linear_r: the look-ahead loads of tile t+2 behind B1 (1, shipped since round 5) or behind B2, back to back with the LayerNorm / copy-out stores (0): 29.3 -> 28.6 us in step
 #define KASF_LINEAR_ISSUE_AT 1
 #endif
@@ -35,17 +36,30 @@ __device__ __forceinline__ bf16x8 tok_frag(const bf16* s, int row, int ks) {
 // PROJ (with WG and RESID; the bone block's q linear): the block's OUTPUT-PROJECTION weight gradient G = g_mid^T . o rides here as well -- g_mid is this
 // kernel's residual operand, the attention output o arrives as one more ring stream -- with the column sums of g_mid (the proj bias / layer-scale terms);
 // the block then has no streaming weight-gradient launch at all, and o and g_mid are not read a second time.
-template <int KC, bool RESID, bool ADD, bool ACC, bool XN, int RING, bool WG = false, bool BIAS = false, bool PROJ = false>
+// MLPFIN (round 6, KC = 4 with RESID): the second launch of the MLP backward.  dY = dZ [M][512] as k_mlp_bwd_s<DZOUT> leaves it, Wt = fc1.weight^T: out = g + LNbwd(dZ W1; x_mid,
+// norm2) -- the dA product that used to be four bf16 partials out of the issue-bound kernel, formed here on an idle matrix pipe with ONE fp32 accumulation over the 512 hidden
+// units; the workgroup's row of `part` is dgamma | dbeta | colsum(g) (the fc2 bias / layer-scale terms), and workgroups past `ngrid` (128 of them, two 256-thread fin blocks each)
+// run the fixed-order sum of the weight-gradient partial tiles (mlp_fin.h) -- the roles k_lnbwd_sum4_fin had.
+template <int KC, bool RESID, bool ADD, bool ACC, bool XN, int RING, bool WG = false, bool BIAS = false, bool PROJ = false, bool MLPFIN = false>
 __global__ __launch_bounds__(R_THR) void k_dgrad_r(const bf16* __restrict__ dY, const bf16* __restrict__ Wt, const bf16* __restrict__ dxn_add,
                                                    const bf16* __restrict__ X, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                    const bf16* __restrict__ resid, bf16* __restrict__ out, float* __restrict__ dgamma,
                                                    float* __restrict__ dbeta, bf16* __restrict__ xn_out, int64_t M, float* __restrict__ part,
                                                    bf16* __restrict__ wpart, float* __restrict__ dbias, const bf16* __restrict__ Oin,
-                                                   bf16* __restrict__ ppart, float* __restrict__ pbrow) {
+                                                   bf16* __restrict__ ppart, float* __restrict__ pbrow, const MlpFinArgs fa, int ngrid) {
+    static_assert(!MLPFIN || (RESID && !WG && !BIAS && !PROJ), "the MLP form: residual operand, no fused weight gradient of its own");
+    if (MLPFIN && (int)blockIdx.x >= ngrid) {            // weight-gradient finish role: fin blocks 2 b, 2 b + 1 (both on the same side of 128: same barrier count)
+        __shared__ f32x4 sHalf[2][128];
+        __shared__ float sDot[2][2];
+        const int sb = threadIdx.x >> 8;
+        mlp_wfinish_body(fa, 2 * ((int)blockIdx.x - ngrid) + sb, (int)(threadIdx.x & 255), sHalf[sb], sDot[sb]);
+        return;
+    }
+    const int nwg = MLPFIN ? ngrid : (int)gridDim.x;     // workgroups that walk token tiles
     static_assert(!WG || XN, "the fused weight gradient multiplies by LN(x)");
     static_assert(!PROJ || (WG && RESID), "the proj gradient multiplies the residual operand g_mid by o");
     static_assert(!BIAS || WG, "the bias gradient rides with the fused weight gradient");
-    constexpr int PLD = 256 + (BIAS ? 128 * KC : 0);    // floats per workgroup row of `part`: dgamma | dbeta [| dbias]
+    constexpr int PLD = 256 + (BIAS ? 128 * KC : 0) + (MLPFIN ? 128 : 0);    // floats per workgroup row of `part`: dgamma | dbeta [| dbias] [| colsum(resid)]
     constexpr int Kd = 128 * KC;
     constexpr int NSTREAM = KC + 1 + (RESID ? 1 : 0) + (ADD ? 1 : 0) + (ACC ? 1 : 0) + (PROJ ? 1 : 0);     // LDS-direct loads per wave per tile
     constexpr int SLOT = NSTREAM * R_TILE;
@@ -58,7 +72,7 @@ __global__ __launch_bounds__(R_THR) void k_dgrad_r(const bf16* __restrict__ dY, 
     float* sRed = reinterpret_cast<float*>(smem);       // [2][32][128] end-of-kernel dgamma/dbeta partials: reuses the (then dead) ring
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4, sub = lane & 15, rl = threadIdx.x >> 4;
     const int64_t ntiles_total = (M + R_BM - 1) / R_BM;
-    const int64_t per = (ntiles_total + gridDim.x - 1) / gridDim.x;
+    const int64_t per = (ntiles_total + nwg - 1) / nwg;
     const int64_t tile0 = (int64_t)blockIdx.x * per;
     int64_t ntiles = ntiles_total - tile0;
     if (ntiles > per) ntiles = per;
@@ -201,6 +215,12 @@ __global__ __launch_bounds__(R_THR) void k_dgrad_r(const bf16* __restrict__ dY, 
                 tile_load8(slot + O_RES, rl, sub * 8, a);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] += a[e];
+                if (MLPFIN) {
+                    if (live) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) gcol[e] += a[e];
+                    }
+                }
                 if (PROJ) {
                     if (live) {
 #pragma unroll
@@ -276,7 +296,7 @@ __global__ __launch_bounds__(R_THR) void k_dgrad_r(const bf16* __restrict__ dY, 
             }
         }
     }
-    if (PROJ) {
+    if (PROJ || MLPFIN) {
         __syncthreads();
 #pragma unroll
         for (int e = 0; e < 8; ++e) sRed[rl * 128 + sub * 8 + e] = gcol[e];
@@ -285,7 +305,11 @@ __global__ __launch_bounds__(R_THR) void k_dgrad_r(const bf16* __restrict__ dY, 
             float sb = 0.f;
 #pragma unroll 8
             for (int k = 0; k < 32; ++k) sb += sRed[k * 128 + threadIdx.x];
-            pbrow[(int64_t)blockIdx.x * 128 + threadIdx.x] = sb;             // one row of colsum(g_mid) per workgroup: the finish launch's `brow`
+            if (MLPFIN) {                                // colsum(g): the third block of the workgroup's row (without scratch: an atomic on the gsum slot, passed as `dbias`)
+                if (part != nullptr) part[(int64_t)blockIdx.x * PLD + 256 + threadIdx.x] = sb;
+                else atomicAdd(dbias + threadIdx.x, sb);
+            }
+            else pbrow[(int64_t)blockIdx.x * 128 + threadIdx.x] = sb;          // one row of colsum(g_mid) per workgroup: the finish launch's `brow`
         }
     }
     if (WG) {
@@ -336,7 +360,7 @@ int launch_dgrad_r(hipStream_t s, const void* dY, const void* Wt, const void* ad
     const int active = (int)((tiles + per - 1) / per);                                  // workgroups that own at least one tile (the others return at once)
     float* part = sink != nullptr ? sink->take(active, PLD) : nullptr;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(R_THR), sh, s, (const bf16*)dY, (const bf16*)Wt, (const bf16*)add, (const bf16*)X, gamma, beta,
-                       (const bf16*)resid, (bf16*)out, dgamma, dbeta, (bf16*)xn_out, M, part, (bf16*)wpart, dbias, (const bf16*)o_in, (bf16*)ppart, pbrow);
+                       (const bf16*)resid, (bf16*)out, dgamma, dbeta, (bf16*)xn_out, M, part, (bf16*)wpart, dbias, (const bf16*)o_in, (bf16*)ppart, pbrow, MlpFinArgs{}, (int)grid);
     if (part != nullptr) {
         sink->add(part, PLD, active, 128, dgamma);
         sink->add(part + 128, PLD, active, 128, dbeta);
@@ -525,6 +549,33 @@ int kasf_launch_dgrad_wg(hipStream_t s, const void* dY, int Kd, const void* Wt, 
     if (Kd == 128 && R && !C) return launch_dgrad_r<1, true, false, false, true, true>(s, dY, Wt, nullptr, X, gamma, beta, resid, out, dgamma, dbeta, nullptr, M, sink, wpart);
     if (Kd == 256 && !R && C) return launch_dgrad_r<2, false, false, true, true, true>(s, dY, Wt, nullptr, X, gamma, beta, resid, out, dgamma, dbeta, nullptr, M, sink, wpart);
     return 0;
+}
+
+// Second launch of the bf16 MLP backward (k_mlp_bwd_s<DZOUT> before it): g_in = g + LNbwd(dZ W1; x, gamma) + per-workgroup rows dgamma | dbeta | colsum(g) in the sink +
+// the weight-gradient finish role.  fin: MlpFinArgs of kasf_launch_mlp_bwd_q (as void* to keep mlp_fin.h out of kernels.h).
+void kasf_launch_mlp_dgrad_fin(hipStream_t s, const void* dZ, const void* W1t, const void* X, const float* gamma, const void* g, void* g_in, float* dgamma, float* dbeta,
+                               float* gsum, int64_t M, KasfColSink* sink, const void* fin_args, const float* b2, const float* ls2, float* dls2, bool have_w2) {
+    constexpr int KC = 4, NSTREAM = KC + 2, PLD = 384;
+    constexpr size_t fixed = (size_t)R_TILE * 2;
+    constexpr int RING = (3 * NSTREAM * R_TILE * 2 + fixed <= 160 * 1024) ? 3 : 2;
+    const size_t sh = (size_t)RING * NSTREAM * R_TILE * 2 + fixed;
+    auto kern = k_dgrad_r<KC, true, false, false, false, RING, false, false, false, true>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    const int64_t tiles = (M + R_BM - 1) / R_BM;
+    const int64_t gcap = kasf_narrow_grid(KASF_NG_DGRAD, 256, M);          // (full width measured 1 % slower in step: profiles/r6_mlp_bwd_dz_form_ab.md)
+    const int grid = (int)(tiles < gcap ? tiles : gcap);
+    const int64_t per = (tiles + grid - 1) / grid;
+    const int active = (int)((tiles + per - 1) / per);
+    float* part = sink != nullptr ? sink->take(active, PLD) : nullptr;
+    hipLaunchKernelGGL(kern, dim3(grid + 128), dim3(R_THR), sh, s, (const bf16*)dZ, (const bf16*)W1t, (const bf16*)nullptr, (const bf16*)X, gamma, (const float*)nullptr,
+                       (const bf16*)g, (bf16*)g_in, dgamma, dbeta, (bf16*)nullptr, M, part, (bf16*)nullptr, gsum, (const bf16*)nullptr, (bf16*)nullptr,
+                       (float*)nullptr, *reinterpret_cast<const MlpFinArgs*>(fin_args), grid);
+    if (part != nullptr) {
+        sink->add(part, PLD, active, 128, dgamma);
+        sink->add(part + 128, PLD, active, 128, dbeta);
+        if (have_w2) sink->add(part + 256, PLD, active, 128, gsum, 1, b2, ls2, dls2);      // gsum is the fc2 bias gradient slot: db2 = ls2 . colsum(g)
+        else sink->add(part + 256, PLD, active, 128, gsum);
+    }
 }
 
 // y = LN?(a) W^T + bias, a [M,128] dense, W [N,128] dense, y [M,N] dense, N in {128, 256, 384}

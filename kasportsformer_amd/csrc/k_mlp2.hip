@@ -13,6 +13,7 @@
 #include "common.h"
 #include "kernels.h"
 #include "tile_ops.h"
+#include "mlp_fin.h"
 
 namespace {
 
@@ -89,96 +90,15 @@ __device__ __forceinline__ void lnbwd_sum4_body(const bf16* __restrict__ dApart,
         else atomicAdd((which == 0 ? dgamma : (which == 1 ? dbeta : gsum)) + c, s);
     }
 }
-// ---------------------------------------------------------------------------------------------------------------
-// End of the MLP backward in ONE launch: sums the per-range partial tiles of dW1 [512][128] and dW2 [128][512] (fixed order)
-// and, for fc2, applies the layer-scale algebra that k_finalize_ls would: with G = g^T H (unscaled),
-//   dls[c] += sum_k W2[c][k] G[c][k] + b2[c] gsum[c];   dW2[c][:] += ls[c] G[c][:];   db2[c] = ls[c] gsum[c].
-// Workgroups 0..127 own 4 rows of dW1 each, workgroups 128..255 one row of dW2 each (512 floats per workgroup); the two
-// halves of a workgroup take the even / odd splits.
-// ---------------------------------------------------------------------------------------------------------------
-// The colsum(g) terms (b2 . gsum into dls, db2 = ls . gsum) are NOT applied here: the column sums are complete only after this launch.
-__device__ __forceinline__ f32x4 ld4(const bf16* p) {
-    const bf16x4 t = *reinterpret_cast<const bf16x4*>(p);
-    return f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
-}
-__device__ __forceinline__ void mlp_wfinish_body(const bf16* __restrict__ p1, const bf16* __restrict__ p2, float* __restrict__ dW1,
-                                                 float* __restrict__ dW2, int splits, const float* __restrict__ W2, const float* __restrict__ b2,
-                                                 const float* __restrict__ ls, float* __restrict__ dls, int bid) {
-    __shared__ f32x4 sHalf[128];
-    __shared__ float sDot[2];
-    const int lane = threadIdx.x & 127, half = threadIdx.x >> 7;
-    const bool second = bid >= 128;
-    const int blk = second ? bid - 128 : bid;
-    const bf16* part = second ? p2 : p1;
-    const int64_t e = (int64_t)blk * 512 + lane * 4;
-    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
-    int z = half;
-    for (; z + 6 < splits; z += 8) {                    // four partial tiles in flight per thread; the order of the additions is the two-at-a-time loop's
-        const f32x4 u0 = ld4(part + (int64_t)z * 65536 + e);
-        const f32x4 v0 = ld4(part + (int64_t)(z + 2) * 65536 + e);
-        const f32x4 u1 = ld4(part + (int64_t)(z + 4) * 65536 + e);
-        const f32x4 v1 = ld4(part + (int64_t)(z + 6) * 65536 + e);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { a[q] += u0[q]; b[q] += v0[q]; }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { a[q] += u1[q]; b[q] += v1[q]; }
-    }
-    for (; z + 2 < splits; z += 4) {
-        const f32x4 u = ld4(part + (int64_t)z * 65536 + e);
-        const f32x4 v = ld4(part + (int64_t)(z + 2) * 65536 + e);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { a[q] += u[q]; b[q] += v[q]; }
-    }
-    if (z < splits) {
-        const f32x4 u = ld4(part + (int64_t)z * 65536 + e);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) a[q] += u[q];
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) a[q] += b[q];
-    if (half == 1) sHalf[lane] = a;
-    __syncthreads();
-    if (half == 0) {
-        const f32x4 o = sHalf[lane];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) a[q] += o[q];                    // a = the summed gradient (G for fc2)
-    }
-    const bool fin = second && W2 != nullptr;
-    float dot = 0.f;
-    if (half == 0) {
-        float* dst = (second ? dW2 : dW1) + e;
-        f32x4 cur = *reinterpret_cast<f32x4*>(dst);
-        const float l = fin ? ls[blk] : 1.0f;
-        if (fin) {
-            const f32x4 w = *reinterpret_cast<const f32x4*>(W2 + e);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) dot += w[q] * a[q];
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) cur[q] += l * a[q];
-        *reinterpret_cast<f32x4*>(dst) = cur;
-    }
-    if (fin) {
-        dot = reduce64(dot);
-        if (half == 0 && (threadIdx.x & 63) == 0) sDot[threadIdx.x >> 6] = dot;
-        __syncthreads();
-        if (threadIdx.x == 0) dls[blk] += sDot[0] + sDot[1];      // this workgroup owns row blk: a plain read-modify-write
-    }
-}
-struct MlpFinArgs {
-    const bf16 *p1, *p2;       // bf16 partial tiles per token range: [ranges][512][128] and [ranges][128][512]
-    float *dW1, *dW2;
-    int splits;
-    const float *W2, *b2, *ls;
-    float* dls;
-};
 template <int RPT>
 __global__ __launch_bounds__(256) void k_lnbwd_sum4_fin(const bf16* __restrict__ dApart, const bf16* __restrict__ X, const bf16* __restrict__ G,
                                                         const float* __restrict__ gamma, bf16* __restrict__ g_in, float* __restrict__ dgamma,
                                                         float* __restrict__ dbeta, float* __restrict__ gsum, float* __restrict__ part, int64_t M,
                                                         const MlpFinArgs fa) {
     if (blockIdx.x < 256) {
-        mlp_wfinish_body(fa.p1, fa.p2, fa.dW1, fa.dW2, fa.splits, fa.W2, fa.b2, fa.ls, fa.dls, (int)blockIdx.x);
+        __shared__ f32x4 sHalf[128];
+        __shared__ float sDot[2];
+        mlp_wfinish_body(fa, (int)blockIdx.x, (int)threadIdx.x, sHalf, sDot);
         return;
     }
     lnbwd_sum4_body<RPT>(dApart, X, G, gamma, g_in, dgamma, dbeta, gsum, part, M, (int)blockIdx.x - 256, (int)gridDim.x - 256);
@@ -202,8 +122,18 @@ void kasf_launch_mlp_bwd_q(hipStream_t s, const void* x, const void* xn, const v
     bf16* p1 = reinterpret_cast<bf16*>(partial);          // (the scratch is sized in floats for the round-3 fp32 tiles: half of it is used)
     bf16* p2 = p1 + (int64_t)used * 512 * 128;
     float* db1_rows = sink != nullptr ? sink->take(used, 512) : nullptr;          // one row of db1 per token range
-    kasf_launch_mlp_bwd_s(s, xn, g, W1, b1, W2ts, W1t, dApart, p1, p2, db1, db1_rows, M, tpr, used);
+    // Round 6, opt-in (KASF_MLP_BWD_DZ=1): the dZ form -- k_mlp_bwd_s<DZOUT> leaves dZ [M][512] where the four dA partials went, and the second launch
+    // (k_dgrad_r<4, ..., MLPFIN>, k_gemm2.hip) forms dA = dZ W1 on its own matrix pipe in front of the LayerNorm backward.  Same bytes, one GEMM moved out of the
+    // issue-bound kernel into the HBM-bound one: k_mlp_bwd_s -10 us, the second launch +9..+28 us, step +0.4 % (inside box noise) -- so the partial-sum form of
+    // rounds 2-5 (k_lnbwd_sum4_fin) stays the default.  profiles/r6_mlp_bwd_dz_form_ab.md
+    static const bool dz_form = [] { const char* e = getenv("KASF_MLP_BWD_DZ"); return e != nullptr && *e == '1'; }();
+    kasf_launch_mlp_bwd_s(s, xn, g, W1, b1, W2ts, W1t, dApart, p1, p2, db1, db1_rows, M, tpr, used, dz_form);
     if (db1_rows != nullptr) sink->add(db1_rows, 512, used, 512, db1);
+    if (dz_form) {
+        const MlpFinArgs fa{p1, p2, dW1, dW2, used, W2, b2, ls2, dls2};
+        kasf_launch_mlp_dgrad_fin(s, dApart, W1t, x, ln_g, g, g_in, dgamma, dbeta, gsum, M, sink, &fa, b2, ls2, dls2, W2 != nullptr);
+        return;
+    }
     int64_t blocks = (M + 31) / 32;                     // two rows of 16 lanes per thread
     if (blocks > 512) blocks = 512;
     float* rows = sink != nullptr ? sink->take((int)blocks, 384) : nullptr;       // dgamma | dbeta | colsum(g) per streaming workgroup

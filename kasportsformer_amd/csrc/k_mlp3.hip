@@ -312,6 +312,11 @@ __global__ __launch_bounds__(S_THR) void k_mlp_fwd_s(const bf16* __restrict__ X,
 // double-buffered 2 x (8 + 8) KB.
 // ---------------------------------------------------------------------------------------------------------------
 // ---------------------------------------------------------------------------------------------------------------
+// DZOUT (round 6): the consumers do NOT form the quarter's dA partial; they copy the quarter's dZ tile out ([M][512] bf16, the same 1,024 B per token as the four dA
+// partials) and the launch that follows -- k_dgrad_r<4, ..., MLPFIN> (k_gemm2.hip) -- forms dA = dZ W1 on ITS idle matrix pipe in front of the LayerNorm backward:
+// 16 of this kernel's 80 MFMAs per tile, their operand reads, the W1^T registers and the 8-byte scattered partial stores leave the issue-bound kernel
+// (knock-outs, profiles/r5_mlp_ab.md: -9 us for the products, -9 us for the stores, of ~110).
+template <bool DZOUT>
 __global__ __launch_bounds__(S_THR) void k_mlp_bwd_s(const bf16* __restrict__ XN, const bf16* __restrict__ G, const bf16* __restrict__ W1,
                                                      const float* __restrict__ b1, const bf16* __restrict__ W2ts, const bf16* __restrict__ W1t,
                                                      bf16* __restrict__ dApart, bf16* __restrict__ dW1part, bf16* __restrict__ dW2part,
@@ -526,10 +531,12 @@ __global__ __launch_bounds__(S_THR) void k_mlp_bwd_s(const bf16* __restrict__ XN
         f32x4 accW1[4][4], accW2[4][4];
         zero_acc(accW1);
         zero_acc(accW2);
+        if (!DZOUT) {
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+            for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) wtf[nt][ks] = *reinterpret_cast<const bf16x8*>(W1t + (int64_t)(ch0 + 16 * nt + i) * 512 + q * 128 + 32 * ks + 8 * g);
+                for (int ks = 0; ks < 4; ++ks) wtf[nt][ks] = *reinterpret_cast<const bf16x8*>(W1t + (int64_t)(ch0 + 16 * nt + i) * 512 + q * 128 + 32 * ks + 8 * g);
+        }
         barrier_keep_async();                            // (the producers' rows of tile 0 have landed)
         TSTART();
         int sc = BW_RING - 1;                            // ring slot of tile t-1 (consumed), rolling mod RING
@@ -538,6 +545,17 @@ __global__ __launch_bounds__(S_THR) void k_mlp_bwd_s(const bf16* __restrict__ XN
             f32x4 accA[2][2];
             auto store_dA = [&]() {
                 const int64_t row0 = (tile0 + t - 1) * S_BM;
+                if (DZOUT) {   // the quarter's dZ tile of tile t - 1, whole 256-byte row pieces: consumer thread (rl, sub) copies chunk `sub` of rows rl and rl + 16
+                    const bf16* cDz = sD + (int)((t - 1) & 1) * TL;
+                    const int ct = c * 64 + lane, rlz = ct >> 4, subz = ct & 15;
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int64_t row = row0 + rlz + 16 * k;
+                        if (row < M)
+                            *reinterpret_cast<f32x4*>(dApart + row * 512 + q * 128 + subz * 8) = *reinterpret_cast<const f32x4*>(cDz + Tile<bf16>::chunk_off(rlz + 16 * k, subz));
+                    }
+                    return;
+                }
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
                     const int64_t row = row0 + mt * 16 + i;
@@ -557,7 +575,7 @@ __global__ __launch_bounds__(S_THR) void k_mlp_bwd_s(const bf16* __restrict__ XN
                 const bf16* cD = sD + (int)((t - 1) & 1) * TL;
                 zero_acc(accA);
 #ifndef KASF_KO_DA
-                {   // ---- dA_q partial: 32 channels x 32 tokens over the 128 hidden units of the quarter ----
+                if (!DZOUT) {   // ---- dA_q partial: 32 channels x 32 tokens over the 128 hidden units of the quarter ----
                     bf16x8 fd[2][2];
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt) fd[0][mt] = tok_frag(cD, mt * 16 + i, 0);
@@ -682,9 +700,15 @@ extern "C" int kasf_debug_read_lstamps(long long* dst, int reset) {      // dst:
 #endif
 
 void kasf_launch_mlp_bwd_s(hipStream_t s, const void* xn, const void* g, const void* W1, const float* b1, const void* W2ts, const void* W1t, void* dApart,
-                           void* p1, void* p2, float* db1, float* db1_rows, int64_t M, int tiles_per_range, int used) {
+                           void* p1, void* p2, float* db1, float* db1_rows, int64_t M, int tiles_per_range, int used, bool dz_out) {
     const size_t sh = (size_t)((2 * BW_RING + 4) * TL) * sizeof(bf16);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_bwd_s), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    hipLaunchKernelGGL(k_mlp_bwd_s, dim3(4 * used), dim3(S_THR), sh, s, (const bf16*)xn, (const bf16*)g, (const bf16*)W1, b1, (const bf16*)W2ts,
+    if (dz_out) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_bwd_s<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        hipLaunchKernelGGL(k_mlp_bwd_s<true>, dim3(4 * used), dim3(S_THR), sh, s, (const bf16*)xn, (const bf16*)g, (const bf16*)W1, b1, (const bf16*)W2ts,
+                           (const bf16*)W1t, (bf16*)dApart, (bf16*)p1, (bf16*)p2, db1, db1_rows, M, tiles_per_range);
+        return;
+    }
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_bwd_s<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    hipLaunchKernelGGL(k_mlp_bwd_s<false>, dim3(4 * used), dim3(S_THR), sh, s, (const bf16*)xn, (const bf16*)g, (const bf16*)W1, b1, (const bf16*)W2ts,
                        (const bf16*)W1t, (bf16*)dApart, (bf16*)p1, (bf16*)p2, db1, db1_rows, M, tiles_per_range);
 }

@@ -99,7 +99,7 @@ inline int kasf_gcn_mask_words(int n_frames) { return n_frames <= 96 ? 3 : (n_fr
 void kasf_launch_mlp_fwd_s(hipStream_t s, const void* x, const float* ln_g, const float* ln_b, const void* W1, const float* b1, const void* W2,
                            const float* b2, const float* ls2, void* out, int64_t M, void* xn_out, unsigned grid);
 void kasf_launch_mlp_bwd_s(hipStream_t s, const void* xn, const void* g, const void* W1, const float* b1, const void* W2ts, const void* W1t, void* dApart,
-                           void* p1, void* p2, float* db1, float* db1_rows, int64_t M, int tiles_per_range, int used);     // p1 / p2: bf16 partial tiles per token range
+                           void* p1, void* p2, float* db1, float* db1_rows, int64_t M, int tiles_per_range, int used, bool dz_out = false);     // p1 / p2: bf16 partial tiles per token range; dz_out: dApart receives dZ [M][512] instead of the four dA partials
 
 // ---- k_attn.hip ----
 // mode 0: spatial (groups = B*T frames of 17 tokens), mode 1: temporal (groups = B*17 joint tracks of T tokens)
@@ -198,6 +198,9 @@ inline int kasf_narrow_grid(int cls, int full, int64_t tokens) {
     return g < 1 ? 1 : g;
 }
 
+// second launch of the bf16 MLP backward in its dZ form (k_gemm2.hip; fin_args: the MlpFinArgs of mlp_fin.h)
+void kasf_launch_mlp_dgrad_fin(hipStream_t s, const void* dZ, const void* W1t, const void* X, const float* gamma, const void* g, void* g_in, float* dgamma, float* dbeta,
+                               float* gsum, int64_t M, KasfColSink* sink, const void* fin_args, const float* b2, const float* ls2, float* dls2, bool have_w2);
 struct KasfBf16Reduce { const void* part; float* out; int nparts; int elems; };
 bool kasf_dgrad_wg_supported(int Kd, bool resid, bool accumulate, bool dxn_add, bool dbias, bool proj, int64_t M, int64_t wpart_bytes);
 int kasf_launch_dgrad_wg(hipStream_t s, const void* dY, int Kd, const void* Wt, const void* X, const float* gamma, const float* beta, const void* resid, void* out,

@@ -207,3 +207,35 @@ def test_fused_attention_backward_matches_oracle(L, T, B):
     tol = 0.04 if B * T >= 900 else 0.35
     bad = sorted(((v, k) for k, v in rep["errors"].items() if not v < tol), reverse=True)
     assert not bad, f"{len(bad)} gradients above {tol}; worst (err, name): {bad[:12]}"
+
+
+_DZ_CHILD = """
+import sys, torch
+from tests.test_gpu_determinism import _three_runs
+T, B, path = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+runs = _three_runs("bf16", T, B)
+assert torch.equal(runs[0][2], runs[1][2]) and torch.equal(runs[0][2], runs[2][2]), "the dZ form does not reproduce itself"
+torch.save({"pred": runs[0][0].cpu(), "grad": runs[0][2].cpu(), "buffers": runs[0][3].cpu()}, path)
+"""
+
+
+@pytest.mark.parametrize("T,B", [(27, 8), (27, 96)])          # 96 clips: 44,064 tokens, several tiles per token range and the half-chip grid class
+def test_mlp_backward_dz_form_agrees_with_the_partial_sum_form(T, B, tmp_path):
+    """KASF_MLP_BWD_DZ=1 (read once per process, hence the child process): k_mlp_bwd_s<DZOUT> stores dZ and k_dgrad_r<4, ..., MLPFIN> forms dA = dZ W1 + the
+    LayerNorm backward, instead of four bf16 dA partials summed by k_lnbwd_sum4_fin.  Same products, one bf16 rounding of dA fewer: not the same bits, the same
+    gradients far inside the bf16 bars, and bit-reproducible."""
+    import subprocess
+    import sys
+    path = str(tmp_path / "dz.pt")
+    env = dict(os.environ, KASF_MLP_BWD_DZ="1")
+    r = subprocess.run([sys.executable, "-c", _DZ_CHILD, str(T), str(B), path], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    a = torch.load(path, weights_only=True)
+    b = _three_runs("bf16", T, B)
+    assert torch.equal(a["pred"], b[0][0].cpu()) and torch.equal(a["buffers"], b[0][3].cpu())
+    ga, gb = a["grad"].double(), b[0][2].cpu().double()
+    assert not torch.equal(ga, gb), "the switch did not change the path"
+    cos = float((ga * gb).sum() / (ga.norm() * gb.norm()))
+    rel = float((ga - gb).abs().max() / gb.abs().max())
+    print(f"[MLP backward dZ form vs partial sums, T = {T}, B = {B}] cosine {cos:.8f}, max |diff| / max |g| {rel:.3e}")
+    assert cos > 0.9999 and rel < 2e-2, (cos, rel)
