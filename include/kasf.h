@@ -181,7 +181,8 @@ int kasf_op_mlp_bwd(int32_t dtype, const void* x, const void* g, const float* ln
                     const void* w2t_scaled, const void* w1t, void* hbuf, void* dzbuf, void* g_in, float* dgamma, float* dbeta, int64_t M, void* stream);
 /* bf16 only: fused MLP backward (hidden-quarter ownership, weights in registers): data gradient AND both weight gradients.
  * g_in = g + LNbwd(dA); dw1 [512,128] += dZ^T LN(x); db1 [512] += colsum(dZ); dw2_unscaled [128,512] += g^T H;
- * gsum [128] += colsum(g); dgamma/dbeta += LayerNorm parameter gradients.  dapart: 4*M*128 elements of scratch (bf16);
+ * gsum [128] += colsum(g); dgamma/dbeta += LayerNorm parameter gradients.  dapart: 4*M*128 elements of scratch (bf16: the four hidden quarters' dA partials;
+ * with KASF_MLP_BWD_DZ=1 in the environment, dZ [M,512] in the same bytes);
  * partial: >= 2*64*65536 + 2048 floats of scratch (the tail holds the inter-workgroup hand-off flags; word 2*64*65536 + 1024 is set to 1 if a
  * bounded wait ran out). */
 int kasf_op_mlp_bwd_fused(const void* x, const void* xn /* LN(x) from kasf_op_mlp_fwd */, const void* g, const float* ln_g, const void* w1, const float* b1, const void* w2t_scaled,
