@@ -1,3 +1,6 @@
+"""Phase timers of k_attn_bwd_kt (temporal attention backward at T = 81, B = 128) through the operator entry point: the library built with -DKT_PROF prints clock64
+differences per phase for workgroups 777 and 2000, waves 0 and 3.   make -C kasportsformer_amd/csrc BUILD=build_ktprof LIB=../libkasf_hip_prof.so EXTRA=-DKT_PROF ;
+KASF_LIB=$PWD/kasportsformer_amd/libkasf_hip_prof.so python tools/kt_prof.py   (profiles/r6_kt_phase_timers.txt)"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.getcwd())
 import torch
