@@ -20,6 +20,8 @@ namespace {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 constexpr int AB_THR = 512, AB_TILE = 32 * 128;
+constexpr int AB_HPAD = 16;                        // bf16 elements between the heads' q | k | v tile images (32 bytes: the 8 heads' images 32 bytes apart modulo the 256 bytes
+                                                   // of an LDS read cycle -- the row copy-out reads 16 lanes = 8 heads x 2 halves)
 constexpr int RP3_PAD = 16;                        // bf16 elements between the heads' q | k | v tile images of k_attn_blk_fwd_rp3
 
 __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
@@ -83,14 +85,14 @@ struct AttnBlkArgs {
 #endif
 template <bool BONE>
 __global__ __launch_bounds__(AB_THR, BONE ? KASF_RP_BONE_WAVES : 4) void k_attn_blk_fwd_rp(const AttnBlkArgs a) {
-    constexpr int NS = BONE ? 2 : 1;
+    constexpr int NS = BONE ? 2 : 1, WS = 3 * 512 + AB_HPAD;       // WS: one wave's q | k | v tiles + 32 bytes (see AB_HPAD)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* sX = reinterpret_cast<bf16*>(smem);           // [32][128] raw x (the residual's operand)
     bf16* sA = sX + AB_TILE;                            // [NS][32][128] LN(x) (| LN_limb(x_limb))
     bf16* sO = sA + NS * AB_TILE;                       // [32][128] attention output of the 8 heads
     bf16* sOut = sO + AB_TILE;                          // [32][128] x_mid
     bf16* sHead = sOut + AB_TILE;                       // [8 waves][q | k | v][32][16] wave-private operand tiles
-    float* sLn = reinterpret_cast<float*>(sHead + 8 * 3 * 512);      // [6][128] gamma, beta, limb gamma, beta, proj bias, ls1
+    float* sLn = reinterpret_cast<float*>(sHead + 8 * WS);           // [6][128] gamma, beta, limb gamma, beta, proj bias, ls1
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4, sub = lane & 15, rl = threadIdx.x >> 4;
     const int r32 = lane & 31, hh = lane >> 5;
     const int L = a.L;
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(AB_THR, BONE ? KASF_RP_BONE_WAVES : 4) void k_attn_
     int ng = a.groups - g0;
     if (ng > per) ng = per;
     if (ng <= 0) return;
-    bf16* sQh = sHead + w * 3 * 512;
+    bf16* sQh = sHead + w * WS;
     bf16* sKh = sQh + 512;
     bf16* sVh = sKh + 512;
     bf16x8 wq[3][4], wp[4];
@@ -228,19 +230,6 @@ __global__ __launch_bounds__(AB_THR, BONE ? KASF_RP_BONE_WAVES : 4) void k_attn_
         RQ(2);
         const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sKh + r32 * 16 + 8 * hh);
         const bf16x8 qf = *reinterpret_cast<const bf16x8*>(sQh + r32 * 16 + 8 * hh);
-        if (a.Qs != nullptr && r32 < L) {   // training: the backward pass reads q | k | v; each lane stores the 16 bytes it is about to use as an operand
-            const unsigned tok = (unsigned)(base_of(G) + r32 * stride);
-            const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sVh + r32 * 16 + 8 * hh);
-            if (BONE) {
-                *reinterpret_cast<bf16x8*>(a.Qs + (size_t)(tok * 128u + 16 * w + 8 * hh)) = qf;
-                *reinterpret_cast<bf16x8*>(a.KVs + (size_t)(tok * 256u + 16 * w + 8 * hh)) = kf;
-                *reinterpret_cast<bf16x8*>(a.KVs + (size_t)(tok * 256u + 128 + 16 * w + 8 * hh)) = vf;
-            } else {
-                *reinterpret_cast<bf16x8*>(a.Qs + (size_t)(tok * 384u + 16 * w + 8 * hh)) = qf;
-                *reinterpret_cast<bf16x8*>(a.Qs + (size_t)(tok * 384u + 128 + 16 * w + 8 * hh)) = kf;
-                *reinterpret_cast<bf16x8*>(a.Qs + (size_t)(tok * 384u + 256 + 16 * w + 8 * hh)) = vf;
-            }
-        }
         RQ(3);
         {   // ---- attention core of head w (k_attn_mfma.hip, one 32x32 score tile) ----
             f32x16 z;
@@ -298,6 +287,32 @@ __global__ __launch_bounds__(AB_THR, BONE ? KASF_RP_BONE_WAVES : 4) void k_attn_
             const int co = Tile<bf16>::chunk_off(rl, sub);
             *reinterpret_cast<f32x4*>(a.OUT + (size_t)(tok * 128u + sub * 8)) = *reinterpret_cast<const f32x4*>(sOut + co);
             if (a.Qs != nullptr) *reinterpret_cast<f32x4*>(a.Os + (size_t)(tok * 128u + sub * 8)) = *reinterpret_cast<const f32x4*>(sO + co);
+            if (BONE && a.Qs != nullptr)
+                *reinterpret_cast<f32x4*>(a.Qs + (size_t)(tok * 128u + sub * 8)) = *reinterpret_cast<const f32x4*>(sHead + (sub >> 1) * WS + rl * 16 + 8 * (sub & 1));
+        }
+        if (a.Qs != nullptr) {   // training: the backward pass reads q | k | v.  Round 6: whole rows, thread = (position, 16-byte chunk), out of the heads' tiles (complete since
+            // B2, untouched until the next group's projections behind B1) -- rounds 2-5: each lane stored the 16 bytes it was about to use as an operand, 32-byte slices per head.
+            if (BONE) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int idx = (int)threadIdx.x + AB_THR * k, row = idx >> 5, c = idx & 31, part = 1 + (c >> 4), ch = c & 15;
+                    if (row < L) {
+                        const unsigned tok = (unsigned)(base_of(G) + row * stride);
+                        *reinterpret_cast<f32x4*>(a.KVs + (size_t)(tok * 256u + c * 8)) = *reinterpret_cast<const f32x4*>(sHead + (ch >> 1) * WS + part * 512 + row * 16 + 8 * (ch & 1));
+                    }
+                }
+            } else {
+                int tx = (int)threadIdx.x;
+                asm volatile("" : "+v"(tx));             // the chunk addresses are formed here, not kept in registers across the loop (128-VGPR cap of two workgroups per CU)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int idx = tx + AB_THR * k, row = idx / 48, c = idx - row * 48, part = c >> 4, ch = c & 15;
+                    if (row < L) {
+                        const unsigned tok = (unsigned)(base_of(G) + row * stride);
+                        *reinterpret_cast<f32x4*>(a.Qs + (size_t)(tok * 384u + c * 8)) = *reinterpret_cast<const f32x4*>(sHead + (ch >> 1) * WS + part * 512 + row * 16 + 8 * (ch & 1));
+                    }
+                }
+            }
         }
         RQ(7);
     }
@@ -320,13 +335,13 @@ __global__ __launch_bounds__(AB_THR, BONE ? KASF_RP_BONE_WAVES : 4) void k_attn_
 // ---------------------------------------------------------------------------------------------------------------
 template <bool BONE>
 __global__ __launch_bounds__(AB_THR, BONE ? KASF_RP_BONE_WAVES : 4) void k_attn_blk_fwd_flat(const AttnBlkArgs a) {
-    constexpr int NS = BONE ? 2 : 1, J = KASF_J, HB = 48, HT = HB * 16;
+    constexpr int NS = BONE ? 2 : 1, J = KASF_J, HB = 48, HT = HB * 16, WS = 3 * HT + AB_HPAD;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* sX = reinterpret_cast<bf16*>(smem);           // [2][32][128] raw x, by tile parity
     bf16* sA = sX + 2 * AB_TILE;                        // [NS][32][128] LN(x) (| LN_limb(x_limb)); sA[0] doubles as the x_mid staging tile
     bf16* sO = sA + NS * AB_TILE;                       // [2][32][128] attention output of the 8 heads, by tile parity (row p at p & 63)
     bf16* sHead = sO + 2 * AB_TILE;                     // [8 waves][q | k | v][48][16] wave-private rolling operand tiles
-    float* sLn = reinterpret_cast<float*>(sHead + 8 * 3 * HT);       // [6][128] gamma, beta, limb gamma, beta, proj bias, ls1
+    float* sLn = reinterpret_cast<float*>(sHead + 8 * WS);           // [6][128] gamma, beta, limb gamma, beta, proj bias, ls1
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4, sub = lane & 15, rl = threadIdx.x >> 4;
     const int r32 = lane & 31, hh = lane >> 5;
     const int per = (a.groups + gridDim.x - 1) / gridDim.x;
@@ -336,7 +351,7 @@ __global__ __launch_bounds__(AB_THR, BONE ? KASF_RP_BONE_WAVES : 4) void k_attn_
     if (nf <= 0) return;
     const int nrows = J * nf, ntiles = (nrows + 31) >> 5;
     const unsigned tok0 = (unsigned)f0 * J;
-    bf16* sQh = sHead + w * 3 * HT;
+    bf16* sQh = sHead + w * WS;
     bf16* sKh = sQh + HT;
     bf16* sVh = sKh + HT;
     bf16x8 wq[3][4], wp[4];
@@ -505,23 +520,6 @@ __global__ __launch_bounds__(AB_THR, BONE ? KASF_RP_BONE_WAVES : 4) void k_attn_
                     }
             }
             lds_fence();
-            const int r32 = lv & 31, hh = lv >> 5;
-            if (a.Qs != nullptr && 32 * t + r32 < nrows) {   // training: the backward pass reads q | k | v; lane (r32, hh) stores 16 bytes of token 32 t + r32
-                const unsigned tok = tok0 + (unsigned)(32 * t + r32);
-                const int hr = (blk(r32 >> 4) + (r32 & 15)) * 16 + 8 * hh;
-                const bf16x8 qf = *reinterpret_cast<const bf16x8*>(sQh + hr);
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sKh + hr);
-                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sVh + hr);
-                if (BONE) {
-                    *reinterpret_cast<bf16x8*>(a.Qs + (size_t)(tok * 128u + 16 * w + 8 * hh)) = qf;
-                    *reinterpret_cast<bf16x8*>(a.KVs + (size_t)(tok * 256u + 16 * w + 8 * hh)) = kf;
-                    *reinterpret_cast<bf16x8*>(a.KVs + (size_t)(tok * 256u + 128 + 16 * w + 8 * hh)) = vf;
-                } else {
-                    *reinterpret_cast<bf16x8*>(a.Qs + (size_t)(tok * 384u + 16 * w + 8 * hh)) = qf;
-                    *reinterpret_cast<bf16x8*>(a.Qs + (size_t)(tok * 384u + 128 + 16 * w + 8 * hh)) = kf;
-                    *reinterpret_cast<bf16x8*>(a.Qs + (size_t)(tok * 384u + 256 + 16 * w + 8 * hh)) = vf;
-                }
-            }
             while (nfr < nf && J * (nfr + 1) <= 32 * (t + 1)) {      // every frame that ends inside this tile (uniform: one or two)
                 core(nfr, sm, lv);
                 ++nfr;
@@ -557,6 +555,34 @@ __global__ __launch_bounds__(AB_THR, BONE ? KASF_RP_BONE_WAVES : 4) void k_attn_
             const int co = Tile<bf16>::chunk_off(rl, sub);
             *reinterpret_cast<f32x4*>(a.OUT + (size_t)(tok * 128u + sub * 8)) = *reinterpret_cast<const f32x4*>(sA + co);
             if (a.Qs != nullptr) *reinterpret_cast<f32x4*>(a.Os + (size_t)(tok * 128u + sub * 8)) = *reinterpret_cast<const f32x4*>(sO + (par ^ 1) * AB_TILE + co);
+        }
+        if (a.Qs != nullptr && t < ntiles) {   // training: the backward pass reads q | k | v.  Round 6: the rows of tile t leave as whole rows, thread = (token, 16-byte chunk), out of
+            // the heads' rolling tiles (complete since B2; tile t + 1's projections, behind the next B1, overwrite tile t's first 16-row block) -- rounds 4-5: 32-byte slices per head.
+            const int hb = (2 * t) % 3;
+            auto rrow = [&](int r) { const int b = hb + (r >> 4); return (b >= 3 ? b - 3 : b) * 16 + (r & 15); };      // rolling row of the tile's row r
+            if (BONE) {
+                if (32 * t + rl < nrows) {
+                    const unsigned tok = tok0 + (unsigned)(32 * t + rl);
+                    *reinterpret_cast<f32x4*>(a.Qs + (size_t)(tok * 128u + sub * 8)) = *reinterpret_cast<const f32x4*>(sHead + (sub >> 1) * WS + rrow(rl) * 16 + 8 * (sub & 1));
+                }
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int idx = 64 * w + lv + AB_THR * k, row = idx >> 5, c = idx & 31, part = 1 + (c >> 4), ch = c & 15;
+                    if (32 * t + row < nrows) {
+                        const unsigned tok = tok0 + (unsigned)(32 * t + row);
+                        *reinterpret_cast<f32x4*>(a.KVs + (size_t)(tok * 256u + c * 8)) = *reinterpret_cast<const f32x4*>(sHead + (ch >> 1) * WS + part * HT + rrow(row) * 16 + 8 * (ch & 1));
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int idx = 64 * w + lv + AB_THR * k, row = idx / 48, c = idx - row * 48, part = c >> 4, ch = c & 15;
+                    if (32 * t + row < nrows) {
+                        const unsigned tok = tok0 + (unsigned)(32 * t + row);
+                        *reinterpret_cast<f32x4*>(a.Qs + (size_t)(tok * 384u + c * 8)) = *reinterpret_cast<const f32x4*>(sHead + (ch >> 1) * WS + part * HT + rrow(row) * 16 + 8 * (ch & 1));
+                    }
+                }
+            }
         }
     }
 }
@@ -868,7 +894,7 @@ bool kasf_launch_attn_block_fwd(hipStream_t s, int bone, const void* x, const vo
     if (mode == 0) {                                    // the 17 joints of a frame: flat 32-token tiles over consecutive frames
         const int want = (a.groups + 1) / 2;            // >= 2 frames per workgroup (a lone frame would pay a whole tile + the lagging iteration)
         const unsigned grid = (unsigned)(want < cap ? (want < 1 ? 1 : want) : cap);
-        const size_t sh = (size_t)(2 + ns + 2) * AB_TILE * 2 + (size_t)8 * 3 * 48 * 16 * 2 + 6 * 128 * 4;
+        const size_t sh = (size_t)(2 + ns + 2) * AB_TILE * 2 + (size_t)8 * (3 * 48 * 16 + AB_HPAD) * 2 + 6 * 128 * 4;
         if (bone) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_blk_fwd_flat<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
             hipLaunchKernelGGL(k_attn_blk_fwd_flat<true>, dim3(grid), dim3(AB_THR), sh, s, a);
@@ -880,7 +906,7 @@ bool kasf_launch_attn_block_fwd(hipStream_t s, int bone, const void* x, const vo
     }
 #endif
     const unsigned grid = (unsigned)(a.groups < cap ? a.groups : cap);
-    const size_t sh = (size_t)(1 + ns + 1 + 1) * AB_TILE * 2 + 8 * 3 * 512 * 2 + 6 * 128 * 4;
+    const size_t sh = (size_t)(1 + ns + 1 + 1) * AB_TILE * 2 + 8 * (3 * 512 + AB_HPAD) * 2 + 6 * 128 * 4;
     if (bone) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_blk_fwd_rp<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
         hipLaunchKernelGGL(k_attn_blk_fwd_rp<true>, dim3(grid), dim3(AB_THR), sh, s, a);
