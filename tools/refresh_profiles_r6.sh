@@ -1,4 +1,5 @@
 #!/bin/bash
+# Before the gpurun call: `git rev-parse HEAD > .git_rev` (the box has no .git; the stamps quote that file as information -- the sha256 of the sources is what is checked).
 # ONE GPU-box pass that regenerates the round-6 evidence under gpurun_out/r6/ (copy into profiles/ afterwards: the names match).
 # Order matters: the traces and counter passes come first and are copied into the box's profiles/ so that the bench line at the end quotes THIS build's
 # numbers.  Any failed trace aborts the pass (the round-3 script only echoed and went on, so a stale file could have ended up in a "final build" set).
