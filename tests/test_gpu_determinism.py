@@ -219,7 +219,7 @@ torch.save({"pred": runs[0][0].cpu(), "grad": runs[0][2].cpu(), "buffers": runs[
 """
 
 
-@pytest.mark.parametrize("T,B", [(27, 8), (27, 96)])          # 96 clips: 44,064 tokens, several tiles per token range and the half-chip grid class
+@pytest.mark.parametrize("T,B", [(27, 8), (27, 96), (27, 256)])          # 96 clips: 44,064 tokens, several tiles per token range; 256: the benchmark's 117,504 tokens (57 tiles per range, half-chip grids)
 def test_mlp_backward_dz_form_agrees_with_the_partial_sum_form(T, B, tmp_path):
     """KASF_MLP_BWD_DZ=1 (read once per process, hence the child process): k_mlp_bwd_s<DZOUT> stores dZ and k_dgrad_r<4, ..., MLPFIN> forms dA = dZ W1 + the
     LayerNorm backward, instead of four bf16 dA partials summed by k_lnbwd_sum4_fin.  Same products, one bf16 rounding of dA fewer: not the same bits, the same
