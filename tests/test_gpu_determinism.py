@@ -9,7 +9,7 @@ and fixed trees instead of LDS atomics; the loss kernel has no atomics.  The onl
 And one thing that had nothing to do with summation order: hipcc's SLP vectoriser turned the scalar BatchNorm-backward arithmetic of k_gcn_bwd2_* into
 packed-fp32 instructions (v_pk_add_f32 / v_pk_mul_f32 with op_sel broadcasts out of register pairs), and those produced slightly different values
 -- fp32-ulp-sized changes of a per-node mean, from identical inputs -- whenever MFMA-heavy kernels of the other two branch streams were co-resident
-on the SIMD.  Bisected with tools/det_probe*.py (first differing tensor = that kernel's output, inputs bit-identical; needs the attention mixers in
+on the SIMD.  Bisected with the round-4 probe scripts (tools/det_probe*.py, deleted in round 6; the record is in HISTORY.md) (first differing tensor = that kernel's output, inputs bit-identical; needs the attention mixers in
 flight; immune to fences, scoped loads and returning atomics; gone with -fno-slp-vectorize, which the whole library is now built with at no
 measurable cost).  The hand-written packed GELU of the MLP kernels (explicit two-float vectors, no op_sel) was never affected."""
 import os
