@@ -136,7 +136,7 @@ TRAFFIC_FILE = _profile("pmc_traffic.json")            # tools/pmc_traffic.py (t
 IN_STEP_STATS = _profile("train_kernel_stats.csv")     # rocprofv3 --kernel-trace --stats of tools/train_once.py 27 256 (three streams overlap)
 ISOLATED_STATS = _profile("single_stream_kernel_stats.csv")   # the same steps with the three branches on ONE stream (tools/prof27.sh): every launch alone on the chip
 ISOLATED_FULL_STATS = _profile("single_stream_fullwidth_kernel_stats.csv")   # ... with every persistent launch at its full grid (KASF_NARROW_PCTS=100,...): comparable with rounds 1-3
-MLP_HALF_CHIP_BELOW = 150000                           # tokens (csrc/kernels.h: kasf_narrow_grid): below it an MLP launch of the engine takes 128 of the 256 CUs
+MLP_HALF_CHIP_BELOW = 1 << 40                          # tokens (csrc/kernels.h: kasf_narrow_grid, KASF_HALF_CHIP_ALWAYS since round 6): an MLP launch of the engine takes 128 of the 256 CUs
 STEP_TRAFFIC_FILE = _profile("pmc_step.json")          # tools/pmc_step.sh: FETCH_SIZE / WRITE_SIZE summed over whole training steps
 TRAFFIC_PARTS = {"k_mlp_fwd_s": {"k_mlp_fwd_s": 1}, "k_mlp_bwd_s(+lnbwd_sum4_fin)": {"k_mlp_bwd_s": 1, "k_lnbwd_sum4_fin": 1}}
 

@@ -800,7 +800,7 @@ static inline int side_index(int br, int mainbr) { return br < mainbr ? br : br 
 
 int kasf_forward(const kasf_model* m, const float* params, const void* packed, float* buffers, const float* x, float* out, void* workspace,
                  int64_t workspace_bytes, int32_t batch, int32_t flags, void* stream) {
-    struct ModelPath { ModelPath() { kasf_tls_model_path = 1; } ~ModelPath() { kasf_tls_model_path = 0; } } model_path;      // grid widths of the persistent launches (kernels.h)
+    struct ModelPath { explicit ModelPath(int v) { kasf_tls_model_path = v; } ~ModelPath() { kasf_tls_model_path = 0; } } model_path((flags & (KASF_FLAG_TRAIN | KASF_FLAG_KEEP)) != 0 ? 1 : 2);      // grid widths of the persistent launches (kernels.h): 1 training step, 2 forward only
     if (check_model(m)) return 2;
     if (!params || !packed || !buffers || !x || !out || !workspace) return kasf_set_error(2, "null pointer argument");
     if (m->d_pro == nullptr) return kasf_set_error(4, "layout-only model cannot run");

@@ -177,14 +177,18 @@ void kasf_launch_gather_clips(hipStream_t s, const float* xa, const float* ya, c
 // worse: the branches are not equally long).  The LDS-ring linear kernels do the same below 80,000 tokens (more tiles per workgroup per fill), the data-gradient kernels
 // below 150,000 since round 5 (tools/width_sweep.sh, B = 256: 4,617-4,658 clips/s at 50 %, 4,633-4,649 at 66 %, 4,560-4,642 at the full grid on the same boxes; in round 4 it cost 1.5 % there).  The widths are a function of the token count only -- never of the stream mode -- so results stay bit-identical between the one-stream
 // and three-stream engines; the operator entry points (tests, bench.py's hot loop) launch at full width.
+// Round 6: rounds 4-5 stopped at 150,000 tokens (T = 81, B = 128 = 176,256 tokens measured -0.4 % with the round-4 kernels).  Re-measured after this round's kernel changes, MLP
+// forward / backward / data gradient at half width against the full grid: T = 81 B = 128: 1,514-1,518 against 1,456-1,486 clips/s; T = 27 B = 384: 4,754 / 4,758 against 4,614 / 4,622;
+// T = 27 B = 512: 4,860 / 4,840 against 4,730 / 4,740; T = 81 B = 256 (352,512 tokens): 1,566 / 1,565 against 1,551 / 1,548 -- half the chip at every size (the linear class keeps 80,000).
 // KASF_NARROW_PCTS = "fwd,bwd,dgrad,linear,attn_fwd,attn_bwd,wgrad" (percent of the full grid) and KASF_NARROW_BELOW = tokens override the table: measurement knobs.
 #include <cstdlib>
 #include <cstdint>
+constexpr int64_t KASF_HALF_CHIP_ALWAYS = int64_t(1) << 40;
 enum { KASF_NG_MLP_FWD = 0, KASF_NG_MLP_BWD = 1, KASF_NG_DGRAD = 2, KASF_NG_LINEAR = 3, KASF_NG_ATTN_FWD = 4, KASF_NG_ATTN_BWD = 5, KASF_NG_WGRAD = 6 };
-inline thread_local int kasf_tls_model_path = 0;        // 1 while the engine's forward / backward is enqueueing (engine.hip)
+inline thread_local int kasf_tls_model_path = 0;        // while the engine is enqueueing (engine.hip): 1 a training step's forward / backward, 2 a forward-only (evaluation) pass
 inline int kasf_narrow_grid(int cls, int full, int64_t tokens) {
     static int pcts[7] = {-1, 0, 0, 0, 0, 0, 0};
-    static int64_t below[7] = {150000, 150000, 150000, 80000, 0, 0, 0};      // (round 5: the data-gradient kernels too below 150,000 tokens: +0.7 % at B = 256 with this round's kernels; -1.5 % in round 4)
+    static int64_t below[7] = {KASF_HALF_CHIP_ALWAYS, KASF_HALF_CHIP_ALWAYS, KASF_HALF_CHIP_ALWAYS, 80000, 0, 0, 0};      // (round 5: the data-gradient kernels too below 150,000 tokens: +0.7 % at B = 256 with this round's kernels; -1.5 % in round 4)
     if (pcts[0] < 0) {
         const int def[7] = {50, 50, 50, 50, 100, 100, 100};
         int tmp[7];
@@ -193,7 +197,8 @@ inline int kasf_narrow_grid(int cls, int full, int64_t tokens) {
         if (const char* e = getenv("KASF_NARROW_BELOW")) for (int k = 0; k < 7; ++k) below[k] = atoll(e);
         for (int k = 6; k >= 0; --k) pcts[k] = tmp[k];   // pcts[0] last: the table is complete when another thread sees it set
     }
-    if (!kasf_tls_model_path || tokens >= below[cls]) return full;
+    if (!kasf_tls_model_path || tokens >= (kasf_tls_model_path == 2 && below[cls] == KASF_HALF_CHIP_ALWAYS ? int64_t(150000) : below[cls])) return full;     // forward-only passes keep the
+                                                                       // 150,000-token threshold: B = 2,048 evaluation 19,322 / 19,365 clips/s at half width against 19,818 / 19,668 at the full grid, B = 512 even
     const int g = full * pcts[cls] / 100;
     return g < 1 ? 1 : g;
 }

@@ -155,7 +155,7 @@ def test_backward_matches_oracle(cd, tol, L, T, B):
 @pytest.mark.parametrize("T,B", [(27, 256), (81, 128)])          # BASELINE.json configs[1] and configs[3] (KASportsFormer.py:320-347, configs/sportspose-gt-kasportsformer.yaml:61,67)
 def test_backward_matches_oracle_at_benchmark_shapes(T, B):
     """The ENGINE against the oracle at the benchmark's own token counts (one layer, bf16): 117,504 / 176,256 tokens put every persistent launch in its
-    full-width grid class (>= 150,000 tokens at T = 81; the half-chip class at T = 27), give the MLP ranges >= 50 tiles and run k_attn_bwd_kt / the fused
+    grid classes of the persistent launches at these token counts (half the chip for the MLP / data-gradient launches), give the MLP ranges >= 50 tiles and run k_attn_bwd_kt / the fused
     attention-block backward over the whole batch -- regimes the smaller oracle cases above never reach (missing #2)."""
     import psutil
     if psutil.virtual_memory().available < 24 * 2**30:
